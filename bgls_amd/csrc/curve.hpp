@@ -1,0 +1,223 @@
+// G1 / G2 group arithmetic (short Weierstrass, a = 0), generic over the coordinate field.
+//
+// Reference operations served: Point.Add (curves/altbn128.go:59-66,181-188;
+// curves/bls12_381.go:33-41,94-102), Point.Mul incl. Mul(-1) negation (altbn128.go:107-128,
+// 235-249; bls12_381.go:65-83,126-137), AggregatePoints (curves/curve.go:73-121),
+// ScalePoints (curves/curve.go:190-214), the G1 cofactor multiplication inside BLS12-381
+// hash-to-G1 (curves/hash.go:91).  The upstream libraries' internals are absent, so the
+// formulas are the standard Jacobian ones (dbl-2009-l, madd-2007-bl, add-2007-bl) with the
+// exceptional cases handled explicitly: affine results are unique, hence bit-identical.
+#pragma once
+#include "tower.hpp"
+
+namespace bgls {
+
+template <class C>
+struct F1 {  // coordinate field of G1
+  typedef Fp<C> T;
+  static BGLS_HD T zero() { return fp_zero<C>(); }
+  static BGLS_HD T one() { return fp_one<C>(); }
+  static BGLS_HD T add(const T& a, const T& b) { return fp_add<C>(a, b); }
+  static BGLS_HD T sub(const T& a, const T& b) { return fp_sub<C>(a, b); }
+  static BGLS_HD T neg(const T& a) { return fp_neg<C>(a); }
+  static BGLS_HD T dbl(const T& a) { return fp_dbl<C>(a); }
+  static BGLS_HD T mul(const T& a, const T& b) { return fp_mul<C>(a, b); }
+  static BGLS_HD T sqr(const T& a) { return fp_sqr<C>(a); }
+  static BGLS_HD T inv(const T& a) { return fp_inv<C>(a); }
+  static BGLS_HD bool is_zero(const T& a) { return fp_is_zero<C>(a); }
+  static BGLS_HD bool eq(const T& a, const T& b) { return fp_eq<C>(a, b); }
+  static BGLS_HD T select(bool c, const T& a, const T& b) { return fp_select<C>(c, a, b); }
+  static BGLS_HD T curve_b() { return fp_load<C>(C::B); }
+  static constexpr int NFP = 1;
+};
+
+template <class C>
+struct F2 {  // coordinate field of G2 (the twist)
+  typedef Fp2<C> T;
+  static BGLS_HD T zero() { return f2_zero<C>(); }
+  static BGLS_HD T one() { return f2_one<C>(); }
+  static BGLS_HD T add(const T& a, const T& b) { return f2_add<C>(a, b); }
+  static BGLS_HD T sub(const T& a, const T& b) { return f2_sub<C>(a, b); }
+  static BGLS_HD T neg(const T& a) { return f2_neg<C>(a); }
+  static BGLS_HD T dbl(const T& a) { return f2_dbl<C>(a); }
+  static BGLS_HD T mul(const T& a, const T& b) { return f2_mul<C>(a, b); }
+  static BGLS_HD T sqr(const T& a) { return f2_sqr<C>(a); }
+  static BGLS_HD T inv(const T& a) { return f2_inv<C>(a); }
+  static BGLS_HD bool is_zero(const T& a) { return f2_is_zero<C>(a); }
+  static BGLS_HD bool eq(const T& a, const T& b) { return f2_eq<C>(a, b); }
+  static BGLS_HD T select(bool c, const T& a, const T& b) { return f2_select<C>(c, a, b); }
+  static BGLS_HD T curve_b() { return {fp_load<C>(C::B2_RE), fp_load<C>(C::B2_IM)}; }
+  static constexpr int NFP = 2;
+};
+
+template <class F>
+struct Aff {
+  typename F::T x, y;
+  bool inf;
+};
+template <class F>
+struct Jac {
+  typename F::T X, Y, Z;  // Z == 0  <=>  infinity
+};
+
+template <class F>
+BGLS_HD Jac<F> jac_inf() {
+  return {F::one(), F::one(), F::zero()};
+}
+template <class F>
+BGLS_HD Jac<F> jac_from_aff(const Aff<F>& a) {
+  if (a.inf) return jac_inf<F>();
+  return {a.x, a.y, F::one()};
+}
+template <class F>
+BGLS_HD bool jac_is_inf(const Jac<F>& p) {
+  return F::is_zero(p.Z);
+}
+
+template <class F>
+BGLS_HD bool aff_on_curve(const Aff<F>& a) {
+  if (a.inf) return true;
+  typename F::T l = F::sqr(a.y);
+  typename F::T r = F::add(F::mul(F::sqr(a.x), a.x), F::curve_b());
+  return F::eq(l, r);
+}
+
+template <class F>
+BGLS_FN Jac<F> jac_dbl(const Jac<F>& p) {
+  typedef typename F::T T;
+  T A = F::sqr(p.X);
+  T B = F::sqr(p.Y);
+  T Cc = F::sqr(B);
+  T D = F::sub(F::sub(F::sqr(F::add(p.X, B)), A), Cc);
+  D = F::dbl(D);
+  T E = F::add(F::dbl(A), A);
+  T Fv = F::sqr(E);
+  T X3 = F::sub(Fv, F::dbl(D));
+  T C8 = F::dbl(F::dbl(F::dbl(Cc)));
+  T Y3 = F::sub(F::mul(E, F::sub(D, X3)), C8);
+  T Z3 = F::dbl(F::mul(p.Y, p.Z));
+  return {X3, Y3, Z3};
+}
+
+// Jacobian + affine
+template <class F>
+BGLS_FN Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
+  typedef typename F::T T;
+  if (q.inf) return p;
+  if (jac_is_inf<F>(p)) return {q.x, q.y, F::one()};
+  T Z1Z1 = F::sqr(p.Z);
+  T U2 = F::mul(q.x, Z1Z1);
+  T S2 = F::mul(F::mul(q.y, p.Z), Z1Z1);
+  T H = F::sub(U2, p.X);
+  T rr = F::sub(S2, p.Y);
+  if (F::is_zero(H)) {
+    if (F::is_zero(rr)) return jac_dbl<F>(p);
+    return jac_inf<F>();
+  }
+  rr = F::dbl(rr);
+  T HH = F::sqr(H);
+  T I = F::dbl(F::dbl(HH));
+  T J = F::mul(H, I);
+  T V = F::mul(p.X, I);
+  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
+  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(p.Y, J)));
+  T Z3 = F::sub(F::sub(F::sqr(F::add(p.Z, H)), Z1Z1), HH);
+  return {X3, Y3, Z3};
+}
+
+// Jacobian + Jacobian
+template <class F>
+BGLS_FN Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+  typedef typename F::T T;
+  if (jac_is_inf<F>(p)) return q;
+  if (jac_is_inf<F>(q)) return p;
+  T Z1Z1 = F::sqr(p.Z);
+  T Z2Z2 = F::sqr(q.Z);
+  T U1 = F::mul(p.X, Z2Z2);
+  T U2 = F::mul(q.X, Z1Z1);
+  T S1 = F::mul(F::mul(p.Y, q.Z), Z2Z2);
+  T S2 = F::mul(F::mul(q.Y, p.Z), Z1Z1);
+  T H = F::sub(U2, U1);
+  T rr = F::sub(S2, S1);
+  if (F::is_zero(H)) {
+    if (F::is_zero(rr)) return jac_dbl<F>(p);
+    return jac_inf<F>();
+  }
+  rr = F::dbl(rr);
+  T I = F::sqr(F::dbl(H));
+  T J = F::mul(H, I);
+  T V = F::mul(U1, I);
+  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
+  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(S1, J)));
+  T Z3 = F::mul(F::sub(F::sub(F::sqr(F::add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+  return {X3, Y3, Z3};
+}
+
+template <class F>
+BGLS_FN Aff<F> jac_to_aff(const Jac<F>& p) {
+  typedef typename F::T T;
+  if (jac_is_inf<F>(p)) return {F::zero(), F::zero(), true};
+  T zi = F::inv(p.Z);
+  T zi2 = F::sqr(zi);
+  return {F::mul(p.X, zi2), F::mul(F::mul(p.Y, zi2), zi), false};
+}
+
+template <class F>
+BGLS_HD Aff<F> aff_neg(const Aff<F>& a) {
+  return {a.x, F::neg(a.y), a.inf};
+}
+
+// k * P, k given as NL little-endian u32 limbs (non-negative); MSB-first double-and-add.
+template <class F>
+BGLS_FN Jac<F> jac_mul(const Aff<F>& p, const u32* k, int nbits) {
+  Jac<F> r = jac_inf<F>();
+  for (int i = nbits - 1; i >= 0; --i) {
+    r = jac_dbl<F>(r);
+    if ((k[i >> 5] >> (i & 31)) & 1u) r = jac_add_aff<F>(r, p);
+  }
+  return r;
+}
+
+// ---- (de)serialisation of affine points at the seam (uncompressed wire formats) ----
+//  G1: x || y big-endian (curves/altbn128.go:42-57; bls12G1Hash.dat)
+//  G2: x_im || x_re || y_im || y_re (curves/altbn128.go:157-179, altbn128_test.go:26-38;
+//      curves/bls12_381.go:147-158,209-226)
+//  infinity = all-zero bytes (curves/altbn128.go:431-439)
+// Returns false when a coordinate is not a canonical field element (>= p).
+template <class C>
+BGLS_HD bool g1_from_bytes(Aff<F1<C>>& out, const uint8_t* b) {
+  Fp<C> x = fp_from_be<C>(b), y = fp_from_be<C>(b + C::FP_BYTES);
+  bool ok = !fp_geq_p<C>(x) && !fp_geq_p<C>(y);
+  out.inf = fp_is_zero<C>(x) && fp_is_zero<C>(y);
+  out.x = fp_to_mont<C>(x);
+  out.y = fp_to_mont<C>(y);
+  return ok;
+}
+template <class C>
+BGLS_HD void g1_to_bytes(uint8_t* b, const Aff<F1<C>>& a) {
+  Fp<C> x = a.inf ? fp_zero<C>() : fp_from_mont<C>(a.x);
+  Fp<C> y = a.inf ? fp_zero<C>() : fp_from_mont<C>(a.y);
+  fp_to_be<C>(b, x);
+  fp_to_be<C>(b + C::FP_BYTES, y);
+}
+template <class C>
+BGLS_HD bool g2_from_bytes(Aff<F2<C>>& out, const uint8_t* b) {
+  constexpr int N = C::FP_BYTES;
+  Fp<C> xi = fp_from_be<C>(b), xr = fp_from_be<C>(b + N), yi = fp_from_be<C>(b + 2 * N), yr = fp_from_be<C>(b + 3 * N);
+  bool ok = !fp_geq_p<C>(xi) && !fp_geq_p<C>(xr) && !fp_geq_p<C>(yi) && !fp_geq_p<C>(yr);
+  out.inf = fp_is_zero<C>(xi) && fp_is_zero<C>(xr) && fp_is_zero<C>(yi) && fp_is_zero<C>(yr);
+  out.x = {fp_to_mont<C>(xr), fp_to_mont<C>(xi)};
+  out.y = {fp_to_mont<C>(yr), fp_to_mont<C>(yi)};
+  return ok;
+}
+template <class C>
+BGLS_HD void g2_to_bytes(uint8_t* b, const Aff<F2<C>>& a) {
+  constexpr int N = C::FP_BYTES;
+  Fp<C> z = fp_zero<C>();
+  fp_to_be<C>(b, a.inf ? z : fp_from_mont<C>(a.x.c1));
+  fp_to_be<C>(b + N, a.inf ? z : fp_from_mont<C>(a.x.c0));
+  fp_to_be<C>(b + 2 * N, a.inf ? z : fp_from_mont<C>(a.y.c1));
+  fp_to_be<C>(b + 3 * N, a.inf ? z : fp_from_mont<C>(a.y.c0));
+}
+
+}  // namespace bgls

@@ -1,0 +1,357 @@
+// Prime-field arithmetic for alt-bn128 (8 x u32) and BLS12-381 (12 x u32), Montgomery form.
+//
+// This is the bottom of the HIP hot path: every kernel in kernels.hip is built from these
+// routines.  The reference has no field arithmetic of its own -- it calls into
+// bn256/cloudflare and dis2/bls12 (curves/altbn128.go:11, curves/bls12_381.go:11) -- so the
+// algorithms here are written from the maths: operand-scanning products on v_mad_u64_u32
+// (32x32+64 -> 64), separate Montgomery reduction so Fp2 can reduce lazily.
+//
+// All functions are plain inline C++ over fixed-size limb arrays so that hipcc keeps operands
+// in VGPRs after full unrolling.  The same header is compiled for the host ONLY by the unit
+// tests (tests/host_harness.cpp) to diff each routine against the oracle without a GPU; the
+// shipped library never executes it on the CPU.
+#pragma once
+#include <stdint.h>
+#include "constants_gen.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BGLS_HD __host__ __device__ __forceinline__
+#define BGLS_FN __host__ __device__ __noinline__
+#else
+#define BGLS_HD inline __attribute__((always_inline))
+#define BGLS_FN __attribute__((noinline))
+#endif
+
+namespace bgls {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+BGLS_HD u32 addc(u32 a, u32 b, u32& c) {
+  u32 co;
+  u32 r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+}
+BGLS_HD u32 subb(u32 a, u32 b, u32& c) {
+  u32 co;
+  u32 r = __builtin_subc(a, b, c, &co);
+  c = co;
+  return r;
+}
+
+template <class C>
+struct Fp {
+  u32 v[C::L];
+};
+
+// ---------------------------------------------------------------- basic
+template <class C>
+BGLS_HD Fp<C> fp_zero() {
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = 0;
+  return r;
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_load(const u32* p) {
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = p[j];
+  return r;
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_one() {
+  return fp_load<C>(C::ONE);
+}
+
+template <class C>
+BGLS_HD bool fp_is_zero(const Fp<C>& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) o |= a.v[j];
+  return o == 0;
+}
+
+template <class C>
+BGLS_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+  u32 o = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) o |= a.v[j] ^ b.v[j];
+  return o == 0;
+}
+
+// r = c ? a : b
+template <class C>
+BGLS_HD Fp<C> fp_select(bool c, const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = c ? a.v[j] : b.v[j];
+  return r;
+}
+
+// a >= p ?  (plain integer compare)
+template <class C>
+BGLS_HD bool fp_geq_p(const Fp<C>& a) {
+  u32 bw = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) (void)subb(a.v[j], C::P[j], bw);
+  return bw == 0;
+}
+
+// a + b without reduction (caller guarantees a + b < 2^(32L); true for a, b < p)
+template <class C>
+BGLS_HD Fp<C> fp_add_nr(const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> r;
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = addc(a.v[j], b.v[j], c);
+  return r;
+}
+
+// conditional subtract: a in [0, 2p) -> [0, p)
+template <class C>
+BGLS_HD Fp<C> fp_reduce_once(const Fp<C>& a) {
+  Fp<C> d;
+  u32 bw = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) d.v[j] = subb(a.v[j], C::P[j], bw);
+  return fp_select<C>(bw != 0, a, d);
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
+  return fp_reduce_once<C>(fp_add_nr<C>(a, b));
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> d;
+  u32 bw = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) d.v[j] = subb(a.v[j], b.v[j], bw);
+  u32 mask = 0u - bw;
+  u32 c = 0;
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = addc(d.v[j], C::P[j] & mask, c);
+  return r;
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_neg(const Fp<C>& a) {
+  Fp<C> d;
+  u32 bw = 0;
+  u32 nz = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) {
+    d.v[j] = subb(C::P[j], a.v[j], bw);
+    nz |= a.v[j];
+  }
+  u32 mask = nz ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) d.v[j] &= mask;
+  return d;
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_dbl(const Fp<C>& a) {
+  return fp_add<C>(a, a);
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_mul3(const Fp<C>& a) {
+  return fp_add<C>(fp_dbl<C>(a), a);
+}
+
+// ---------------------------------------------------------------- wide (2L-limb) helpers
+template <int N>
+BGLS_HD void w_add(u32 (&r)[N], const u32 (&a)[N], const u32 (&b)[N]) {
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) r[j] = addc(a[j], b[j], c);
+}
+template <int N>
+BGLS_HD void w_sub(u32 (&r)[N], const u32 (&a)[N], const u32 (&b)[N]) {
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) r[j] = subb(a[j], b[j], c);
+}
+
+// t[0..2L) = a * b   (operand scanning; one v_mad_u64_u32 + one v_addc per limb product)
+template <class C>
+BGLS_HD void mul_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L], const u32 (&b)[C::L]) {
+  constexpr int L = C::L;
+  {
+    u64 P[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) P[j] = (u64)a[j] * b[0];
+    t[0] = (u32)P[0];
+    u32 c = 0;
+#pragma unroll
+    for (int j = 1; j < L; ++j) t[j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c);
+    t[L] = (u32)(P[L - 1] >> 32) + c;
+  }
+#pragma unroll
+  for (int i = 1; i < L; ++i) {
+    u64 P[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) P[j] = (u64)a[j] * b[i] + t[i + j];
+    t[i] = (u32)P[0];
+    u32 c = 0;
+#pragma unroll
+    for (int j = 1; j < L; ++j) t[i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c);
+    t[i + L] = (u32)(P[L - 1] >> 32) + c;
+  }
+}
+
+// t = a^2: off-diagonal products once, doubled, plus the diagonal.
+template <class C>
+BGLS_HD void sqr_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L]) {
+  constexpr int L = C::L;
+#pragma unroll
+  for (int k = 0; k < 2 * L; ++k) t[k] = 0;
+  // off-diagonal: rows i, columns j > i
+#pragma unroll
+  for (int i = 0; i < L - 1; ++i) {
+    u32 hi = 0, c = 0;
+#pragma unroll
+    for (int j = i + 1; j < L; ++j) {
+      u64 P = (u64)a[j] * a[i] + t[i + j];
+      t[i + j] = addc((u32)P, hi, c);
+      hi = (u32)(P >> 32);
+    }
+    t[i + L] = hi + c;
+  }
+  // double
+  {
+    u32 c = 0;
+#pragma unroll
+    for (int k = 1; k < 2 * L - 1; ++k) t[k] = addc(t[k], t[k], c);
+    t[2 * L - 1] = c;
+  }
+  // diagonal
+  {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      u64 P = (u64)a[i] * a[i];
+      t[2 * i] = addc(t[2 * i], (u32)P, c);
+      t[2 * i + 1] = addc(t[2 * i + 1], (u32)(P >> 32), c);
+    }
+  }
+}
+
+// Montgomery reduction: t < p * 2^(32L)  ->  t / 2^(32L) mod p, fully reduced.  Clobbers t.
+template <class C>
+BGLS_HD Fp<C> redc(u32 (&t)[2 * C::L]) {
+  constexpr int L = C::L;
+  u32 top = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    u32 m = t[i] * C::N0INV;
+    u64 P[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) P[j] = (u64)m * C::P[j] + t[i + j];
+    u32 c = 0;
+#pragma unroll
+    for (int j = 1; j < L; ++j) t[i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c);
+    u64 s = (u64)t[i + L] + (u32)(P[L - 1] >> 32);
+    s += c;
+    s += top;
+    t[i + L] = (u32)s;
+    top = (u32)(s >> 32);
+  }
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < L; ++j) r.v[j] = t[L + j];
+  return fp_reduce_once<C>(r);
+}
+
+template <class C>
+BGLS_FN Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
+  u32 t[2 * C::L];
+  mul_wide<C>(t, a.v, b.v);
+  return redc<C>(t);
+}
+
+template <class C>
+BGLS_FN Fp<C> fp_sqr(const Fp<C>& a) {
+  u32 t[2 * C::L];
+  sqr_wide<C>(t, a.v);
+  return redc<C>(t);
+}
+
+// plain integer (< 2^(32L)) -> Montgomery form, fully reduced (valid for ANY L-limb input)
+template <class C>
+BGLS_HD Fp<C> fp_to_mont(const Fp<C>& a) {
+  return fp_mul<C>(a, fp_load<C>(C::R2));
+}
+
+// Montgomery form -> canonical integer in [0, p)
+template <class C>
+BGLS_HD Fp<C> fp_from_mont(const Fp<C>& a) {
+  u32 t[2 * C::L];
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) {
+    t[j] = a.v[j];
+    t[C::L + j] = 0;
+  }
+  return redc<C>(t);
+}
+
+// a^e for a public, wave-uniform exponent e given as NL little-endian u32 limbs.
+template <class C, int NL>
+BGLS_FN Fp<C> fp_pow(const Fp<C>& a, const u32* e) {
+  Fp<C> r = fp_one<C>();
+  bool started = false;
+  for (int i = NL * 32 - 1; i >= 0; --i) {
+    u32 bit = (e[i >> 5] >> (i & 31)) & 1u;
+    if (started) r = fp_sqr<C>(r);
+    if (bit) {
+      r = started ? fp_mul<C>(r, a) : a;
+      started = true;
+    }
+  }
+  return r;
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_inv(const Fp<C>& a) {  // a^(p-2); 0 -> 0
+  return fp_pow<C, C::L>(a, C::EXP_INV);
+}
+
+// candidate square root a^((p+1)/4) (calcQuadRes, curves/hash.go:178-190); caller checks r^2 == a
+template <class C>
+BGLS_HD Fp<C> fp_sqrt_candidate(const Fp<C>& a) {
+  return fp_pow<C, C::L>(a, C::EXP_SQRT);
+}
+
+// big-endian bytes (FP_BYTES) -> limbs (plain integer)
+template <class C>
+BGLS_HD Fp<C> fp_from_be(const uint8_t* b) {
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) {
+    const uint8_t* q = b + 4 * (C::L - 1 - j);
+    r.v[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  return r;
+}
+
+template <class C>
+BGLS_HD void fp_to_be(uint8_t* b, const Fp<C>& a) {
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) {
+    uint8_t* q = b + 4 * (C::L - 1 - j);
+    q[0] = (uint8_t)(a.v[j] >> 24);
+    q[1] = (uint8_t)(a.v[j] >> 16);
+    q[2] = (uint8_t)(a.v[j] >> 8);
+    q[3] = (uint8_t)(a.v[j]);
+  }
+}
+
+}  // namespace bgls

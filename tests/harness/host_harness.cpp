@@ -1,0 +1,162 @@
+// TEST-ONLY: compiles the device arithmetic headers for the host so that every routine can be
+// diffed against the oracle in the CPU test tier (no GPU here).  Never linked into the product.
+#include <string.h>
+#include "../../bgls_amd/csrc/pairing.hpp"
+#include "../../bgls_amd/csrc/h2c.hpp"
+
+using namespace bgls;
+
+template <class C>
+static int fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fp<C> x = fp_to_mont<C>(fp_from_be<C>(a));
+  Fp<C> y = fp_to_mont<C>(fp_from_be<C>(b));
+  Fp<C> r;
+  switch (op) {
+    case 0: r = fp_mul<C>(x, y); break;
+    case 1: r = fp_sqr<C>(x); break;
+    case 2: r = fp_add<C>(x, y); break;
+    case 3: r = fp_sub<C>(x, y); break;
+    case 4: r = fp_neg<C>(x); break;
+    case 5: r = fp_inv<C>(x); break;
+    case 6: r = fp_sqrt_candidate<C>(x); break;
+    default: return -1;
+  }
+  fp_to_be<C>(out, fp_from_mont<C>(r));
+  return 0;
+}
+
+template <class C>
+static int f2_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {  // re||im
+  constexpr int N = C::FP_BYTES;
+  Fp2<C> x = {fp_to_mont<C>(fp_from_be<C>(a)), fp_to_mont<C>(fp_from_be<C>(a + N))};
+  Fp2<C> y = {fp_to_mont<C>(fp_from_be<C>(b)), fp_to_mont<C>(fp_from_be<C>(b + N))};
+  Fp2<C> r;
+  switch (op) {
+    case 0: r = f2_mul<C>(x, y); break;
+    case 1: r = f2_sqr<C>(x); break;
+    case 2: r = f2_mulxi<C>(x); break;
+    case 3: r = f2_inv<C>(x); break;
+    default: return -1;
+  }
+  fp_to_be<C>(out, fp_from_mont<C>(r.c0));
+  fp_to_be<C>(out + N, fp_from_mont<C>(r.c1));
+  return 0;
+}
+
+template <class C>
+static int f12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fp12<C> x, y, r;
+  if (!gt_from_bytes<C>(x, a)) return -2;
+  if (b && !gt_from_bytes<C>(y, b)) return -2;
+  switch (op) {
+    case 0: r = f12_mul<C>(x, y); break;
+    case 1: r = f12_sqr<C>(x); break;
+    case 2: r = f12_inv<C>(x); break;
+    case 3: r = f12_frob<C>(x, 1); break;
+    case 4: r = f12_frob<C>(x, 2); break;
+    case 5: r = f12_frob<C>(x, 3); break;
+    case 6: r = f12_cyclo_sqr<C>(x); break;
+    case 7: r = f12_conj<C>(x); break;
+    case 8: r = final_exp<C>(x); break;
+    default: return -1;
+  }
+  gt_to_bytes<C>(out, r);
+  return 0;
+}
+
+template <class C>
+static int miller(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+  Aff<F1<C>> P;
+  Aff<F2<C>> Q;
+  if (!g1_from_bytes<C>(P, g1) || !g2_from_bytes<C>(Q, g2)) return -2;
+  gt_to_bytes<C>(out, miller_loop<C>(P, Q));
+  return 0;
+}
+
+template <class C>
+static int group_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* k_be32, uint8_t* out) {
+  u32 k[8];
+  if (k_be32)
+    for (int j = 0; j < 8; ++j) {
+      const uint8_t* q = k_be32 + 4 * (7 - j);
+      k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | q[3];
+    }
+  if (op < 10) {
+    typedef F1<C> F;
+    Aff<F> P, Q;
+    if (!g1_from_bytes<C>(P, a)) return -2;
+    Jac<F> r;
+    if (op == 0) {
+      if (!g1_from_bytes<C>(Q, b)) return -2;
+      r = jac_add_aff<F>(jac_from_aff<F>(P), Q);
+    } else if (op == 1) {
+      r = jac_mul<F>(P, k, 256);
+    } else if (op == 2) {
+      if (!g1_from_bytes<C>(Q, b)) return -2;
+      r = jac_add<F>(jac_dbl<F>(jac_from_aff<F>(P)), jac_dbl<F>(jac_from_aff<F>(Q)));  // 2P + 2Q
+    } else if (op == 3) {
+      return aff_on_curve<F>(P) ? 1 : 0;
+    } else
+      return -1;
+    g1_to_bytes<C>(out, jac_to_aff<F>(r));
+  } else {
+    typedef F2<C> F;
+    Aff<F> P, Q;
+    if (!g2_from_bytes<C>(P, a)) return -2;
+    Jac<F> r;
+    if (op == 10) {
+      if (!g2_from_bytes<C>(Q, b)) return -2;
+      r = jac_add_aff<F>(jac_from_aff<F>(P), Q);
+    } else if (op == 11) {
+      r = jac_mul<F>(P, k, 256);
+    } else if (op == 12) {
+      if (!g2_from_bytes<C>(Q, b)) return -2;
+      r = jac_add<F>(jac_dbl<F>(jac_from_aff<F>(P)), jac_dbl<F>(jac_from_aff<F>(Q)));
+    } else if (op == 13) {
+      return aff_on_curve<F>(P) ? 1 : 0;
+    } else
+      return -1;
+    g2_to_bytes<C>(out, jac_to_aff<F>(r));
+  }
+  return 0;
+}
+
+extern "C" {
+int ht_fp_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  return curve == 0 ? fp_op<BN254>(op, a, b, out) : fp_op<BLS381>(op, a, b, out);
+}
+int ht_f2_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  return curve == 0 ? f2_op<BN254>(op, a, b, out) : f2_op<BLS381>(op, a, b, out);
+}
+int ht_f12_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  return curve == 0 ? f12_op<BN254>(op, a, b, out) : f12_op<BLS381>(op, a, b, out);
+}
+int ht_miller(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+  return curve == 0 ? miller<BN254>(g1, g2, out) : miller<BLS381>(g1, g2, out);
+}
+int ht_group_op(int curve, int op, const uint8_t* a, const uint8_t* b, const uint8_t* k, uint8_t* out) {
+  return curve == 0 ? group_op<BN254>(op, a, b, k, out) : group_op<BLS381>(op, a, b, k, out);
+}
+int ht_hash_to_g1(int curve, const uint8_t* msg, size_t len, uint8_t* out) {
+  if (curve == 0) {
+    Aff<F1<BN254>> p;
+    if (!bn_hash_to_g1(msg, len, p)) return -3;
+    g1_to_bytes<BN254>(out, p);
+  } else {
+    g1_to_bytes<BLS381>(out, bls_hash_to_g1(msg, len));
+  }
+  return 0;
+}
+int ht_keccak256(const uint8_t* msg, size_t len, uint8_t prefix, uint8_t* out) {
+  ByteSrc s; s.msg = msg; s.len = len; s.pre[0] = prefix; s.npre = 1; s.nsuf = 0;
+  u32 d[8]; keccak256_legacy(s, d);
+  for (int i = 0; i < 8; ++i) { out[4*i] = d[i] >> 24; out[4*i+1] = d[i] >> 16; out[4*i+2] = d[i] >> 8; out[4*i+3] = d[i]; }
+  return 0;
+}
+int ht_blake2b(const uint8_t* msg, size_t len, int k, uint8_t* out) {
+  ByteSrc s; s.msg = msg; s.len = len; s.npre = 0; s.pre[0] = 0; s.suf[0]='G'; s.suf[1]='1'; s.suf[2]='_'; s.suf[3]='0'+k; s.nsuf = 4;
+  u32 d[16]; blake2b512(s, d);
+  for (int i = 0; i < 16; ++i) { out[4*i] = d[i] >> 24; out[4*i+1] = d[i] >> 16; out[4*i+2] = d[i] >> 8; out[4*i+3] = d[i]; }
+  return 0;
+}
+}

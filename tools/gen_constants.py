@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate bgls_amd/csrc/constants_gen.hpp: per-curve constants as little-endian u32 limbs.
+
+Stand-alone on purpose (imports nothing from oracle/ -- the product build must not depend on the
+checker).  Everything is derived from the curve-family polynomials and the literal constants the
+reference lists in curves/altbn128.go:458-480 and curves/bls12_381.go:328-346.
+Field elements are emitted in Montgomery form (R = 2^(32 L)); exponents/scalars as plain integers.
+"""
+import os, sys
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "bgls_amd", "csrc", "constants_gen.hpp")
+
+
+def limbs(x, n):
+    assert 0 <= x < (1 << (32 * n)), (x, n)
+    return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+def arr(name, vals, ctype="uint32_t"):
+    return "  static constexpr %s %s[%d] = {%s};\n" % (ctype, name, len(vals), ", ".join("0x%08xu" % v for v in vals))
+
+
+def naf(k):
+    out = []
+    while k:
+        d = (2 - (k % 4)) if (k & 1) else 0
+        k -= d
+        out.append(d)
+        k >>= 1
+    return out[::-1]
+
+
+class F2:
+    def __init__(s, p): s.p = p
+    def mul(s, a, b): p = s.p; return ((a[0]*b[0]-a[1]*b[1]) % p, (a[0]*b[1]+a[1]*b[0]) % p)
+    def inv(s, a):
+        p = s.p; n = pow(a[0]*a[0]+a[1]*a[1], p-2, p); return (a[0]*n % p, -a[1]*n % p)
+    def pow(s, a, e):
+        r = (1, 0)
+        while e:
+            if e & 1: r = s.mul(r, a)
+            a = s.mul(a, a); e >>= 1
+        return r
+
+
+def emit(cname, cid, L, p, r, b, xi, twist, loop, extra):
+    R = 1 << (32 * L)
+    M = lambda x: (x % p) * R % p
+    f2 = F2(p)
+    o = "struct %s {\n" % cname
+    o += "  static constexpr int L = %d;\n  static constexpr int CURVE_ID = %d;\n" % (L, cid)
+    o += "  static constexpr bool TWIST_D = %s;\n" % ("true" if twist == "D" else "false")
+    o += "  static constexpr int FP_BYTES = %d;\n" % (4 * L)
+    o += "  static constexpr uint32_t N0INV = 0x%08xu;\n" % ((-pow(p, -1, 1 << 32)) % (1 << 32))
+    o += "  static constexpr int XI_RE = %d;\n" % xi[0]
+    o += arr("P", limbs(p, L))
+    o += arr("P2W", limbs(p * p, 2 * L))          # p^2, for lazy-reduction offsets
+    o += arr("ONE", limbs(M(1), L))
+    o += arr("R2", limbs(R * R % p, L))
+    o += arr("HALF", limbs(M(pow(2, p - 2, p)), L))
+    o += arr("B", limbs(M(b), L))
+    b2 = f2.mul((b, 0), f2.inv(xi)) if twist == "D" else f2.mul((b, 0), xi)
+    o += arr("B2_RE", limbs(M(b2[0]), L)) + arr("B2_IM", limbs(M(b2[1]), L))
+    b23 = (3 * b2[0] % p, 3 * b2[1] % p)
+    o += arr("B2X3_RE", limbs(M(b23[0]), L)) + arr("B2X3_IM", limbs(M(b23[1]), L))
+    # Frobenius constants gamma_j[k] = xi^(k (p^j - 1)/6), flattened [j-1][k][re,im][L]
+    g = []
+    for j in (1, 2, 3):
+        g1 = f2.pow(xi, (p ** j - 1) // 6)
+        cur = (1, 0)
+        for k in range(6):
+            g += limbs(M(cur[0]), L) + limbs(M(cur[1]), L)
+            cur = f2.mul(cur, g1)
+    o += arr("GAMMA", g)
+    o += arr("EXP_SQRT", limbs((p + 1) // 4, L))   # calcQuadRes exponent, hash.go:178-190
+    o += arr("EXP_INV", limbs(p - 2, L))
+    o += arr("ORDER", limbs(r, 8))
+    digs = naf(loop)
+    o += "  static constexpr int LOOP_LEN = %d;\n" % len(digs)
+    o += "  static constexpr int8_t LOOP_NAF[%d] = {%s};\n" % (len(digs), ", ".join(str(d) for d in digs))
+    o += extra(M, limbs, L)
+    o += "};\n\n"
+    return o
+
+
+def main():
+    u = 4965661367192848881
+    p_bn = 36*u**4 + 36*u**3 + 24*u**2 + 6*u + 1
+    r_bn = 36*u**4 + 36*u**3 + 18*u**2 + 6*u + 1
+    assert p_bn == 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    x = -0xd201000000010000
+    p_bls = (x - 1)**2 * (x**4 - x**2 + 1) // 3 + x
+    r_bls = x**4 - x**2 + 1
+    assert p_bls == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+    def bn_extra(M, limbs, L):
+        g2 = [10857046999023057135944570762232829481370756359578518086990519993285655852781,
+              11559732032986387107991004021392285783925812861821192530917403151452391805634,
+              8495653923123431417604973247489272438418190587263600148770280649306958101930,
+              4082367875863433681332203403145435568316851327593401208105741076214120093531]
+        o = arr("G1X", limbs(M(1), L)) + arr("G1Y", limbs(M(2), L))
+        o += arr("G2", sum((limbs(M(v), L) for v in g2), []))      # x_re, x_im, y_re, y_im
+        o += arr("U_ABS", limbs(u, 2))
+        o += "  static constexpr int U_BITS = %d;\n" % u.bit_length()
+        return o
+
+    def bls_extra(M, limbs, L):
+        g1x = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+        g1y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+        g2 = [0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+              0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e,
+              0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+              0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be]
+        sqrt_m3 = 1586958781458431025242759403266842894121773480562120986020912974854563298150952611241517463240701
+        z_sw = 793479390729215512621379701633421447060886740281060493010456487427281649075476305620758731620350
+        root1 = 248294325734266649657405162895821171812231848760181225578082735178502750823719347628762635478508544819911854747095
+        cof = (x - 1)**2 // 3
+        assert cof == 76329603384216526031706109802092473003
+        o = arr("G1X", limbs(M(g1x), L)) + arr("G1Y", limbs(M(g1y), L))
+        o += arr("G2", sum((limbs(M(v), L) for v in g2), []))
+        o += arr("U_ABS", limbs(-x, 2))
+        o += "  static constexpr int U_BITS = %d;\n" % (-x).bit_length()
+        o += arr("SQRT_M3", limbs(M(sqrt_m3), L)) + arr("Z_SW", limbs(M(z_sw), L))
+        o += arr("FT_ROOT1", limbs(root1, L)) + arr("FT_ROOT2", limbs(p_bls - root1, L))   # plain (compared before Montgomery conversion)
+        o += arr("COFACTOR", limbs(cof, 4))
+        o += "  static constexpr int COFACTOR_BITS = %d;\n" % cof.bit_length()
+        o += arr("R3", limbs((1 << (32 * L)) ** 3 % p_bls, L))    # to Montgomery-convert a 2L-limb value: redc(wide) * R3
+        return o
+
+    txt = "// GENERATED by tools/gen_constants.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\nnamespace bgls {\n\n"
+    txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, bn_extra)
+    txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, bls_extra)
+    txt += "}  // namespace bgls\n"
+    with open(OUT, "w") as f:
+        f.write(txt)
+    print("wrote", os.path.normpath(OUT), len(txt), "bytes")
+
+
+if __name__ == "__main__":
+    main()
