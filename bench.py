@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aggregate-verify signer-pairs/sec (BASELINE.json `metric`).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one complete VerifyAggregateSignature over the resident batch: duplicate-message
+scan, n hash-to-G1, n+1 Miller loops, GT product, ONE final exponentiation, compare with 1 --
+everything bgls/bgls.go:94-119 does, inputs already in HBM (keys as the reference's wire-format
+bytes, 64-byte messages as in bgls/bgls_test.go:186-202).
+N = 1 workload: BASELINE.json configs[1] (alt-bn128, 2^16 signers, 1 MI355X).
+N > 1: weak scaling -- every rank verifies its own 2^16-signer shard of ONE n = N * 2^16
+aggregate signature: partial Miller product per rank, one RCCL all-gather of the 384-byte
+partials, local combine + final exponentiation on every rank (bgls_amd/sharding.py).
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from bgls_amd import _lib  # noqa: E402
+from bgls_amd.sharding import all_gather_bytes  # noqa: E402
+
+# Algorithmic work model (SURVEY.md 8d / DESIGN.md): 32x32->64 MACs per unit.
+MAC_PER_FPMUL = {0: 136, 1: 300}                       # CIOS 2L^2+L, L = 8 / 12
+MILLER_FPMUL = {0: 8250, 1: 6700}                      # Miller loop, Fp multiplications per pair
+PAIR_FPMUL = {0: 9030, 1: 14650}                       # whole path per signer-pair (hash + Miller + product)
+MULTISIG_FPMUL = {0: 29, 1: 29}                        # one G2 mixed addition per signer
+ALGO_BYTES_PER_PAIR = {0: 128 + 64, 1: 192 + 64}       # key + message read once
+ORDER = {0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+         1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+
+
+def B(b):
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError("%s failed: %d %s" % (what, rc, _lib.last_error()))
+    return rc
+
+
+def make_shard(lib, cid, n, seed):
+    """n keys, n distinct 64-byte messages and the shard's partial aggregate signature, all
+    produced by the engine itself on the GPU (setup, untimed)."""
+    fp = 32 if cid == 0 else 48
+    rnd = random.Random(seed)
+    msgs = rnd.randbytes(64 * n)
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+    kb = b"".join(s.to_bytes(32, "big") for s in sks)
+    g2 = (ctypes.c_uint8 * (4 * fp))()
+    check(lib.bgls_generator(cid, 2, g2), "generator")
+    keys = (ctypes.c_uint8 * (n * 4 * fp))()
+    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(kb), None, n, keys), "scale_points(G2)")
+    off = (ctypes.c_uint64 * (n + 1))(*[64 * i for i in range(n + 1)])
+    hs = (ctypes.c_uint8 * (n * 2 * fp))()
+    check(lib.bgls_hash_to_g1(cid, B(msgs), off, n, hs), "hash_to_g1")
+    sigs = (ctypes.c_uint8 * (n * 2 * fp))()
+    check(lib.bgls_scale_points(cid, 1, hs, B(kb), None, n, sigs), "scale_points(G1)")
+    agg = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_aggregate_points(cid, 1, sigs, n, agg), "aggregate_points")
+    return bytes(keys), msgs, bytes(agg), bytes(sigs)
+
+
+def stage(lib, name):
+    ms, cnt = ctypes.c_double(), ctypes.c_ulonglong()
+    lib.bgls_profile_get(name.encode(), ctypes.byref(ms), ctypes.byref(cnt))
+    return ms.value, cnt.value
+
+
+def cpu_baseline(cid, keys, msgs, sigs, n, fp, lib):
+    """Oracle (C restatement, oracle/c) timed on this box's host cores over a bounded sample of the
+    same instance, in the reference's parallel shape: one task per hash and per FULL pairing
+    (final exponentiation inside every pairing, curves/curve.go:132-134)."""
+    from oracle import coracle
+    cores = os.cpu_count() or 1
+    probe = min(n, 4 * cores)
+
+    def run(cnt, faithful):
+        agg = (ctypes.c_uint8 * (2 * fp))()
+        check(lib.bgls_aggregate_points(cid, 1, B(sigs[:cnt * 2 * fp]), cnt, agg), "aggregate_points(sample)")
+        ms = [msgs[64 * i:64 * i + 64] for i in range(cnt)]
+        t0 = time.perf_counter()
+        ok = coracle.verify_aggregate(cid, bytes(agg), keys[:cnt * 4 * fp], ms, False, cores, faithful)
+        dt = time.perf_counter() - t0
+        if ok != 1:
+            raise RuntimeError("oracle rejected the GPU-generated instance (cpu_baseline sample)")
+        return dt
+
+    t_probe = run(probe, 1)
+    cnt = int(min(n, max(probe, probe * 12.0 / max(t_probe, 1e-3))))     # ~12 s of CPU work
+    dt = run(cnt, 1)
+    dt_shared = run(min(cnt, 4096), 0)
+    return {"value": cnt / dt, "unit": "signer-pairs/s", "cores": cores, "kind": "port",
+            "sample": "first %d signers of the same instance, C oracle, %d threads, final exponentiation per pairing "
+                      "(reference shape); with one shared final exponentiation: %.0f pairs/s" % (cnt, cores, min(cnt, 4096) / dt_shared)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
+    ap.add_argument("--n", type=int, default=1 << 16, help="signers per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch N > 1 with torch.distributed.run" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+    check(lib.bgls_init(local_rank), "bgls_init")
+    cid = 0 if args.curve == "altbn128" else 1
+    fp = 32 if cid == 0 else 48
+    n = args.n
+    gtb = 12 * fp
+
+    # ---- setup (untimed): resident shard + the global aggregate signature on rank 0
+    keys, msgs, part_sig, sigs = make_shard(lib, cid, n, 0xB6150000 + 1 + 1000 * rank)
+    t_keys = torch.frombuffer(bytearray(keys), dtype=torch.uint8).to(dev)
+    t_msgs = torch.frombuffer(bytearray(msgs), dtype=torch.uint8).to(dev)
+    t_psig = torch.frombuffer(bytearray(part_sig), dtype=torch.uint8).to(dev)
+    all_sigs = all_gather_bytes(t_psig, world)
+    agg = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_aggregate_points(cid, 1, B(bytes(all_sigs.cpu().numpy().tobytes())), world, agg), "aggregate_points(global)")
+    t_sig = torch.frombuffer(bytearray(bytes(agg)), dtype=torch.uint8).to(dev)
+    t_part = torch.zeros(gtb, dtype=torch.uint8, device=dev)
+    t_flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(msgs_t=t_msgs):
+        t_flags.zero_()
+        check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
+                                          64, 64, n, 1, t_part.data_ptr(), t_flags.data_ptr(), stream), "miller_product_dev")
+        parts = all_gather_bytes(t_part, world)
+        return check(lib.bgls_final_verify_dev(cid, parts.data_ptr(), world, t_flags.data_ptr(), stream), "final_verify_dev")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # correctness gate: the valid instance verifies, one flipped message bit rejects
+    if step() != 1:
+        raise RuntimeError("valid instance rejected")
+    bad = t_msgs.clone()
+    if rank == world - 1:
+        bad[64 * (n // 2) + 3] ^= 0x20
+    if step(bad) != 0:
+        raise RuntimeError("tampered instance accepted")
+
+    for _ in range(args.warmup):
+        step()
+    lib.bgls_profile_enable(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if step() != 1:
+            raise RuntimeError("verification failed inside the timed region")
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stages = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
+    lib.bgls_profile_enable(0)
+
+    if rank == 0:
+        peak = ctypes.c_double()
+        check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
+        mil_ms, mil_cnt = stages["miller"]
+        mil_avg_s = mil_ms / max(mil_cnt, 1) * 1e-3
+        macs_per_launch = (n + 1) * MILLER_FPMUL[cid] * MAC_PER_FPMUL[cid]
+        achieved = macs_per_launch / mil_avg_s / 1e12 if mil_avg_s > 0 else 0.0
+        value = world * n * args.steps / elapsed
+        out = {
+            "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s VerifyAggregateSignature, %d signers per GPU (%d total), distinct 64-byte messages, "
+                                   "keys and messages resident in HBM" % (args.curve, n, world * n),
+                       "curve": args.curve, "signers_per_gpu": n, "parallelism": "signer-shards x%d + all-gather of GT partials" % world},
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_miller", "achieved": achieved, "peak": peak.value / 1e12,
+                         "unit": "TMAC/s", "frac": achieved / (peak.value / 1e12) if peak.value else None, "traffic": None,
+                         "launch_ms": mil_avg_s * 1e3, "macs_per_launch": macs_per_launch,
+                         "note": "integer bignum path: bounded by v_mad_u64_u32 issue, not HBM or MFMA (SURVEY 8d); peak measured "
+                                 "live by bgls_probe_mad_peak; HBM side: %.3f GB/s algorithmic of 8000 peak"
+                                 % (value * ALGO_BYTES_PER_PAIR[cid] / world / 1e9),
+                         "whole_path_frac": value / world * PAIR_FPMUL[cid] * MAC_PER_FPMUL[cid] / peak.value if peak.value else None},
+            "stage_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cid, keys, msgs, sigs, n, fp, lib)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI (include/bgls_hip.h).  Loads the in-tree HIP library and fails
+loudly if it is missing: there is no CPU fallback for the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbgls_hip.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+vp = ctypes.c_void_p
+sz = ctypes.c_size_t
+ci = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/bgls_hip.h one to one
+SIGNATURES = {
+    "bgls_init": (ci, [ci]),
+    "bgls_last_error": (ctypes.c_char_p, []),
+    "bgls_abi_version": (ci, []),
+    "bgls_fp_size": (sz, [ci]),
+    "bgls_g1_size": (sz, [ci]),
+    "bgls_g2_size": (sz, [ci]),
+    "bgls_gt_size": (sz, [ci]),
+    "bgls_verify_aggregate": (ci, [ci, u8p, u8p, u8p, u64p, sz, ci]),
+    "bgls_verify_multi": (ci, [ci, u8p, u8p, sz, u8p, sz]),
+    "bgls_pairing_product": (ci, [ci, u8p, u8p, sz, u8p]),
+    "bgls_hash_to_g1": (ci, [ci, u8p, u64p, sz, u8p]),
+    "bgls_aggregate_points": (ci, [ci, ci, u8p, sz, u8p]),
+    "bgls_scale_points": (ci, [ci, ci, u8p, u8p, u8p, sz, u8p]),
+    "bgls_point_add": (ci, [ci, ci, u8p, u8p, u8p]),
+    "bgls_point_check": (ci, [ci, ci, u8p]),
+    "bgls_generator": (ci, [ci, ci, u8p]),
+    "bgls_pair": (ci, [ci, u8p, u8p, u8p]),
+    "bgls_gt_mul": (ci, [ci, u8p, u8p, u8p]),
+    "bgls_gt_identity": (ci, [ci, u8p]),
+    "bgls_miller_product_dev": (ci, [ci, vp, vp, vp, sz, sz, sz, ci, vp, vp, vp]),
+    "bgls_final_verify_dev": (ci, [ci, vp, sz, vp, vp]),
+    "bgls_aggregate_points_dev": (ci, [ci, ci, vp, sz, vp, vp]),
+    "bgls_verify_multi_dev": (ci, [ci, vp, vp, sz, vp, sz, vp]),
+    "bgls_profile_enable": (ci, [ci]),
+    "bgls_profile_get": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong)]),
+    "bgls_probe_mad_peak": (ci, [ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "bgls_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "The HIP library is the product; there is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def buf(data):
+    """bytes-like -> ctypes uint8 array (copy)."""
+    b = bytes(data)
+    return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+
+
+def out(n):
+    return (ctypes.c_uint8 * max(n, 1))()
+
+
+def last_error():
+    return load().bgls_last_error().decode()

@@ -1,0 +1,96 @@
+"""Host-side mirror of the reference's `bgls` scheme functions on the hot path
+(bgls/bgls.go, bgls/blsKosk.go), same names and semantics, each routed to ONE batch C call."""
+import ctypes
+import secrets
+from . import _lib
+from .curves import AggregatePoints, Point, G1, G2
+
+
+def KeyGen(curve):                                   # bgls/bgls.go:30-37
+    x = secrets.randbelow(curve.GetG1Order())
+    return x, LoadPublicKey(curve, x), None
+
+
+def LoadPublicKey(curve, sk):                        # bgls/bgls.go:40-43
+    return curve.GetG2().Mul(sk)
+
+
+def Sign(curve, sk, msg):                            # bgls/bgls.go:46-56
+    return curve.HashToG1(msg).Mul(sk)
+
+
+def KoskSign(curve, sk, msg):                        # bgls/blsKosk.go:73-77
+    return Sign(curve, sk, b"\x01" + bytes(msg))
+
+
+def AggregateSignatures(sigs):                       # bgls/bgls.go:123-125
+    return AggregatePoints(sigs)
+
+
+def AggregateKeys(keys):                             # bgls/bgls.go:129-131
+    return AggregatePoints(keys)
+
+
+def _verify_agg(curve, aggsig, keys, msgs, allow_duplicates):
+    if len(keys) != len(msgs):                       # bgls/bgls.go:95-97
+        return False
+    n = len(keys)
+    for k in keys:
+        if not (isinstance(k, Point) and k.curve is curve and k.group == G2):
+            return False
+    if not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False
+    off = (ctypes.c_uint64 * (n + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        off[i] = acc
+        acc += len(m)
+    off[n] = acc
+    rc = _lib.load().bgls_verify_aggregate(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in keys)),
+                                           _lib.buf(b"".join(bytes(m) for m in msgs)), off, n, 1 if allow_duplicates else 0)
+    return rc == 1                                   # every failure collapses to false (bgls.go:115-118)
+
+
+def VerifyAggregateSignature(curve, aggsig, keys, msgs):      # bgls/bgls.go:82-84
+    return _verify_agg(curve, aggsig, keys, msgs, False)
+
+
+def KoskVerifyAggregateSignature(curve, aggsig, keys, msgs):  # bgls/blsKosk.go:100-106
+    return _verify_agg(curve, aggsig, keys, [b"\x01" + bytes(m) for m in msgs], True)
+
+
+def _verify_multi(curve, aggsig, keys, msg):                  # bgls/bgls.go:89-92
+    for k in keys:
+        if not (isinstance(k, Point) and k.curve is curve and k.group == G2):
+            return False
+    rc = _lib.load().bgls_verify_multi(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in keys)), len(keys),
+                                       _lib.buf(msg), len(msg))
+    return rc == 1
+
+
+def VerifySingleSignature(curve, sig, pubkey, msg):           # bgls/bgls.go:59-70
+    return _verify_multi(curve, sig, [pubkey], bytes(msg))
+
+
+def KoskVerifySingleSignature(curve, sig, pubkey, msg):       # bgls/blsKosk.go:86-90
+    return VerifySingleSignature(curve, sig, pubkey, b"\x01" + bytes(msg))
+
+
+def KoskVerifyMultiSignature(curve, aggsig, keys, msg):       # bgls/blsKosk.go:117-120
+    return _verify_multi(curve, aggsig, keys, b"\x01" + bytes(msg))
+
+
+class AggSig:                                                 # bgls/bgls.go:22-26,73-75
+    def __init__(self, keys, msgs, sig):
+        self.keys, self.msgs, self.sig = keys, msgs, sig
+
+    def Verify(self, curve):
+        return VerifyAggregateSignature(curve, self.sig, self.keys, self.msgs)
+
+
+class MultiSig:                                               # bgls/bgls.go:15-19, blsKosk.go:110-112
+    def __init__(self, keys, sig, msg):
+        self.keys, self.sig, self.msg = keys, sig, msg
+
+    def Verify(self, curve):
+        return KoskVerifyMultiSignature(curve, self.sig, self.keys, self.msg)

@@ -1,0 +1,1013 @@
+// HIP kernels + C ABI of the aggregate-verify engine (see include/bgls_hip.h for the contract).
+//
+// Pipeline of bgls.VerifyAggregateSignature (bgls/bgls.go:94-119) on the device:
+//   k_dup_check   exact duplicate-message scan        (containsDuplicateMessage, bgls.go:139-150)
+//   k_h2c         H(m_i) for every message            (concurrentHash, bgls.go:107-111,134-137)
+//   k_sig_prep    -sigma                              (aggsig.Mul(-1), bgls.go:112)
+//   k_miller      Miller value of every (H(m_i), pk_i) and of (-sigma, g2)
+//                                                     (concurrentPair, curves/curve.go:132-134,217-223)
+//   k_f12_reduce  product of the Miller values        (GT Add tree, curves/curve.go:141-169)
+//   k_final       ONE final exponentiation, compare with 1 (Equals(GetGTIdentity), bgls.go:115-118)
+// Round-1 mapping: one work-item per pairing / message / point (thread-local tower arithmetic).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+#include <string>
+
+#include "pairing.hpp"
+#include "h2c.hpp"
+#include "../../include/bgls_hip.h"
+
+using namespace bgls;
+
+// ======================================================================= device side
+struct MsgView {
+  const uint8_t* base;
+  const uint64_t* off;  // n+1 offsets, or nullptr for fixed stride
+  size_t len, stride;
+  __device__ __forceinline__ const uint8_t* ptr(size_t i) const { return off ? base + off[i] : base + i * stride; }
+  __device__ __forceinline__ size_t size(size_t i) const { return off ? (size_t)(off[i + 1] - off[i]) : len; }
+};
+
+enum : uint32_t { FLAG_DUP = 1u, FLAG_ENC = 2u, FLAG_HASH = 4u };
+
+// ---- duplicate-message scan: open-addressing table of (index+1), exact byte comparison ----
+__device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= p[i];
+    h *= 0x100000001b3ull;
+  }
+  h ^= h >> 29;
+  h *= 0xbf58476d1ce4e5b9ull;
+  h ^= h >> 32;
+  return h;
+}
+
+__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m = mv.ptr(i);
+  const size_t len = mv.size(i);
+  uint32_t slot = (uint32_t)msg_hash64(m, len) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t prev = atomicCAS(&table[slot], 0u, (uint32_t)i + 1u);
+    if (prev == 0u) return;
+    size_t j = prev - 1u;
+    if (mv.size(j) == len) {
+      const uint8_t* o = mv.ptr(j);
+      bool same = true;
+      for (size_t k = 0; k < len; ++k)
+        if (o[k] != m[k]) {
+          same = false;
+          break;
+        }
+      if (same) {
+        atomicOr(flags, FLAG_DUP);
+        return;
+      }
+    }
+    slot = (slot + 1u) & mask;
+  }
+}
+
+// ---- hash to G1 ----
+template <class C>
+__global__ void __launch_bounds__(64) k_h2c(MsgView mv, size_t n, Aff<F1<C>>* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if constexpr (C::CURVE_ID == 0) {
+    Aff<F1<C>> p;
+    if (!bn_hash_to_g1(mv.ptr(i), mv.size(i), p)) {
+      atomicOr(flags, FLAG_HASH);
+      p = {fp_zero<C>(), fp_zero<C>(), true};
+    }
+    out[i] = p;
+  } else {
+    out[i] = bls_hash_to_g1(mv.ptr(i), mv.size(i));
+  }
+}
+
+template <class C>
+__global__ void k_g1_to_bytes(const Aff<F1<C>>* in, size_t n, uint8_t* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_to_bytes<C>(out + i * 2 * C::FP_BYTES, in[i]);
+}
+
+// parse n G1 points (optionally negating them); bad encodings / off-curve points set FLAG_ENC
+template <class C>
+__global__ void k_g1_parse(const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p;
+  bool ok = g1_from_bytes<C>(p, in + i * 2 * C::FP_BYTES);
+  ok = ok && aff_on_curve<F1<C>>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+  if (negate) p = aff_neg<F1<C>>(p);
+  out[i] = p;
+}
+
+// ---- Miller loops: one work-item per pair ----
+template <class C>
+__global__ void __launch_bounds__(64) k_miller(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long gen_at,
+                                               Fp12<C>* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F2<C>> Q;
+  if ((long long)i == gen_at) {
+    Q.x = f2_load<C>(C::G2);
+    Q.y = f2_load<C>(C::G2 + 2 * C::L);
+    Q.inf = false;
+  } else {
+    size_t k = (gen_at >= 0 && (long long)i > gen_at) ? i - 1 : i;
+    bool ok = g2_from_bytes<C>(Q, g2s + k * 4 * C::FP_BYTES);
+    ok = ok && aff_on_curve<F2<C>>(Q);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+  }
+  Aff<F1<C>> P = g1s[i];
+  out[i] = miller_loop<C>(P, Q);
+}
+
+// out[t] = prod in[t*R .. min(n, (t+1)*R))
+template <class C>
+__global__ void __launch_bounds__(64) k_f12_reduce(const Fp12<C>* in, size_t n, int R, Fp12<C>* out) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Fp12<C> acc = in[lo];
+  for (size_t k = lo + 1; k < hi; ++k) acc = f12_mul<C>(acc, in[k]);
+  out[t] = acc;
+}
+
+template <class C>
+__global__ void k_f12_to_bytes(const Fp12<C>* in, uint8_t* out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) gt_to_bytes<C>(out, in[0]);
+}
+
+// product of `count` serialised partials -> final exponentiation -> GT bytes + (== 1) verdict
+template <class C>
+__global__ void __launch_bounds__(64) k_final(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out,
+                                              uint32_t* verdict, uint32_t* flags) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fp12<C> acc = f12_one<C>();
+  for (size_t k = 0; k < count; ++k) {
+    Fp12<C> x;
+    if (!gt_from_bytes<C>(x, partials + k * 12 * C::FP_BYTES)) atomicOr(flags, FLAG_ENC);
+    acc = f12_mul<C>(acc, x);
+  }
+  if (do_final_exp) acc = final_exp<C>(acc);
+  if (gt_out) gt_to_bytes<C>(gt_out, acc);
+  verdict[0] = f12_is_one<C>(acc) ? 1u : 0u;
+}
+
+// ---- point sums ----
+template <class F>
+__device__ __forceinline__ bool aff_from_bytes(Aff<F>& p, const uint8_t* b);
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F1<BN254>>(Aff<F1<BN254>>& p, const uint8_t* b) { return g1_from_bytes<BN254>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F1<BLS381>>(Aff<F1<BLS381>>& p, const uint8_t* b) { return g1_from_bytes<BLS381>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F2<BN254>>(Aff<F2<BN254>>& p, const uint8_t* b) { return g2_from_bytes<BN254>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F2<BLS381>>(Aff<F2<BLS381>>& p, const uint8_t* b) { return g2_from_bytes<BLS381>(p, b); }
+
+template <class F>
+__device__ __forceinline__ void aff_to_bytes(uint8_t* b, const Aff<F>& p);
+template <>
+__device__ __forceinline__ void aff_to_bytes<F1<BN254>>(uint8_t* b, const Aff<F1<BN254>>& p) { g1_to_bytes<BN254>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F1<BLS381>>(uint8_t* b, const Aff<F1<BLS381>>& p) { g1_to_bytes<BLS381>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F2<BN254>>(uint8_t* b, const Aff<F2<BN254>>& p) { g2_to_bytes<BN254>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F2<BLS381>>(uint8_t* b, const Aff<F2<BLS381>>& p) { g2_to_bytes<BLS381>(b, p); }
+
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_sum_first(const uint8_t* pts, size_t n, int R, Jac<F>* out, uint32_t* flags) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = jac_inf<F>();
+  for (size_t k = lo; k < hi; ++k) {
+    Aff<F> p;
+    bool ok = aff_from_bytes<F>(p, pts + k * PT_BYTES);
+    ok = ok && aff_on_curve<F>(p);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+    acc = jac_add_aff<F>(acc, p);
+  }
+  out[t] = acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) k_sum_next(const Jac<F>* in, size_t n, int R, Jac<F>* out) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = in[lo];
+  for (size_t k = lo + 1; k < hi; ++k) acc = jac_add<F>(acc, in[k]);
+  out[t] = acc;
+}
+
+template <class F>
+__global__ void k_jac_to_bytes(const Jac<F>* in, size_t n, uint8_t* out, int pt_bytes) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aff_to_bytes<F>(out + i * pt_bytes, jac_to_aff<F>(in[i]));
+}
+
+// ---- ScalePoints ----
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
+                                              uint8_t* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+  ok = ok && aff_on_curve<F>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+  uint8_t sg = signs ? signs[i] : 0;
+  if (sg == 2) {  // nil factor: Copy()
+    aff_to_bytes<F>(out + i * PT_BYTES, p);
+    return;
+  }
+  u32 k[8];
+  const uint8_t* s = scalars + i * 32;
+  int top = -1;
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = s + 4 * (7 - j);
+    k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  for (int j = 7; j >= 0 && top < 0; --j)
+    if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+  if (sg == 1) p = aff_neg<F>(p);
+  Jac<F> r = jac_mul<F>(p, k, top + 1);
+  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(r));
+}
+
+template <class F, int PT_BYTES>
+__global__ void k_check(const uint8_t* pts, size_t n, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+  ok = ok && aff_on_curve<F>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+}
+
+template <class C>
+__global__ void k_generator(int group, uint8_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (group == BGLS_G1) {
+    Aff<F1<C>> g = {fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+    g1_to_bytes<C>(out, g);
+  } else {
+    Aff<F2<C>> g = {f2_load<C>(C::G2), f2_load<C>(C::G2 + 2 * C::L), false};
+    g2_to_bytes<C>(out, g);
+  }
+}
+
+// ---- peak probe: dependent-free v_mad_u64_u32 chains (roofline denominator) ----
+__global__ void __launch_bounds__(256) k_mad_probe(uint32_t seed, int iters, uint64_t* sink) {
+  uint32_t a = seed ^ (threadIdx.x * 2654435761u), b = seed + blockIdx.x * 40503u + 1u;
+  uint64_t acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = (uint64_t)j * 0x9e3779b97f4a7c15ull + a;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (uint64_t)(uint32_t)(a + j) * (uint32_t)(b + it) + acc[j];
+  }
+  uint64_t x = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) x ^= acc[j];
+  if (x == 0x1234567ull) sink[0] = x;
+}
+
+// ======================================================================= host side
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[256];
+  if (e != hipSuccess)
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(buf, sizeof buf, "%s", what);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                         \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return fail(BGLS_ERR_HIP, #expr, e_); \
+  } while (0)
+
+struct Ctx {
+  std::mutex mu;
+  int device = 0;
+  bool ready = false;
+  hipStream_t stream = nullptr;
+  std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
+  // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
+  bool prof = false;
+  struct Pending { hipEvent_t a, b; int stage; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+  double stage_ms[8] = {0};
+  unsigned long long stage_cnt[8] = {0};
+  hipEvent_t ev() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void collect() {
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { stage_ms[p.stage] += ms; stage_cnt[p.stage] += 1; }
+      ev_pool.push_back(p.a);
+      ev_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+
+  int ensure() {
+    if (ready) return 0;
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) return fail(BGLS_ERR_NO_DEVICE, "no HIP device available", e);
+    if (device >= cnt) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreate(&stream));
+    ws.assign(16, {nullptr, 0});
+    ready = true;
+    return 0;
+  }
+  int get(int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ws[slot].second < bytes) {
+      if (ws[slot].first) HIPCHK(hipFree(ws[slot].first));
+      ws[slot] = {nullptr, 0};
+      size_t cap = bytes + bytes / 4;
+      HIPCHK(hipMalloc(&ws[slot].first, cap));
+      ws[slot].second = cap;
+    }
+    *out = ws[slot].first;
+    return 0;
+  }
+};
+
+Ctx& ctx() {
+  static Ctx c;
+  return c;
+}
+
+enum { ST_DUP = 0, ST_H2C, ST_MILLER, ST_REDUCE, ST_FINAL, ST_SUM, ST_NUM };
+const char* const STAGE_NAMES[ST_NUM] = {"dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points"};
+
+struct Scope {  // brackets the launches of one stage with events when profiling is on
+  Ctx& c; hipStream_t st; int stage; hipEvent_t a = nullptr;
+  Scope(Ctx& c_, hipStream_t st_, int stage_) : c(c_), st(st_), stage(stage_) {
+    if (c.prof) { a = c.ev(); (void)hipEventRecord(a, st); }
+  }
+  ~Scope() {
+    if (c.prof && a) { hipEvent_t b = c.ev(); (void)hipEventRecord(b, st); c.pending.push_back({a, b, stage}); }
+  }
+};
+
+// workspace slots
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP };
+
+inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+template <class C>
+struct Engine {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  static constexpr size_t FB = C::FP_BYTES, G1B = 2 * FB, G2B = 4 * FB, GTB = 12 * FB;
+
+  // d_flags: device u32 (already zeroed by caller).  Writes the product of the n (+1) Miller
+  // values to d_partial (GT bytes, no final exponentiation).
+  static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
+                            int check_dups, uint8_t* d_partial, uint32_t* d_flags) {
+    const size_t total = n + (d_sig ? 1 : 0);
+    void *g1s, *fa, *fb;
+    int rc;
+    if ((rc = c.get(WS_G1S, (total + 1) * sizeof(Aff<G1F>), &g1s))) return rc;
+    if ((rc = c.get(WS_F_A, (total + 1) * sizeof(Fp12<C>), &fa))) return rc;
+    if ((rc = c.get(WS_F_B, (total / 4 + 2) * sizeof(Fp12<C>), &fb))) return rc;
+    if (check_dups && n > 1) {
+      uint32_t cap = 1;
+      while (cap < 2 * n) cap <<= 1;
+      void* tab;
+      if ((rc = c.get(WS_TABLE, (size_t)cap * 4, &tab))) return rc;
+      Scope sc(c, st, ST_DUP);
+      HIPCHK(hipMemsetAsync(tab, 0, (size_t)cap * 4, st));
+      k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, (uint32_t*)tab, cap - 1, d_flags);
+    }
+    if (n) {
+      Scope sc(c, st, ST_H2C);
+      k_h2c<C><<<nblk(n, 64), 64, 0, st>>>(mv, n, (Aff<G1F>*)g1s, d_flags);
+    }
+    if (d_sig) k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
+    if (total == 0) {
+      HIPCHK(hipMemsetAsync(d_partial, 0, GTB, st));
+      uint8_t one = 1;
+      HIPCHK(hipMemcpyAsync(d_partial + GTB - 1, &one, 1, hipMemcpyHostToDevice, st));
+      return 0;
+    }
+    {
+      Scope sc(c, st, ST_MILLER);
+      k_miller<C><<<nblk(total, 64), 64, 0, st>>>((const Aff<G1F>*)g1s, d_keys, total, d_sig ? (long long)n : -1LL,
+                                                  (Fp12<C>*)fa, d_flags);
+    }
+    Scope sc(c, st, ST_REDUCE);
+    return reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, total, d_partial);
+  }
+
+  static int reduce_to_bytes(hipStream_t st, Fp12<C>* a, Fp12<C>* b, size_t cnt, uint8_t* d_out) {
+    const int R = 8;
+    while (cnt > 1) {
+      size_t nout = (cnt + R - 1) / R;
+      k_f12_reduce<C><<<nblk(nout, 64), 64, 0, st>>>(a, cnt, R, b);
+      Fp12<C>* t = a;
+      a = b;
+      b = t;
+      cnt = nout;
+    }
+    k_f12_to_bytes<C><<<1, 64, 0, st>>>(a, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
+  // returns 1/0 or <0; optionally copies the GT bytes out
+  static int finalize(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
+                      uint8_t* h_gt_out) {
+    void *tmp, *fl;
+    int rc;
+    if ((rc = c.get(WS_TMP, GTB + 16, &tmp))) return rc;
+    if ((rc = c.get(WS_OUT, 16, &fl))) return rc;
+    uint8_t* d_gt = (uint8_t*)tmp;
+    uint32_t* d_verdict = (uint32_t*)(d_gt + GTB);
+    uint32_t* d_fl2 = (uint32_t*)fl;
+    HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
+    {
+      Scope sc(c, st, ST_FINAL);
+      k_final<C><<<1, 64, 0, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+    }
+    HIPCHK(hipGetLastError());
+    uint32_t h[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(&h[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&h[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
+    if (d_flags_in) HIPCHK(hipMemcpyAsync(&h[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
+    if (h_gt_out) HIPCHK(hipMemcpyAsync(h_gt_out, d_gt, GTB, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c.collect();
+    uint32_t f = h[1] | h[2];
+    if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+    if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
+    if (f & FLAG_DUP) return 0;
+    return h[0] ? 1 : 0;
+  }
+
+  template <class F, int PTB>
+  static int sum_points(Ctx& c, hipStream_t st, const uint8_t* d_pts, size_t n, uint8_t* d_out, uint32_t* d_flags) {
+    if (n == 0) {
+      HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
+      return 0;
+    }
+    const int R = 16;
+    void *ja, *jb;
+    int rc;
+    Scope sc(c, st, ST_SUM);
+    size_t n1 = (n + R - 1) / R;
+    if ((rc = c.get(WS_JAC_A, (n1 + 1) * sizeof(Jac<F>), &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (n1 / R + 2) * sizeof(Jac<F>), &jb))) return rc;
+    k_sum_first<F, PTB><<<nblk(n1, 64), 64, 0, st>>>(d_pts, n, R, (Jac<F>*)ja, d_flags);
+    Jac<F>*a = (Jac<F>*)ja, *b = (Jac<F>*)jb;
+    size_t cnt = n1;
+    while (cnt > 1) {
+      size_t nout = (cnt + R - 1) / R;
+      k_sum_next<F><<<nblk(nout, 64), 64, 0, st>>>(a, cnt, R, b);
+      Jac<F>* t = a;
+      a = b;
+      b = t;
+      cnt = nout;
+    }
+    k_jac_to_bytes<F><<<1, 64, 0, st>>>(a, 1, d_out, PTB);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+};
+
+int flags_to_rc(uint32_t f) {
+  if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+  if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
+  return 0;
+}
+
+#define DISPATCH(curve, CALL)                                    \
+  do {                                                           \
+    if ((curve) == BGLS_CURVE_ALTBN128) {                        \
+      typedef BN254 CV;                                          \
+      return CALL;                                               \
+    } else if ((curve) == BGLS_CURVE_BLS12_381) {                \
+      typedef BLS381 CV;                                         \
+      return CALL;                                               \
+    }                                                            \
+    return fail(BGLS_ERR_ARG, "unknown curve id");               \
+  } while (0)
+
+template <class C>
+int verify_aggregate_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* blob, const uint64_t* off, size_t n, int allow_dups) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = n ? off[n] : 0;
+  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, mv, n, !allow_dups, (uint8_t*)d_part,
+                              (uint32_t*)d_flags)))
+    return rc;
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, size_t n, const uint8_t* d_msg,
+                       size_t msg_len) {
+  typedef Engine<C> E;
+  int rc;
+  void *d_flags, *d_g2s, *d_g1s, *fa, *fb, *d_part;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_TMP + 1, 2 * E::G2B, &d_g2s))) return rc;
+  if ((rc = c.get(WS_G1S, 4 * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_F_A, 4 * sizeof(Fp12<C>), &fa))) return rc;
+  if ((rc = c.get(WS_F_B, 4 * sizeof(Fp12<C>), &fb))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  // apk = sum(keys)  (AggregatePoints)
+  if ((rc = E::template sum_points<F2<C>, (int)E::G2B>(c, st, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags))) return rc;
+  // h = -H(msg); pairs (h, apk), (sig, g2)
+  MsgView mv = {d_msg, nullptr, msg_len, msg_len};
+  Aff<F1<C>>* g1s = (Aff<F1<C>>*)d_g1s;
+  k_h2c<C><<<1, 64, 0, st>>>(mv, 1, g1s + 2, (uint32_t*)d_flags);
+  k_g1_to_bytes<C><<<1, 64, 0, st>>>(g1s + 2, 1, (uint8_t*)d_part);           // scratch: H(m) bytes
+  k_g1_parse<C><<<1, 64, 0, st>>>((const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);  // -H(m)
+  k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);               // sig
+  k_miller<C><<<1, 64, 0, st>>>(g1s, (const uint8_t*)d_g2s, 2, 1LL, (Fp12<C>*)fa, (uint32_t*)d_flags);
+  if ((rc = E::reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, 2, (uint8_t*)d_part))) return rc;
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int verify_multi_t(const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sig, *d_keys, *d_msg;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, msg_len, &d_msg))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (msg_len) HIPCHK(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len);
+}
+
+template <class C>
+int pairing_product_t(const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void *d_g1b, *d_g2b, *d_g1s, *fa, *fb, *d_flags, *d_part;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_g1b))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_g2b))) return rc;
+  if ((rc = c.get(WS_G1S, (n + 1) * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_F_A, (n + 1) * sizeof(Fp12<C>), &fa))) return rc;
+  if ((rc = c.get(WS_F_B, (n / 4 + 2) * sizeof(Fp12<C>), &fb))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n == 0) {
+    memset(gt_out, 0, E::GTB);
+    gt_out[E::GTB - 1] = 1;
+    return 0;
+  }
+  HIPCHK(hipMemcpyAsync(d_g1b, g1s, n * E::G1B, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_g2b, g2s, n * E::G2B, hipMemcpyHostToDevice, st));
+  k_g1_parse<C><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_g1b, n, 0, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags);
+  k_miller<C><<<nblk(n, 64), 64, 0, st>>>((const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_g2b, n, -1LL, (Fp12<C>*)fa, (uint32_t*)d_flags);
+  if ((rc = E::reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, n, (uint8_t*)d_part))) return rc;
+  rc = E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, gt_out);
+  return rc < 0 ? rc : 0;
+}
+
+template <class C>
+int hash_to_g1_t(const uint8_t* blob, const uint64_t* off, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = off[n];
+  void *d_blob, *d_off, *d_g1s, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_G1S, n * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  k_h2c<C><<<nblk(n, 64), 64, 0, st>>>(mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags);
+  k_g1_to_bytes<C><<<nblk(n, 64), 64, 0, st>>>((const Aff<F1<C>>*)d_g1s, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int aggregate_points_t(int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * PB, &d_in))) return rc;
+  if ((rc = c.get(WS_OUT, PB, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_in, pts, n * PB, hipMemcpyHostToDevice, st));
+  if (group == BGLS_G1)
+    rc = E::template sum_points<F1<C>, (int)E::G1B>(c, st, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  else
+    rc = E::template sum_points<F2<C>, (int)E::G2B>(c, st, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  if (rc) return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int scale_points_t(int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_sc, *d_sg, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * PB, &d_in))) return rc;
+  if ((rc = c.get(WS_IN_C, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_IN_D, n, &d_sg))) return rc;
+  if ((rc = c.get(WS_IN_A, n * PB, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, pts, n * PB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, st));
+  if (signs) HIPCHK(hipMemcpyAsync(d_sg, signs, n, hipMemcpyHostToDevice, st));
+  const uint8_t* sg = signs ? (const uint8_t*)d_sg : nullptr;
+  if (group == BGLS_G1)
+    k_scale<F1<C>, (int)E::G1B><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out,
+                                                             (uint32_t*)d_flags);
+  else
+    k_scale<F2<C>, (int)E::G2B><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out,
+                                                             (uint32_t*)d_flags);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int point_check_t(int group, const uint8_t* a) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_flags;
+  if ((rc = c.get(WS_IN_B, PB, &d_in))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, a, PB, hipMemcpyHostToDevice, st));
+  if (group == BGLS_G1)
+    k_check<F1<C>, (int)E::G1B><<<1, 64, 0, st>>>((const uint8_t*)d_in, 1, (uint32_t*)d_flags);
+  else
+    k_check<F2<C>, (int)E::G2B><<<1, 64, 0, st>>>((const uint8_t*)d_in, 1, (uint32_t*)d_flags);
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return f ? 0 : 1;
+}
+
+template <class C>
+int generator_t(int group, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void* d_out;
+  if ((rc = c.get(WS_OUT, PB, &d_out))) return rc;
+  k_generator<C><<<1, 64, 0, st>>>(group, (uint8_t*)d_out);
+  HIPCHK(hipMemcpyAsync(out, d_out, PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+template <class C>
+int gt_mul_t(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void* d_in;
+  if ((rc = c.get(WS_IN_A, 2 * E::GTB, &d_in))) return rc;
+  HIPCHK(hipMemcpyAsync(d_in, a, E::GTB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((uint8_t*)d_in + E::GTB, b, E::GTB, hipMemcpyHostToDevice, st));
+  rc = E::finalize(c, st, (const uint8_t*)d_in, 2, 0, nullptr, out);
+  return rc < 0 ? rc : 0;
+}
+
+template <class C>
+int miller_product_dev_t(const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
+                         int check_dups, void* d_partial, void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  return E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, mv, n, check_dups, (uint8_t*)d_partial,
+                           (uint32_t*)d_flags);
+}
+
+template <class C>
+int final_verify_dev_t(const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return E::finalize(c, st, (const uint8_t*)d_partials, count, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int aggregate_points_dev_t(int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  void* d_flags;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (group == BGLS_G1)
+    rc = E::template sum_points<F1<C>, (int)E::G1B>(c, st, (const uint8_t*)d_pts, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  else
+    rc = E::template sum_points<F2<C>, (int)E::G2B>(c, st, (const uint8_t*)d_pts, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  if (rc) return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len, void* stream) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len);
+}
+
+bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+int bgls_abi_version(void) { return 1; }
+
+const char* bgls_last_error(void) { return g_err.c_str(); }
+
+int bgls_init(int device) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (c.ready && c.device == device) return 0;
+  if (c.ready) return fail(BGLS_ERR_ARG, "bgls_init: context already bound to another device");
+  c.device = device;
+  return c.ensure();
+}
+
+size_t bgls_fp_size(int curve) { return curve == BGLS_CURVE_ALTBN128 ? 32 : curve == BGLS_CURVE_BLS12_381 ? 48 : 0; }
+size_t bgls_g1_size(int curve) { return 2 * bgls_fp_size(curve); }
+size_t bgls_g2_size(int curve) { return 4 * bgls_fp_size(curve); }
+size_t bgls_gt_size(int curve) { return 12 * bgls_fp_size(curve); }
+
+int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                          size_t n, int allow_duplicates) {
+  if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_aggregate_t<CV>(sig, keys, msg_blob, msg_off, n, allow_duplicates));
+}
+
+int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
+}
+
+int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+  if (!gt_out || (n && (!g1s || !g2s))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, pairing_product_t<CV>(g1s, g2s, n, gt_out));
+}
+
+int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out) {
+  if (n && (!msg_off || !g1_out)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, hash_to_g1_t<CV>(msg_blob, msg_off, n, g1_out));
+}
+
+int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (!group_ok(group) || !out || (n && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, aggregate_points_t<CV>(group, pts, n, out));
+}
+
+int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
+                      uint8_t* out) {
+  if (!group_ok(group) || (n && (!pts || !scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, scale_points_t<CV>(group, pts, scalars, signs, n, out));
+}
+
+int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (!group_ok(group) || !a || !b || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  size_t pb = group == BGLS_G1 ? bgls_g1_size(curve) : bgls_g2_size(curve);
+  if (!pb) return fail(BGLS_ERR_ARG, "unknown curve id");
+  std::vector<uint8_t> two(2 * pb);
+  memcpy(two.data(), a, pb);
+  memcpy(two.data() + pb, b, pb);
+  return bgls_aggregate_points(curve, group, two.data(), 2, out);
+}
+
+int bgls_point_check(int curve, int group, const uint8_t* a) {
+  if (!group_ok(group) || !a) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, point_check_t<CV>(group, a));
+}
+
+int bgls_generator(int curve, int group, uint8_t* out) {
+  if (!group_ok(group) || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, generator_t<CV>(group, out));
+}
+
+int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out) {
+  return bgls_pairing_product(curve, g1, g2, 1, gt_out);
+}
+
+int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (!a || !b || !out) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, gt_mul_t<CV>(a, b, out));
+}
+
+int bgls_gt_identity(int curve, uint8_t* out) {
+  size_t n = bgls_gt_size(curve);
+  if (!n || !out) return fail(BGLS_ERR_ARG, "unknown curve id or NULL argument");
+  memset(out, 0, n);
+  out[n - 1] = 1;
+  return 0;
+}
+
+int bgls_profile_enable(int on) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.prof = on != 0;
+  for (int i = 0; i < 8; ++i) { c.stage_ms[i] = 0; c.stage_cnt[i] = 0; }
+  return 0;
+}
+
+int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches) {
+  if (!stage || !total_ms || !launches) return fail(BGLS_ERR_ARG, "NULL argument");
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (int i = 0; i < ST_NUM; ++i)
+    if (!strcmp(stage, STAGE_NAMES[i])) {
+      *total_ms = c.stage_ms[i];
+      *launches = c.stage_cnt[i];
+      return 0;
+    }
+  return fail(BGLS_ERR_ARG, "unknown stage name");
+}
+
+int bgls_probe_mad_peak(double* mac_per_s) {
+  if (!mac_per_s) return fail(BGLS_ERR_ARG, "NULL argument");
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void* sink;
+  if ((rc = c.get(WS_OUT, 16, &sink))) return rc;
+  const int iters = 4096, blocks = 256 * 8, threads = 256;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHK(hipEventRecord(a, st));
+    k_mad_probe<<<blocks, threads, 0, st>>>(12345u + rep, iters, (uint64_t*)sink);
+    HIPCHK(hipEventRecord(b, st));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    double macs = (double)blocks * threads * iters * 16.0;
+    double rate = macs / (ms * 1e-3);
+    if (rep > 0 && rate > best) best = rate;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *mac_per_s = best;
+  return 0;
+}
+
+int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len,
+                            size_t msg_stride, size_t n, int check_duplicates, void* d_partial_out, void* d_flags,
+                            void* stream) {
+  if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
+                                           d_flags, stream));
+}
+
+int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, final_verify_dev_t<CV>(d_partials, count, d_flags, stream));
+}
+
+int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+  if (!group_ok(group) || !d_out || (n && !d_pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, aggregate_points_dev_t<CV>(group, d_pts, n, d_out, stream));
+}
+
+int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
+                          void* stream) {
+  if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+/*
+ * bgls_hip.h -- C ABI of the MI355X aggregate-signature verification engine.
+ *
+ * Drop-in boundary for the hot path of Project-Arda/bgls: everything the Go package `curves`
+ * reaches through its CurveSystem / Point / PointT interfaces (curves/curve.go:12-70) and the
+ * goroutine helpers built on them (curves/curve.go:73-223), restated as BATCH entry points so
+ * one cgo call replaces n goroutines.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   curve   : BGLS_CURVE_ALTBN128 (curves.Altbn128, curves/altbn128.go:32) or
+ *             BGLS_CURVE_BLS12_381 (curves.Bls12, curves/bls12_381.go:31)
+ *   return  : verify-style calls return 1 (valid) / 0 (invalid); every call returns < 0 on a
+ *             usage or runtime error.  The Go shim maps anything != 1 to `false` / `nil,false`,
+ *             which is the reference's only error convention (curves/curve.go:15-22,46-48;
+ *             bgls/bgls.go:95-97,115-118).  No exceptions, no abort().
+ *   formats : uncompressed big-endian wire formats of the reference --
+ *             G1 = x||y (curves/altbn128.go:42-57; curves/testcases/bls12G1Hash.dat),
+ *             G2 = x_im||x_re||y_im||y_re (curves/altbn128.go:157-179, altbn128_test.go:26-38;
+ *                  curves/bls12_381.go:147-158,209-226),
+ *             infinity = all-zero bytes (curves/altbn128.go:431-439),
+ *             GT = 12 field elements (384 B / 576 B; curves/altbn128.go:378-387), layout in
+ *                  DESIGN.md (byte-parity with the upstream Go libraries is unpinned).
+ *             Sizes: bgls_g1_size / bgls_g2_size / bgls_gt_size.
+ *   memory  : the caller owns every buffer; inputs are const and never modified (the reference's
+ *             in-place mutation quirks, curves/altbn128.go:306-309,344-349 and
+ *             curves/bls12_381.go:70,131, are NOT reproduced).
+ *   threads : every entry point may be called concurrently; calls on one context serialise.
+ *   device  : all arithmetic runs in HIP kernels on the selected GPU; there is no CPU fallback.
+ *             If no gfx950 device is usable every compute call returns BGLS_ERR_NO_DEVICE.
+ */
+#ifndef BGLS_HIP_H
+#define BGLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGLS_CURVE_ALTBN128 0
+#define BGLS_CURVE_BLS12_381 1
+
+#define BGLS_G1 1
+#define BGLS_G2 2
+
+#define BGLS_ERR_ARG (-1)       /* bad curve/group id, NULL pointer, inconsistent offsets */
+#define BGLS_ERR_ENCODING (-2)  /* a coordinate >= q, or a point not on its curve */
+#define BGLS_ERR_HASH (-3)      /* try-and-increment exhausted 256 counters (probability 2^-256) */
+#define BGLS_ERR_NO_DEVICE (-4) /* no usable HIP device */
+#define BGLS_ERR_HIP (-5)       /* a HIP runtime call failed; see bgls_last_error() */
+
+/* ---- runtime ---------------------------------------------------------------------------- */
+/* Select the HIP device used by the calling process (default 0).  Idempotent. */
+int bgls_init(int device);
+/* Human-readable text for the last error on this thread ("" if none). */
+const char* bgls_last_error(void);
+/* ABI version; bumped on any signature change. */
+int bgls_abi_version(void);
+
+size_t bgls_fp_size(int curve); /* 32 / 48 */
+size_t bgls_g1_size(int curve); /* 64 / 96 */
+size_t bgls_g2_size(int curve); /* 128 / 192 */
+size_t bgls_gt_size(int curve); /* 384 / 576 */
+
+/* ---- the hot path, host buffers ------------------------------------------------------------ */
+
+/* bgls.VerifyAggregateSignature (bgls/bgls.go:82-84) -> verifyAggSig (bgls/bgls.go:94-119).
+ * keys: n G2 points; messages: msg_blob[msg_off[i] .. msg_off[i+1]), i < n (msg_off has n+1
+ * entries).  allow_duplicates = 0 reproduces the duplicate-message rejection
+ * (containsDuplicateMessage, bgls/bgls.go:139-150); 1 is the Kosk / distinct-message callers'
+ * mode (bgls/blsKosk.go:100-106, bgls/blsDistinctMessage.go:45-57).
+ * Computes e(-sig, g2) * prod_i e(HashToG1(m_i), pk_i) == 1. */
+int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob,
+                          const uint64_t* msg_off, size_t n, int allow_duplicates);
+
+/* verifyMultiSignature (bgls/bgls.go:89-92): apk = sum(keys) (AggregatePoints,
+ * curves/curve.go:73-121) then VerifySingleSignature (bgls/bgls.go:59-70) on msg.
+ * KoskVerifyMultiSignature (bgls/blsKosk.go:117-120) is this call with 0x01 prepended to msg. */
+int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg,
+                      size_t msg_len);
+
+/* CurveSystem.PairingProduct (curves/altbn128.go:143-145, curves/bls12_381.go:238-240 ->
+ * concurrentPairingProduct, curves/curve.go:125-170): gt_out = prod_i e(g1s[i], g2s[i]). */
+int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out);
+
+/* CurveSystem.HashToG1 over a batch (curves/altbn128.go:509-513, curves/bls12_381.go:349-351;
+ * the per-message goroutines of bgls/bgls.go:107-111,134-137). g1_out: n G1 points. */
+int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out);
+
+/* curves.AggregatePoints (curves/curve.go:73-121): out = sum of n points of `group`.
+ * n == 0 yields infinity (the reference spins forever there, curves/curve.go:94-108). */
+int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out);
+
+/* curves.ScalePoints (curves/curve.go:190-214) -> Point.Mul (curves/altbn128.go:107-121,235-249;
+ * curves/bls12_381.go:65-76,126-137): out[i] = k_i * pts[i].  scalars: n x 32-byte big-endian
+ * magnitudes; signs: NULL (all non-negative) or n bytes, 0 = +, 1 = negative (negate-then-mul),
+ * 2 = nil factor (copy the point). */
+int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs,
+                      size_t n, uint8_t* out);
+
+/* ---- per-point operations backing the Go Point / PointT methods --------------------------- */
+/* Point.Add (curves/altbn128.go:59-66,181-188; curves/bls12_381.go:33-41,94-102) */
+int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out);
+/* MakeG1Point/MakeG2Point/Unmarshal* validation (curves/altbn128.go:42-57,157-179;
+ * curves/bls12_381.go:196-226): 1 if canonical and on the curve, 0 otherwise. */
+int bgls_point_check(int curve, int group, const uint8_t* a);
+/* GetG1 / GetG2 (curves/altbn128.go:423-429, curves/bls12_381.go:275-281) */
+int bgls_generator(int curve, int group, uint8_t* out);
+/* CurveSystem.Pair (curves/altbn128.go:130-141, curves/bls12_381.go:228-236) */
+int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out);
+/* PointT.Add = Fp12 multiplication (curves/altbn128.go:264-271, curves/bls12_381.go:160-168) */
+int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out);
+/* GetGTIdentity (curves/altbn128.go:441-443,478; curves/bls12_381.go:295-297,341) */
+int bgls_gt_identity(int curve, uint8_t* out);
+
+/* ---- device-resident variants (inputs already in HBM; used by bench.py and multi-GPU) ------ */
+/* All pointers prefixed d_ are device pointers on the current device; `stream` is a hipStream_t
+ * (NULL = the context's own stream).  Calls are asynchronous unless they return a verdict. */
+
+/* Partial Miller product of one shard: d_partial_out (bgls_gt_size bytes, GT wire format of the
+ * UN-exponentiated Fp12 value) = [miller(-sig, g2) if d_sig != NULL] * prod_i miller(H(m_i), pk_i).
+ * Messages are fixed-stride: message i is d_msgs[i*msg_stride .. i*msg_stride + msg_len).
+ * check_duplicates != 0 runs the exact duplicate-message scan on the device; *d_flags (one
+ * uint32 in HBM, bit 0 = duplicate found, bit 1 = bad encoding, bit 2 = hash failure) is OR-ed. */
+int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, const void* d_msgs,
+                            size_t msg_len, size_t msg_stride, size_t n, int check_duplicates,
+                            void* d_partial_out, void* d_flags, void* stream);
+
+/* Multiply `count` partial products (count x bgls_gt_size bytes, e.g. the all-gathered shards),
+ * apply the single shared final exponentiation and compare with 1.  Returns 1 / 0 / < 0.
+ * d_flags (may be NULL) is read: any bit set forces 0 (duplicate) or the matching error. */
+int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags,
+                          void* stream);
+
+/* Device-resident key sum for the multisig path: d_out = projective partial sum of n G2 keys,
+ * serialised as affine G2 bytes (bgls_g2_size).  Shards combine with bgls_aggregate_points. */
+int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream);
+
+/* verify_multi with keys already on the device. */
+int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg,
+                          size_t msg_len, void* stream);
+
+/* ---- measurement hooks (bench.py; not part of the reference's interface) ------------------ */
+/* Per-stage device time, measured with HIP events on the stream the kernels are launched on.
+ * Stages: "dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points". */
+int bgls_profile_enable(int on); /* also resets the counters */
+int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches);
+/* Measured peak of dependent-free v_mad_u64_u32 chains on this GPU, in 32x32->64 MAC/s:
+ * the roofline denominator for the integer-multiply-bound kernels. */
+int bgls_probe_mad_peak(double* mac_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGLS_HIP_H */

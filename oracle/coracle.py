@@ -1,0 +1,97 @@
+"""ctypes wrapper of the C oracle (oracle/c/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "c", "liboracle.so")
+_lib = None
+u8p = ctypes.POINTER(ctypes.c_uint8)
+FP = {0: 32, 1: 48}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "c")], check=True)
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _b(x):
+    x = bytes(x)
+    return (ctypes.c_uint8 * max(1, len(x))).from_buffer_copy(x if x else b"\0")
+
+
+def _offsets(msgs):
+    off = (ctypes.c_uint64 * (len(msgs) + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        off[i] = acc
+        acc += len(m)
+    off[len(msgs)] = acc
+    return off
+
+
+def hash_to_g1(curve, msg):
+    o = (ctypes.c_uint8 * (2 * FP[curve]))()
+    rc = lib().oracle_hash_to_g1(curve, _b(msg), ctypes.c_size_t(len(msg)), o)
+    assert rc == 0, rc
+    return bytes(o)
+
+
+def miller(curve, g1, g2):
+    o = (ctypes.c_uint8 * (12 * FP[curve]))()
+    assert lib().oracle_miller(curve, _b(g1), _b(g2), o) == 0
+    return bytes(o)
+
+
+def final_exp(curve, gt):
+    o = (ctypes.c_uint8 * (12 * FP[curve]))()
+    assert lib().oracle_final_exp(curve, _b(gt), o) == 0
+    return bytes(o)
+
+
+def pairing_product(curve, g1s, g2s, n, threads=1, faithful=0):
+    o = (ctypes.c_uint8 * (12 * FP[curve]))()
+    rc = lib().oracle_pairing_product(curve, _b(g1s), _b(g2s), ctypes.c_size_t(n), o, threads, faithful)
+    assert rc == 0, rc
+    return bytes(o)
+
+
+def verify_aggregate(curve, sig, keys, msgs, allow_dups=False, threads=1, faithful=0):
+    return lib().oracle_verify_aggregate(curve, _b(sig), _b(keys), _b(b"".join(msgs)), _offsets(msgs),
+                                         ctypes.c_size_t(len(msgs)), 1 if allow_dups else 0, threads, faithful)
+
+
+def verify_multi(curve, sig, keys, n, msg, faithful=0):
+    return lib().oracle_verify_multi(curve, _b(sig), _b(keys), ctypes.c_size_t(n), _b(msg), ctypes.c_size_t(len(msg)), faithful)
+
+
+def aggregate_points(curve, group, pts, n):
+    size = (2 if group == 1 else 4) * FP[curve]
+    o = (ctypes.c_uint8 * size)()
+    assert lib().oracle_aggregate_points(curve, group, _b(pts), ctypes.c_size_t(n), o) == 0
+    return bytes(o)
+
+
+def scale_point(curve, group, pt, k):
+    size = (2 if group == 1 else 4) * FP[curve]
+    o = (ctypes.c_uint8 * size)()
+    assert lib().oracle_scale_point(curve, group, _b(pt), _b(abs(k).to_bytes(32, "big")), 1 if k < 0 else 0, o) == 0
+    return bytes(o)
+
+
+def miller_product(curve, g1s, g2s, n, threads=1):
+    o = (ctypes.c_uint8 * (12 * FP[curve]))()
+    rc = lib().oracle_miller_product(curve, _b(g1s), _b(g2s), ctypes.c_size_t(n), o, threads)
+    assert rc == 0, rc
+    return bytes(o)
+
+
+def gt_mul(curve, a, b):
+    o = (ctypes.c_uint8 * (12 * FP[curve]))()
+    assert lib().oracle_gt_mul(curve, _b(a), _b(b), o) == 0
+    return bytes(o)

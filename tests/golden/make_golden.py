@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Regenerate the golden fixtures under tests/golden/ (run in the build container only).
+
+ h2c_kat.json        the reference's own hash-to-G1 vectors, re-encoded as hex DATA:
+                     curves/testcases/altbn128G1Hash.dat, curves/testcases/bls12G1Hash.dat,
+                     curves/altbn128_test.go:16-21 (Solidity point), curves/bls12_test.go:57-67,
+                     curves/altbn128_test.go:26-38 (G2 generator coordinates).
+ vectors_<curve>.json  outputs of the Python oracle (oracle/pyref) on seeded inputs: Miller / GT
+                     values, pairing products, group sums, scalar multiples, extra hash-to-G1
+                     messages, end-to-end accept/reject cases mirroring bgls/bgls_test.go:40-77 and
+                     bgls/blsKosk_test.go:35-64.
+"""
+import base64, json, os, random, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+from oracle.pyref.params import BN254, BLS381
+from oracle.pyref.pairing import Pairing
+from oracle.pyref import h2c, scheme
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/curves/testcases"
+
+
+def kat():
+    out = {}
+    for name, n in (("altbn128", 32), ("bls12", 48)):
+        rows = []
+        for line in open(os.path.join(REF, name + "G1Hash.dat")):
+            a, b = line.strip().split(",")
+            rows.append({"msg": base64.b64decode(a).hex(), "point": base64.b64decode(b).hex()})
+        out[name] = rows
+    a = 9121282642809701931333593728297233225556711250127745709186816755779879923737
+    x = 11423386531623885114587219621463106117140760157404497425836076043015227528156
+    y = 20262289731964024720969923714809935701428881933342918937283877214228227624643
+    out["altbn128"].append({"msg": a.to_bytes((a.bit_length() + 7) // 8, "big").hex(), "point": (x.to_bytes(32, "big") + y.to_bytes(32, "big")).hex()})
+    x = 315124130825307604287835216317628428134609737854237653839182597515996444073032649481416725367158979153513345579672
+    y = 3093537746211397858160667262592024570071165158580434464756577567510401504168962073691924150397172185836012224315174
+    out["bls12"].append({"msg": "", "point": (x.to_bytes(48, "big") + y.to_bytes(48, "big")).hex()})
+    g2 = [11559732032986387107991004021392285783925812861821192530917403151452391805634,
+          10857046999023057135944570762232829481370756359578518086990519993285655852781,
+          4082367875863433681332203403145435568316851327593401208105741076214120093531,
+          8495653923123431417604973247489272438418190587263600148770280649306958101930]
+    out["altbn128_g2_generator"] = b"".join(v.to_bytes(32, "big") for v in g2).hex()
+    json.dump(out, open(os.path.join(HERE, "h2c_kat.json"), "w"), indent=1)
+
+
+def vectors(c, seed):
+    rnd = random.Random(seed)
+    PR = Pairing(c); G = PR.G; T = PR.T
+    v = {"curve": c.name}
+    # pairings
+    pairs = []
+    for i in range(3):
+        P = G.g1_mul(c.g1, rnd.randrange(1, c.r)); Q = G.g2_mul(c.g2, rnd.randrange(1, c.r))
+        m = PR.miller(P, Q)
+        pairs.append({"g1": G.g1_bytes(P).hex(), "g2": G.g2_bytes(Q).hex(), "miller": PR.gt_bytes(m).hex(), "gt": PR.gt_bytes(PR.final_exp(m)).hex()})
+    pairs.append({"g1": G.g1_bytes(c.g1).hex(), "g2": G.g2_bytes(c.g2).hex(), "miller": PR.gt_bytes(PR.miller(c.g1, c.g2)).hex(), "gt": PR.gt_bytes(PR.pair(c.g1, c.g2)).hex()})
+    one = PR.gt_bytes(T.F12_ONE).hex()
+    pairs.append({"g1": G.g1_bytes(None).hex(), "g2": G.g2_bytes(c.g2).hex(), "miller": one, "gt": one})
+    pairs.append({"g1": G.g1_bytes(c.g1).hex(), "g2": G.g2_bytes(None).hex(), "miller": one, "gt": one})
+    v["pairings"] = pairs
+    Ps = [G.g1_mul(c.g1, rnd.randrange(1, c.r)) for _ in range(5)]
+    Qs = [G.g2_mul(c.g2, rnd.randrange(1, c.r)) for _ in range(5)]
+    v["pairing_product"] = {"g1s": [G.g1_bytes(P).hex() for P in Ps], "g2s": [G.g2_bytes(Q).hex() for Q in Qs],
+                            "gt": PR.gt_bytes(PR.pairing_product(Ps, Qs)).hex()}
+    # group sums (with a repeated point and an inverse pair) and scalar multiples
+    pts1 = Ps + [Ps[0], G.g1_neg(Ps[1])]
+    pts2 = Qs + [Qs[0], G.g2_neg(Qs[1])]
+    v["sum_g1"] = {"pts": [G.g1_bytes(P).hex() for P in pts1], "sum": G.g1_bytes(G.g1_sum(pts1)).hex()}
+    v["sum_g2"] = {"pts": [G.g2_bytes(P).hex() for P in pts2], "sum": G.g2_bytes(G.g2_sum(pts2)).hex()}
+    ks = [0, 1, 2, c.r - 1, c.r, rnd.randrange(c.r), -rnd.randrange(c.r), 2**64 + 12345]
+    v["scale_g1"] = [{"pt": G.g1_bytes(Ps[0]).hex(), "k": str(k), "out": G.g1_bytes(G.g1_mul(Ps[0], k)).hex()} for k in ks]
+    v["scale_g2"] = [{"pt": G.g2_bytes(Qs[0]).hex(), "k": str(k), "out": G.g2_bytes(G.g2_mul(Qs[0], k)).hex()} for k in ks]
+    # extra hash-to-G1 messages: block-boundary lengths of Keccak (136) / BLAKE2b (128)
+    hs = []
+    for ln in (0, 1, 31, 32, 33, 64, 123, 124, 127, 128, 134, 135, 136, 137, 200, 271, 272, 400):
+        m = rnd.randbytes(ln)
+        hs.append({"msg": m.hex(), "point": G.g1_bytes(h2c.hash_to_g1(c, m)).hex()})
+    v["h2c"] = hs
+    # end-to-end aggregate cases (bgls/bgls_test.go:40-77)
+    cases = []
+    for n in (1, 2, 6):
+        sks = [rnd.randrange(1, c.r) for _ in range(n + 1)]
+        msgs = [rnd.randbytes(32) for _ in range(n)]
+        keys = [scheme.load_public_key(c, s) for s in sks]
+        sigs = [scheme.sign(c, s, m) for s, m in zip(sks, msgs)]
+        agg = G.g1_sum(sigs)
+        kb = [G.g2_bytes(k).hex() for k in keys]
+        mh = [m.hex() for m in msgs]
+        cases.append({"name": "valid_n%d" % n, "sig": G.g1_bytes(agg).hex(), "keys": kb[:n], "msgs": mh, "allow_dups": False, "expect": True})
+        if n > 1:
+            cases.append({"name": "missing_key_n%d" % n, "sig": G.g1_bytes(agg).hex(), "keys": kb[:n - 1], "msgs": mh, "allow_dups": False, "expect": False})
+            sw = [mh[1], mh[0]] + mh[2:]
+            cases.append({"name": "swapped_msgs_n%d" % n, "sig": G.g1_bytes(agg).hex(), "keys": kb[:n], "msgs": sw, "allow_dups": False, "expect": False})
+            # duplicate message: extra signer signs msgs[0]
+            sdup = G.g1_add(agg, scheme.sign(c, sks[n], msgs[0]))
+            cases.append({"name": "duplicate_msg_n%d" % n, "sig": G.g1_bytes(sdup).hex(), "keys": kb, "msgs": mh + [mh[0]], "allow_dups": False, "expect": False})
+            cases.append({"name": "duplicate_msg_allowed_n%d" % n, "sig": G.g1_bytes(sdup).hex(), "keys": kb, "msgs": mh + [mh[0]], "allow_dups": True, "expect": True})
+            cases.append({"name": "wrong_sig_n%d" % n, "sig": G.g1_bytes(sdup).hex(), "keys": kb[:n], "msgs": mh, "allow_dups": False, "expect": False})
+        cases.append({"name": "tampered_msg_n%d" % n, "sig": G.g1_bytes(agg).hex(), "keys": kb[:n], "msgs": mh[:-1] + [(msgs[-1] + b"!").hex()], "allow_dups": False, "expect": False})
+    for c_ in cases:
+        got = scheme.verify_agg(c, G.g1_from_bytes(bytes.fromhex(c_["sig"])), [G.g2_from_bytes(bytes.fromhex(k)) for k in c_["keys"]],
+                                [bytes.fromhex(m) for m in c_["msgs"]], c_["allow_dups"])
+        assert got == c_["expect"], c_["name"]
+    v["aggregate_cases"] = cases
+    # multisig cases (bgls/blsKosk_test.go:35-64); msg already carries the Kosk 0x01 prefix
+    mc = []
+    for n in (1, 2, 8):
+        sks = [rnd.randrange(1, c.r) for _ in range(n)]
+        msg = b"\x01" + rnd.randbytes(32)
+        keys = [scheme.load_public_key(c, s) for s in sks]
+        sig = G.g1_sum([scheme.sign(c, s, msg) for s in sks])
+        kb = [G.g2_bytes(k).hex() for k in keys]
+        mc.append({"name": "valid_n%d" % n, "sig": G.g1_bytes(sig).hex(), "keys": kb, "msg": msg.hex(), "expect": True})
+        mc.append({"name": "wrong_msg_n%d" % n, "sig": G.g1_bytes(sig).hex(), "keys": kb, "msg": (msg + b"x").hex(), "expect": False})
+        other = G.g2_bytes(scheme.load_public_key(c, rnd.randrange(1, c.r))).hex()
+        mc.append({"name": "wrong_signer_n%d" % n, "sig": G.g1_bytes(sig).hex(), "keys": [other] + kb[1:], "msg": msg.hex(), "expect": False})
+        mc.append({"name": "preaggregated_key_n%d" % n, "sig": G.g1_bytes(sig).hex(), "keys": [G.g2_bytes(G.g2_sum(keys)).hex()], "msg": msg.hex(), "expect": True})
+    for c_ in mc:
+        got = scheme.verify_multi_signature(c, G.g1_from_bytes(bytes.fromhex(c_["sig"])), [G.g2_from_bytes(bytes.fromhex(k)) for k in c_["keys"]], bytes.fromhex(c_["msg"]))
+        assert got == c_["expect"], c_["name"]
+    v["multi_cases"] = mc
+    json.dump(v, open(os.path.join(HERE, "vectors_%s.json" % c.name), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    kat()
+    vectors(BN254, 20260928)
+    vectors(BLS381, 20260929)
+    print("golden fixtures written")

@@ -1,0 +1,115 @@
+"""CPU tier: the device arithmetic headers (bgls_amd/csrc/*.hpp), compiled for the host by the
+test harness, diffed routine by routine against the oracle.  Catches arithmetic bugs without a GPU;
+the GPU tier repeats the comparisons through the C ABI on the real kernels."""
+import ctypes
+import random
+
+from oracle.pyref import h2c
+from oracle.pyref.hashes import blake2b512, keccak256_legacy
+from oracle.pyref.pairing import Pairing
+from oracle.pyref.params import CURVES
+
+
+def B(b):
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
+
+
+def out(n):
+    return (ctypes.c_uint8 * n)()
+
+
+def test_fp_and_fp2(host_harness, curve):
+    lib, cid, n = host_harness, curve["id"], curve["fp"]
+    c = CURVES[curve["name"]]
+    p = c.p
+    T = Pairing(c).T
+    rnd = random.Random(7)
+    ops = ((0, lambda a, b: a * b % p), (1, lambda a, b: a * a % p), (2, lambda a, b: (a + b) % p), (3, lambda a, b: (a - b) % p),
+           (4, lambda a, b: (-a) % p), (5, lambda a, b: pow(a, p - 2, p)), (6, lambda a, b: pow(a, (p + 1) // 4, p)))
+    samples = [(0, 0), (1, p - 1), (p - 1, p - 1), (p - 1, 1), (2, (p + 1) // 2)] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(24)]
+    for op, fn in ops:
+        for a, b in samples:
+            o = out(n)
+            assert lib.ht_fp_op(cid, op, B(a.to_bytes(n, "big")), B(b.to_bytes(n, "big")), o) == 0
+            assert int.from_bytes(bytes(o), "big") == fn(a, b), (op, a, b)
+    f2b = lambda x: x[0].to_bytes(n, "big") + x[1].to_bytes(n, "big")
+    for op, fn in ((0, T.f2_mul), (1, lambda a, b: T.f2_sqr(a)), (2, lambda a, b: T.f2_mulxi(a)), (3, lambda a, b: T.f2_inv(a))):
+        for _ in range(16):
+            a, b = (rnd.randrange(p), rnd.randrange(p)), (rnd.randrange(p), rnd.randrange(p))
+            o = out(2 * n)
+            lib.ht_f2_op(cid, op, B(f2b(a)), B(f2b(b)), o)
+            assert bytes(o) == f2b(fn(a, b)), op
+    # worst-case operands for the lazy-reduction bounds
+    a = (p - 1, p - 1)
+    o = out(2 * n)
+    lib.ht_f2_op(cid, 0, B(f2b(a)), B(f2b(a)), o)
+    assert bytes(o) == f2b(T.f2_mul(a, a))
+
+
+def test_fp12_tower(host_harness, curve):
+    lib, cid, n = host_harness, curve["id"], curve["fp"]
+    c = CURVES[curve["name"]]
+    PR = Pairing(c)
+    T = PR.T
+    rnd = random.Random(9)
+    r12 = lambda: tuple(tuple((rnd.randrange(c.p), rnd.randrange(c.p)) for _ in range(3)) for _ in range(2))
+    for _ in range(3):
+        a, b = r12(), r12()
+        for op, fn in ((0, T.f12_mul), (1, lambda a, b: T.f12_sqr(a)), (2, lambda a, b: T.f12_inv(a)), (3, lambda a, b: T.f12_frob(a, 1)),
+                       (4, lambda a, b: T.f12_frob(a, 2)), (5, lambda a, b: T.f12_frob(a, 3)), (7, lambda a, b: T.f12_conj(a))):
+            o = out(12 * n)
+            assert lib.ht_f12_op(cid, op, B(PR.gt_bytes(a)), B(PR.gt_bytes(b)), o) == 0
+            assert bytes(o) == PR.gt_bytes(fn(a, b)), op
+    u = r12()
+    u = T.f12_mul(T.f12_conj(u), T.f12_inv(u))
+    u = T.f12_mul(T.f12_frob(u, 2), u)
+    o = out(12 * n)
+    lib.ht_f12_op(cid, 6, B(PR.gt_bytes(u)), None, o)
+    assert bytes(o) == PR.gt_bytes(T.f12_sqr(u))          # cyclotomic squaring on a unitary element
+
+
+def test_miller_final_exp_and_groups_against_golden(host_harness, curve):
+    lib, cid, n, v = host_harness, curve["id"], curve["fp"], curve["vec"]
+    for row in v["pairings"]:
+        m = out(12 * n)
+        assert lib.ht_miller(cid, B(bytes.fromhex(row["g1"])), B(bytes.fromhex(row["g2"])), m) == 0
+        assert bytes(m).hex() == row["miller"]
+        g = out(12 * n)
+        lib.ht_f12_op(cid, 8, m, None, g)
+        assert bytes(g).hex() == row["gt"]
+    for base, key, size in ((0, "scale_g1", 2 * n), (10, "scale_g2", 4 * n)):
+        for row in v[key]:
+            k = int(row["k"])
+            if 0 <= k < 1 << 256:
+                o = out(size)
+                lib.ht_group_op(cid, base + 1, B(bytes.fromhex(row["pt"])), None, B(k.to_bytes(32, "big")), o)
+                assert bytes(o).hex() == row["out"], k
+    for base, key, size in ((0, "sum_g1", 2 * n), (10, "sum_g2", 4 * n)):
+        pts = [bytes.fromhex(x) for x in v[key]["pts"]]
+        o = out(size)
+        lib.ht_group_op(cid, base, B(pts[0]), B(pts[5]), None, o)     # P + P  (doubling inside add)
+        o2 = out(size)
+        lib.ht_group_op(cid, base + 1, B(pts[0]), None, B((2).to_bytes(32, "big")), o2)
+        assert bytes(o) == bytes(o2)
+        o3 = out(size)
+        neg = pts[6]
+        lib.ht_group_op(cid, base, B(pts[1]), B(neg), None, o3)      # P + (-P) = infinity
+        assert bytes(o3) == bytes(size)
+
+
+def test_hashes_and_h2c(host_harness, curve, kat):
+    lib, cid, n = host_harness, curve["id"], curve["fp"]
+    rnd = random.Random(13)
+    for ln in (0, 1, 64, 123, 124, 127, 128, 134, 135, 136, 137, 251, 252, 300):
+        m = rnd.randbytes(ln)
+        o = out(32)
+        lib.ht_keccak256(B(m), ctypes.c_size_t(ln), 7, o)
+        assert bytes(o) == keccak256_legacy(b"\x07" + m)
+        o = out(64)
+        lib.ht_blake2b(B(m), ctypes.c_size_t(ln), 1, o)
+        assert bytes(o) == blake2b512(m + b"G1_1")
+    for row in kat[curve["name"]] + curve["vec"]["h2c"]:
+        m = bytes.fromhex(row["msg"])
+        o = out(2 * n)
+        assert lib.ht_hash_to_g1(cid, B(m), ctypes.c_size_t(len(m)), o) == 0
+        assert bytes(o).hex() == row["point"]
