@@ -1,0 +1,173 @@
+// Wave-cooperative Fp12 arithmetic: one Fp12 value is spread over a GROUP of 6 lanes, lane j
+// holding the Fp2 coefficient e_j of  f = sum_j e_j w^j  (w^6 = xi).  A wavefront carries 10
+// groups (60 lanes; lanes 60..63 shadow group 9 and never store).
+//
+// Why: in the product of pairings  prod_i e(P_i, Q_i)  the Miller accumulator can be SHARED:
+//      f <- f^2 * l_1 * l_2 * ... * l_6      (one squaring for six pairings)
+// gives exactly prod_i f_i because field arithmetic is exact and commutative -- this is the
+// reference's PairingProduct value (curves/curve.go:125-170) with 5/6 of the Fp12 squarings
+// removed.  Each lane runs the G2 point step of ITS pairing in registers (embarrassingly
+// parallel), publishes the three line coefficients to LDS, and then the six lanes cooperate on
+// the Fp12 updates: every lane produces ONE output coefficient as a short dot product
+//      c_j = sum_t A_t * B_{(j - s_t) mod 6} * (xi if s_t > j)
+// accumulated in double width (Karatsuba per term, 2 Montgomery reductions per coefficient).
+// Operands come from LDS: region RB holds each coefficient twice (plain and pre-multiplied by
+// xi) so that the wrap-around factor is an address choice, not a branch; region RL holds the
+// 6 x 3 line coefficients (or, for a general product, the plain coefficients of the other factor).
+//
+// LDS per group: 30 Fp2 = 1920 B (alt-bn128) / 2880 B (BLS12-381); per wave 19.2 / 28.8 KB.
+#pragma once
+#include "pairing.hpp"
+
+namespace bgls {
+
+template <class C>
+struct Coop {
+  static constexpr int L = C::L;
+  static constexpr int S2 = 2 * C::L;        // dwords per Fp2
+  static constexpr int RB = 0;               // [6][2] Fp2: coefficient k -> {e_k, xi*e_k}
+  static constexpr int RL = 12 * S2;         // [6][3] Fp2 line coefficients / [6] plain operand
+  static constexpr int GROUP_DW = 30 * S2;
+  static constexpr int GROUPS = 10;
+  static constexpr int WAVE_BYTES = GROUPS * GROUP_DW * 4;
+  static constexpr int LAZY_K = C::CURVE_ID == 0 ? 3 : 2;   // 12 p^2 < LAZY_K * p * 2^(32L)
+};
+
+__device__ __constant__ const int COOP_SH6[6] = {0, 1, 2, 3, 4, 5};
+__device__ __constant__ const int COOP_SH_D[3] = {0, 1, 3};   // D-type line: e0 + e1 w + e3 w^3
+__device__ __constant__ const int COOP_SH_M[3] = {0, 2, 3};   // M-type line: e0 + e2 w^2 + e3 w^3
+
+template <class C>
+__device__ __forceinline__ Fp2<C> lds_load_f2(int off) {
+  extern __shared__ u32 lds[];
+  Fp2<C> r;
+  const uint4* p = reinterpret_cast<const uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) {
+    uint4 v = p[k];
+    r.c0.v[4 * k] = v.x; r.c0.v[4 * k + 1] = v.y; r.c0.v[4 * k + 2] = v.z; r.c0.v[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) {
+    uint4 v = p[C::L / 4 + k];
+    r.c1.v[4 * k] = v.x; r.c1.v[4 * k + 1] = v.y; r.c1.v[4 * k + 2] = v.z; r.c1.v[4 * k + 3] = v.w;
+  }
+  return r;
+}
+
+template <class C>
+__device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a) {
+  extern __shared__ u32 lds[];
+  uint4* p = reinterpret_cast<uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) p[k] = make_uint4(a.c0.v[4 * k], a.c0.v[4 * k + 1], a.c0.v[4 * k + 2], a.c0.v[4 * k + 3]);
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k)
+    p[C::L / 4 + k] = make_uint4(a.c1.v[4 * k], a.c1.v[4 * k + 1], a.c1.v[4 * k + 2], a.c1.v[4 * k + 3]);
+}
+
+// c_j = sum_{t<NT} A[t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
+//   A[t] at dword offset a_off + t*a_stride, B from the group's RB region at rb_off.
+template <class C, int NT>
+__device__ __noinline__ Fp2<C> coop_dot(int a_off, int a_stride, int rb_off, int j, const int* sh) {
+  constexpr int L = C::L, W = 2 * C::L, S2 = 2 * C::L;
+  u32 v0[W], v1[W], s[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) v0[k] = v1[k] = s[k] = 0;
+#pragma unroll 1
+  for (int t = 0; t < NT; ++t) {
+    const int sht = sh[t];
+    int k = j - sht;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    Fp2<C> a = lds_load_f2<C>(a_off + t * a_stride);
+    Fp2<C> b = lds_load_f2<C>(rb_off + (2 * k + wrap) * S2);
+    u32 tmp[W];
+    mul_wide<C>(tmp, a.c0.v, b.c0.v);
+    w_add<W>(v0, v0, tmp);
+    mul_wide<C>(tmp, a.c1.v, b.c1.v);
+    w_add<W>(v1, v1, tmp);
+    Fp<C> sa = fp_add_nr<C>(a.c0, a.c1);
+    Fp<C> sb = fp_add_nr<C>(b.c0, b.c1);
+    mul_wide<C>(tmp, sa.v, sb.v);
+    w_add<W>(s, s, tmp);
+  }
+  w_sub<W>(s, s, v0);
+  w_sub<W>(s, s, v1);                                   // sum (a0 b1 + a1 b0)         < 2 NT p^2
+  if constexpr (NT == 6) w_add<W>(v0, v0, C::P2W6); else w_add<W>(v0, v0, C::P2W3);
+  w_sub<W>(v0, v0, v1);                                 // sum (a0 b0 - a1 b1) + NT p^2 in (0, 2 NT p^2)
+  Fp2<C> r;
+  r.c0 = redc_k<C, Coop<C>::LAZY_K>(v0);
+  r.c1 = redc_k<C, Coop<C>::LAZY_K>(s);
+  return r;
+}
+
+// publish this lane's coefficient (plain and xi-multiplied) into the group's RB region
+template <class C>
+__device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v, bool live) {
+  if (live) {
+    lds_store_f2<C>(rb_off + (2 * j) * Coop<C>::S2, v);
+    lds_store_f2<C>(rb_off + (2 * j + 1) * Coop<C>::S2, f2_mulxi<C>(v));
+  }
+  __syncthreads();
+}
+
+// f <- f * g for two distributed values: g's coefficient of this lane is `gj`, f lives in RB.
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool live) {
+  typedef Coop<C> K;
+  if (live) lds_store_f2<C>(gb + K::RL + j * K::S2, gj);
+  __syncthreads();
+  Fp2<C> r = coop_dot<C, 6>(gb + K::RL, K::S2, gb + K::RB, j, COOP_SH6);
+  __syncthreads();
+  return r;
+}
+
+// f <- f^2, f in RB
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_sqr(int gb, int j) {
+  typedef Coop<C> K;
+  return coop_dot<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
+}
+
+// f <- f * line_m, line coefficients at RL[m][0..2]
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m) {
+  typedef Coop<C> K;
+  return coop_dot<C, 3>(gb + K::RL + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+}
+
+// write this lane's (scaled) line into RL[j]; an inactive pairing contributes the constant 1
+template <class C>
+__device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<C>& l, const Fp<C>& xP, const Fp<C>& yP, bool valid,
+                                                bool live) {
+  typedef Coop<C> K;
+  Fp2<C> e0, e1, e2;
+  if constexpr (C::TWIST_D) {
+    e0 = f2_muls<C>(l.c0, yP); e1 = f2_muls<C>(l.c1, xP); e2 = l.c2;
+  } else {
+    e0 = l.c2; e1 = f2_muls<C>(l.c1, xP); e2 = f2_muls<C>(l.c0, yP);
+  }
+  if (!valid) { e0 = f2_one<C>(); e1 = f2_zero<C>(); e2 = f2_zero<C>(); }
+  if (live) {
+    const int o = gb + K::RL + j * 3 * K::S2;
+    lds_store_f2<C>(o, e0);
+    lds_store_f2<C>(o + K::S2, e1);
+    lds_store_f2<C>(o + 2 * K::S2, e2);
+  }
+  __syncthreads();
+}
+
+// fold the six published lines into f (f in RB on entry and on exit; returns this lane's coefficient)
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_apply_lines(int gb, int j, bool live) {
+  Fp2<C> fj;
+#pragma unroll 1
+  for (int m = 0; m < 6; ++m) {
+    fj = coop_mul_line<C>(gb, j, m);
+    coop_publish<C>(gb + Coop<C>::RB, j, fj, live);
+  }
+  return fj;
+}
+
+}  // namespace bgls

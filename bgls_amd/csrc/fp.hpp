@@ -245,9 +245,10 @@ BGLS_HD void sqr_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L]) {
   }
 }
 
-// Montgomery reduction: t < p * 2^(32L)  ->  t / 2^(32L) mod p, fully reduced.  Clobbers t.
+// Montgomery reduction without the final conditional subtraction: returns (t + m p) / 2^(32L),
+// which is < t / 2^(32L) + p.  Clobbers t.
 template <class C>
-BGLS_HD Fp<C> redc(u32 (&t)[2 * C::L]) {
+BGLS_HD Fp<C> redc_raw(u32 (&t)[2 * C::L]) {
   constexpr int L = C::L;
   u32 top = 0;
 #pragma unroll
@@ -268,7 +269,22 @@ BGLS_HD Fp<C> redc(u32 (&t)[2 * C::L]) {
   Fp<C> r;
 #pragma unroll
   for (int j = 0; j < L; ++j) r.v[j] = t[L + j];
-  return fp_reduce_once<C>(r);
+  return r;
+}
+
+// Montgomery reduction: t < p * 2^(32L)  ->  t / 2^(32L) mod p, fully reduced.  Clobbers t.
+template <class C>
+BGLS_HD Fp<C> redc(u32 (&t)[2 * C::L]) {
+  return fp_reduce_once<C>(redc_raw<C>(t));
+}
+
+// Same for lazily accumulated inputs t < K p * 2^(32L) (result < (K+1) p before the K subtractions).
+template <class C, int K>
+BGLS_HD Fp<C> redc_k(u32 (&t)[2 * C::L]) {
+  Fp<C> r = redc_raw<C>(t);
+#pragma unroll
+  for (int k = 0; k < K; ++k) r = fp_reduce_once<C>(r);
+  return r;
 }
 
 template <class C>

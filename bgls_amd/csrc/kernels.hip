@@ -12,12 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include <string>
 
 #include "pairing.hpp"
 #include "h2c.hpp"
+#include "coop.hpp"
 #include "../../include/bgls_hip.h"
 
 using namespace bgls;
@@ -289,6 +291,241 @@ __global__ void __launch_bounds__(256) k_mad_probe(uint32_t seed, int iters, uin
   if (x == 0x1234567ull) sink[0] = x;
 }
 
+// ======================================================================= cooperative (v2) kernels
+// One wave per block, 10 groups of 6 lanes; see coop.hpp.  Partial products are kept in the
+// "w-basis" layout: 6 consecutive Fp2 per Fp12, coefficient j of w^j.
+template <class C>
+struct CoopLane {
+  int lane, g, j, gb;
+  bool live;
+  __device__ __forceinline__ CoopLane() {
+    lane = threadIdx.x;
+    live = lane < 60;
+    g = live ? lane / 6 : 9;
+    j = live ? lane % 6 : lane - 60;
+    gb = g * Coop<C>::GROUP_DW;
+  }
+};
+
+template <class C>
+__global__ void __launch_bounds__(64) k_miller_coop(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long gen_at, int rounds,
+                                                    size_t groups_total, Fp2<C>* out, uint32_t* flags) {
+  typedef Coop<C> K;
+  CoopLane<C> ln;
+  const int j = ln.j, gb = ln.gb;
+  const bool live = ln.live;
+  const size_t G = (size_t)blockIdx.x * K::GROUPS + ln.g;
+  Fp2<C> ft = j == 0 ? f2_one<C>() : f2_zero<C>();      // running product over rounds
+  for (int r = 0; r < rounds; ++r) {
+    const size_t idx = ((size_t)r * groups_total + G) * 6 + j;
+    Aff<F2<C>> Q;
+    Aff<F1<C>> P;
+    bool valid = idx < n && G < groups_total;
+    if (valid) {
+      if ((long long)idx == gen_at) {
+        Q.x = f2_load<C>(C::G2);
+        Q.y = f2_load<C>(C::G2 + 2 * C::L);
+        Q.inf = false;
+      } else {
+        size_t k = (gen_at >= 0 && (long long)idx > gen_at) ? idx - 1 : idx;
+        bool ok = g2_from_bytes<C>(Q, g2s + k * 4 * C::FP_BYTES);
+        ok = ok && aff_on_curve<F2<C>>(Q);
+        if (!ok) atomicOr(flags, FLAG_ENC);
+      }
+      P = g1s[idx];
+      valid = !P.inf && !Q.inf;
+    }
+    if (!valid) {  // keep the arithmetic well defined; the lines are replaced by 1
+      Q.x = f2_load<C>(C::G2);
+      Q.y = f2_load<C>(C::G2 + 2 * C::L);
+      P.x = fp_load<C>(C::G1X);
+      P.y = fp_load<C>(C::G1Y);
+    }
+    G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+    const Fp2<C> nyq = f2_neg<C>(Q.y);
+    Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
+    coop_publish<C>(gb + K::RB, j, fj, live);
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      LineCoeffs<C> l = dbl_step<C>(T);
+      coop_write_line<C>(gb, j, l, P.x, P.y, valid, live);
+      fj = coop_sqr<C>(gb, j);
+      coop_publish<C>(gb + K::RB, j, fj, live);
+      fj = coop_apply_lines<C>(gb, j, live);
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        l = add_step<C>(T, Q.x, d > 0 ? Q.y : nyq);
+        coop_write_line<C>(gb, j, l, P.x, P.y, valid, live);
+        fj = coop_apply_lines<C>(gb, j, live);
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+      LineCoeffs<C> l = add_step<C>(T, x1, y1);
+      coop_write_line<C>(gb, j, l, P.x, P.y, valid, live);
+      fj = coop_apply_lines<C>(gb, j, live);
+      l = add_step<C>(T, x2, y2);
+      coop_write_line<C>(gb, j, l, P.x, P.y, valid, live);
+      fj = coop_apply_lines<C>(gb, j, live);
+    } else {
+      if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
+      coop_publish<C>(gb + K::RB, j, fj, live);
+    }
+    ft = coop_mul<C>(gb, j, ft, live);                    // ft <- ft * f
+  }
+  if (live && G < groups_total) out[G * 6 + j] = ft;
+}
+
+// out[G] = prod in[G*R .. min(count, (G+1)*R))   (w-basis Fp12 arrays)
+template <class C>
+__global__ void __launch_bounds__(64) k_reduce_coop(const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
+  typedef Coop<C> K;
+  CoopLane<C> ln;
+  const int j = ln.j, gb = ln.gb;
+  const bool live = ln.live;
+  const size_t G = (size_t)blockIdx.x * K::GROUPS + ln.g;
+  const size_t lo = G * (size_t)R;
+  const bool has = lo < count;
+  const size_t hi = lo + R < count ? lo + R : count;
+  Fp2<C> acc = has ? in[lo * 6 + j] : (j == 0 ? f2_one<C>() : f2_zero<C>());
+#pragma unroll 1
+  for (int t = 1; t < R; ++t) {                           // uniform trip count; missing operands are 1
+    coop_publish<C>(gb + K::RB, j, acc, live);
+    const size_t k = lo + t;
+    Fp2<C> x = (has && k < hi) ? in[k * 6 + j] : (j == 0 ? f2_one<C>() : f2_zero<C>());
+    acc = coop_mul<C>(gb, j, x, live);
+  }
+  if (live && has) out[G * 6 + j] = acc;
+}
+
+template <class C>
+__global__ void k_w_to_bytes(const Fp2<C>* in, uint8_t* out) {
+  const int t = threadIdx.x;
+  if (blockIdx.x != 0 || t >= 6) return;
+  const int order[6] = {5, 3, 1, 4, 2, 0};                 // h.a2 h.a1 h.a0 g.a2 g.a1 g.a0
+  Fp2<C> e = in[order[t]];
+  fp_to_be<C>(out + (2 * t) * C::FP_BYTES, fp_from_mont<C>(e.c1));
+  fp_to_be<C>(out + (2 * t + 1) * C::FP_BYTES, fp_from_mont<C>(e.c0));
+}
+
+// ---- cooperative final exponentiation: one group of six lanes ----
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_frob(const Fp2<C>& e, int j, int k) {     // coefficient of f^(p^k)
+  Fp2<C> x = (k & 1) ? f2_conj<C>(e) : e;
+  return f2_mul<C>(x, gamma_const<C>(k, j));
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_conj(const Fp2<C>& e, int j) { return (j & 1) ? f2_neg<C>(e) : e; }
+
+// a * b for distributed values held in registers
+template <class C>
+__device__ __forceinline__ Fp2<C> cmul(const CoopLane<C>& ln, const Fp2<C>& a, const Fp2<C>& b) {
+  coop_publish<C>(ln.gb + Coop<C>::RB, ln.j, a, ln.live);
+  return coop_mul<C>(ln.gb, ln.j, b, ln.live);
+}
+template <class C>
+__device__ __forceinline__ Fp2<C> csqr(const CoopLane<C>& ln, const Fp2<C>& a) {
+  coop_publish<C>(ln.gb + Coop<C>::RB, ln.j, a, ln.live);
+  Fp2<C> r = coop_sqr<C>(ln.gb, ln.j);
+  __syncthreads();
+  return r;
+}
+// a^e, public exponent, top bit set
+template <class C>
+__device__ __noinline__ Fp2<C> cpow(const CoopLane<C>& ln, const Fp2<C>& a, const u32* e, int nbits) {
+  Fp2<C> r = a;
+  for (int i = nbits - 2; i >= 0; --i) {
+    r = csqr<C>(ln, r);
+    if ((e[i >> 5] >> (i & 31)) & 1u) r = cmul<C>(ln, r, a);
+  }
+  return r;
+}
+// inverse through lane 0 of the group (thread-local tower inversion)
+template <class C>
+__device__ __noinline__ Fp2<C> cinv(const CoopLane<C>& ln, const Fp2<C>& a) {
+  typedef Coop<C> K;
+  coop_publish<C>(ln.gb + K::RB, ln.j, a, ln.live);
+  if (ln.live && ln.j == 0) {
+    Fp2<C> e[6];
+    for (int k = 0; k < 6; ++k) e[k] = lds_load_f2<C>(ln.gb + K::RB + 2 * k * K::S2);
+    Fp12<C> f = {{e[0], e[2], e[4]}, {e[1], e[3], e[5]}};
+    Fp12<C> fi = f12_inv<C>(f);
+    const Fp2<C> o[6] = {fi.g.a0, fi.h.a0, fi.g.a1, fi.h.a1, fi.g.a2, fi.h.a2};
+    for (int k = 0; k < 6; ++k) lds_store_f2<C>(ln.gb + K::RL + k * K::S2, o[k]);
+  }
+  __syncthreads();
+  Fp2<C> r = lds_load_f2<C>(ln.gb + K::RL + ln.j * K::S2);
+  __syncthreads();
+  return r;
+}
+
+template <class C>
+__device__ __noinline__ Fp2<C> coop_final_exp(const CoopLane<C>& ln, Fp2<C> f) {
+  const int j = ln.j;
+  // easy part
+  Fp2<C> t = cmul<C>(ln, coop_conj<C>(f, j), cinv<C>(ln, f));
+  f = cmul<C>(ln, coop_frob<C>(t, j, 2), t);
+  if constexpr (C::CURVE_ID == 0) {
+    Fp2<C> ft1 = cpow<C>(ln, f, C::U_ABS, C::U_BITS);
+    Fp2<C> ft2 = cpow<C>(ln, ft1, C::U_ABS, C::U_BITS);
+    Fp2<C> ft3 = cpow<C>(ln, ft2, C::U_ABS, C::U_BITS);
+    Fp2<C> y0 = cmul<C>(ln, cmul<C>(ln, coop_frob<C>(f, j, 1), coop_frob<C>(f, j, 2)), coop_frob<C>(f, j, 3));
+    Fp2<C> y1 = coop_conj<C>(f, j);
+    Fp2<C> y2 = coop_frob<C>(ft2, j, 2);
+    Fp2<C> y3 = coop_conj<C>(coop_frob<C>(ft1, j, 1), j);
+    Fp2<C> y4 = coop_conj<C>(cmul<C>(ln, ft1, coop_frob<C>(ft2, j, 1)), j);
+    Fp2<C> y5 = coop_conj<C>(ft2, j);
+    Fp2<C> y6 = coop_conj<C>(cmul<C>(ln, ft3, coop_frob<C>(ft3, j, 1)), j);
+    Fp2<C> t0 = cmul<C>(ln, cmul<C>(ln, csqr<C>(ln, y6), y4), y5);
+    Fp2<C> t1 = cmul<C>(ln, cmul<C>(ln, y3, y5), t0);
+    t0 = cmul<C>(ln, t0, y2);
+    t1 = csqr<C>(ln, cmul<C>(ln, csqr<C>(ln, t1), t0));
+    t0 = cmul<C>(ln, t1, y1);
+    t1 = cmul<C>(ln, t1, y0);
+    t0 = csqr<C>(ln, t0);
+    return cmul<C>(ln, t1, t0);
+  } else {
+    Fp2<C> a = cpow<C>(ln, f, C::COFACTOR, C::COFACTOR_BITS);
+    Fp2<C> ax = coop_conj<C>(cpow<C>(ln, a, C::U_ABS, C::U_BITS), j);
+    Fp2<C> b = cmul<C>(ln, ax, coop_frob<C>(a, j, 1));
+    Fp2<C> bx = coop_conj<C>(cpow<C>(ln, b, C::U_ABS, C::U_BITS), j);
+    Fp2<C> bxx = coop_conj<C>(cpow<C>(ln, bx, C::U_ABS, C::U_BITS), j);
+    Fp2<C> d = cmul<C>(ln, cmul<C>(ln, bxx, coop_frob<C>(b, j, 2)), coop_conj<C>(b, j));
+    return cmul<C>(ln, d, f);
+  }
+}
+
+// product of `count` serialised partials -> final exponentiation -> GT bytes + verdict (one wave, group 0 meaningful)
+template <class C>
+__global__ void __launch_bounds__(64) k_final_coop(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out,
+                                                   uint32_t* verdict, uint32_t* flags) {
+  CoopLane<C> ln;
+  const int j = ln.j;
+  const int order_pos[6] = {5, 2, 4, 1, 3, 0};             // byte slot of w-coefficient j (inverse of k_w_to_bytes order)
+  Fp2<C> acc = j == 0 ? f2_one<C>() : f2_zero<C>();
+  for (size_t k = 0; k < count; ++k) {
+    const uint8_t* b = partials + k * 12 * C::FP_BYTES + (size_t)(2 * order_pos[j]) * C::FP_BYTES;
+    Fp<C> im = fp_from_be<C>(b), re = fp_from_be<C>(b + C::FP_BYTES);
+    if (fp_geq_p<C>(im) || fp_geq_p<C>(re)) atomicOr(flags, FLAG_ENC);
+    Fp2<C> x = {fp_to_mont<C>(re), fp_to_mont<C>(im)};
+    acc = (k == 0) ? x : cmul<C>(ln, acc, x);
+  }
+  if (do_final_exp) acc = coop_final_exp<C>(ln, acc);
+  const bool is_one = j == 0 ? f2_eq<C>(acc, f2_one<C>()) : f2_is_zero<C>(acc);
+  const unsigned long long ball = __ballot(is_one);
+  if (ln.lane < 6) {
+    if (gt_out) {
+      uint8_t* o = gt_out + (size_t)(2 * order_pos[j]) * C::FP_BYTES;
+      fp_to_be<C>(o, fp_from_mont<C>(acc.c1));
+      fp_to_be<C>(o + C::FP_BYTES, fp_from_mont<C>(acc.c0));
+    }
+    if (ln.lane == 0) verdict[0] = ((ball & 0x3Full) == 0x3Full) ? 1u : 0u;
+  }
+}
+
 // ======================================================================= host side
 namespace {
 
@@ -370,6 +607,16 @@ Ctx& ctx() {
   return c;
 }
 
+// BGLS_KERNELS=v1 selects the round-1 thread-per-pairing kernels (kept for A/B measurements);
+// default is the wave-cooperative path (coop.hpp).
+bool use_coop() {
+  static const bool v = [] {
+    const char* e = getenv("BGLS_KERNELS");
+    return !(e && !strcmp(e, "v1"));
+  }();
+  return v;
+}
+
 enum { ST_DUP = 0, ST_H2C, ST_MILLER, ST_REDUCE, ST_FINAL, ST_SUM, ST_NUM };
 const char* const STAGE_NAMES[ST_NUM] = {"dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points"};
 
@@ -424,6 +671,8 @@ struct Engine {
       HIPCHK(hipMemcpyAsync(d_partial + GTB - 1, &one, 1, hipMemcpyHostToDevice, st));
       return 0;
     }
+    if (use_coop())
+      return miller_coop(c, st, (const Aff<G1F>*)g1s, d_keys, total, d_sig ? (long long)n : -1LL, d_partial, d_flags);
     {
       Scope sc(c, st, ST_MILLER);
       k_miller<C><<<nblk(total, 64), 64, 0, st>>>((const Aff<G1F>*)g1s, d_keys, total, d_sig ? (long long)n : -1LL,
@@ -431,6 +680,39 @@ struct Engine {
     }
     Scope sc(c, st, ST_REDUCE);
     return reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, total, d_partial);
+  }
+
+  // wave-cooperative Miller product: groups of 6 lanes share one accumulator (coop.hpp)
+  static int miller_coop(Ctx& c, hipStream_t st, const Aff<G1F>* g1s, const uint8_t* g2s, size_t total, long long gen_at,
+                         uint8_t* d_partial, uint32_t* d_flags) {
+    typedef Coop<C> K;
+    const size_t max_groups = 256 * 8 * K::GROUPS;                 // 8 resident waves per CU
+    size_t groups = (total + 5) / 6;
+    if (groups > max_groups) groups = max_groups;
+    const int rounds = (int)((total + groups * 6 - 1) / (groups * 6));
+    void *pa, *pb;
+    int rc;
+    if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / 16 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    {
+      Scope sc(c, st, ST_MILLER);
+      k_miller_coop<C><<<nblk(groups, K::GROUPS), 64, K::WAVE_BYTES, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
+    }
+    Scope sc(c, st, ST_REDUCE);
+    Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;
+    size_t cnt = groups;
+    const int R = 16;
+    while (cnt > 1) {
+      size_t nout = (cnt + R - 1) / R;
+      k_reduce_coop<C><<<nblk(nout, K::GROUPS), 64, K::WAVE_BYTES, st>>>(a, cnt, R, b);
+      Fp2<C>* t = a;
+      a = b;
+      b = t;
+      cnt = nout;
+    }
+    k_w_to_bytes<C><<<1, 64, 0, st>>>(a, d_partial);
+    HIPCHK(hipGetLastError());
+    return 0;
   }
 
   static int reduce_to_bytes(hipStream_t st, Fp12<C>* a, Fp12<C>* b, size_t cnt, uint8_t* d_out) {
@@ -461,7 +743,10 @@ struct Engine {
     HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
     {
       Scope sc(c, st, ST_FINAL);
-      k_final<C><<<1, 64, 0, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      if (use_coop())
+        k_final_coop<C><<<1, 64, Coop<C>::WAVE_BYTES, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      else
+        k_final<C><<<1, 64, 0, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
     }
     HIPCHK(hipGetLastError());
     uint32_t h[3] = {0, 0, 0};

@@ -55,6 +55,8 @@ def emit(cname, cid, L, p, r, b, xi, twist, loop, extra):
     o += "  static constexpr int XI_RE = %d;\n" % xi[0]
     o += arr("P", limbs(p, L))
     o += arr("P2W", limbs(p * p, 2 * L))          # p^2, for lazy-reduction offsets
+    o += arr("P2W3", limbs(3 * p * p, 2 * L))
+    o += arr("P2W6", limbs(6 * p * p, 2 * L))
     o += arr("ONE", limbs(M(1), L))
     o += arr("R2", limbs(R * R % p, L))
     o += arr("HALF", limbs(M(pow(2, p - 2, p)), L))
