@@ -208,6 +208,27 @@ BGLS_HD void mul_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L], const u32 (&b)[C
   }
 }
 
+// N independent products with their rows interleaved in program order: a single wave then has
+// N independent mad/carry chains in flight (matters when only one or two waves share a SIMD).
+template <class C, int N>
+BGLS_HD void mul_wide_n(u32 (&t)[N][2 * C::L], const u32 (&a)[N][C::L], const u32 (&b)[N][C::L]) {
+  constexpr int L = C::L;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      u64 P[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) P[j] = (u64)a[q][j] * b[q][i] + (i ? t[q][i + j] : 0u);
+      t[q][i] = (u32)P[0];
+      u32 c = 0;
+#pragma unroll
+      for (int j = 1; j < L; ++j) t[q][i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c);
+      t[q][i + L] = (u32)(P[L - 1] >> 32) + c;
+    }
+  }
+}
+
 // t = a^2: off-diagonal products once, doubled, plus the diagonal.
 template <class C>
 BGLS_HD void sqr_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L]) {
@@ -335,15 +356,53 @@ BGLS_FN Fp<C> fp_pow(const Fp<C>& a, const u32* e) {
   return r;
 }
 
+// In-place variants for hot loops (no call, operands stay in VGPRs)
+template <class C>
+BGLS_HD Fp<C> fp_mul_inl(const Fp<C>& a, const Fp<C>& b) {
+  u32 t[2 * C::L];
+  mul_wide<C>(t, a.v, b.v);
+  return redc<C>(t);
+}
+template <class C>
+BGLS_HD Fp<C> fp_sqr_inl(const Fp<C>& a) {
+  u32 t[2 * C::L];
+  sqr_wide<C>(t, a.v);
+  return redc<C>(t);
+}
+
+// a^e, fixed 4-bit windows, public wave-uniform exponent (NL limbs); the loop body is expanded
+// in place once (4 squarings + 1 multiplication), the 16-entry table lives in private memory.
+template <class C, int NL>
+BGLS_FN Fp<C> fp_pow_w4(const Fp<C>& a, const u32* e) {
+  Fp<C> tab[16];
+  tab[0] = fp_one<C>();
+  tab[1] = a;
+#pragma unroll 1
+  for (int k = 2; k < 16; ++k) tab[k] = fp_mul_inl<C>(tab[k - 1], a);
+  int d = NL * 8 - 1;
+  while (d > 0 && ((e[d >> 3] >> ((d & 7) * 4)) & 15u) == 0) --d;
+  Fp<C> r = tab[(e[d >> 3] >> ((d & 7) * 4)) & 15u];
+#pragma unroll 1
+  for (--d; d >= 0; --d) {
+    r = fp_sqr_inl<C>(r);
+    r = fp_sqr_inl<C>(r);
+    r = fp_sqr_inl<C>(r);
+    r = fp_sqr_inl<C>(r);
+    const u32 w = (e[d >> 3] >> ((d & 7) * 4)) & 15u;
+    if (w) r = fp_mul_inl<C>(r, tab[w]);
+  }
+  return r;
+}
+
 template <class C>
 BGLS_HD Fp<C> fp_inv(const Fp<C>& a) {  // a^(p-2); 0 -> 0
-  return fp_pow<C, C::L>(a, C::EXP_INV);
+  return fp_pow_w4<C, C::L>(a, C::EXP_INV);
 }
 
 // candidate square root a^((p+1)/4) (calcQuadRes, curves/hash.go:178-190); caller checks r^2 == a
 template <class C>
 BGLS_HD Fp<C> fp_sqrt_candidate(const Fp<C>& a) {
-  return fp_pow<C, C::L>(a, C::EXP_SQRT);
+  return fp_pow_w4<C, C::L>(a, C::EXP_SQRT);
 }
 
 // big-endian bytes (FP_BYTES) -> limbs (plain integer)

@@ -92,6 +92,50 @@ __global__ void __launch_bounds__(64) k_h2c(MsgView mv, size_t n, Aff<F1<C>>* ou
   }
 }
 
+// alt-bn128 try-and-increment as compacting rounds (curves/hash.go:53-77 has data-dependent trip
+// counts: geometric(1/2) per message, so a per-lane loop idles most of the wave).  Round r tests
+// LPM consecutive counters of every still-unfinished message on LPM adjacent lanes; the LOWEST
+// successful counter wins (= what the sequential loop would have found), failures are appended to
+// the next round's work list.  Counters 0..255 are covered by the fixed schedule in h2c_bn().
+template <int LPM>
+__global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const uint32_t* list_in, const uint32_t* count_in,
+                                                     uint32_t c0, uint32_t* list_out, uint32_t* count_out, int last,
+                                                     Aff<F1<BN254>>* out, uint32_t* flags) {
+  typedef BN254 C;
+  const size_t count = count_in ? (size_t)*count_in : n;
+  const size_t slots = (count * LPM + 63) / 64 * 64;
+  const int lane = threadIdx.x;
+  for (size_t slot = (size_t)blockIdx.x * 64 + lane; slot < slots; slot += (size_t)gridDim.x * 64) {
+    const size_t item = slot / LPM;
+    const uint32_t sub = (uint32_t)(slot % LPM);
+    const uint32_t c = c0 + sub;
+    const bool active = item < count && c < 256;
+    size_t idx = 0;
+    Fp<C> x, r;
+    bool ok = false;
+    if (item < count) idx = list_in ? list_in[item] : item;
+    if (active) ok = bn_h2c_try(mv.ptr(idx), mv.size(idx), c, x, r);
+    const unsigned long long ball = __ballot(ok);
+    const int seg = (lane / LPM) * LPM;
+    const unsigned long long segmask = LPM == 64 ? ball : ((ball >> seg) & ((1ull << (LPM & 63)) - 1ull));
+    if (item < count) {
+      if (segmask == 0) {
+        if (sub == 0) {
+          if (last) {
+            atomicOr(flags, FLAG_HASH);
+            out[idx] = {fp_zero<C>(), fp_zero<C>(), true};
+          } else {
+            list_out[atomicAdd(count_out, 1u)] = (uint32_t)idx;
+          }
+        }
+      } else if (sub == (uint32_t)__builtin_ctzll(segmask)) {
+        if (bn_h2c_sign(mv.ptr(idx), mv.size(idx))) r = fp_neg<C>(r);
+        out[idx] = {x, r, false};
+      }
+    }
+  }
+}
+
 template <class C>
 __global__ void k_g1_to_bytes(const Aff<F1<C>>* in, size_t n, uint8_t* out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -584,7 +628,7 @@ struct Ctx {
     if (device >= cnt) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreate(&stream));
-    ws.assign(16, {nullptr, 0});
+    ws.assign(24, {nullptr, 0});
     ready = true;
     return 0;
   }
@@ -631,7 +675,7 @@ struct Scope {  // brackets the launches of one stage with events when profiling
 };
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_NUM };
 
 inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -662,7 +706,8 @@ struct Engine {
     }
     if (n) {
       Scope sc(c, st, ST_H2C);
-      k_h2c<C><<<nblk(n, 64), 64, 0, st>>>(mv, n, (Aff<G1F>*)g1s, d_flags);
+      int rc2 = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags);
+      if (rc2) return rc2;
     }
     if (d_sig) k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
     if (total == 0) {
@@ -680,6 +725,42 @@ struct Engine {
     }
     Scope sc(c, st, ST_REDUCE);
     return reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, total, d_partial);
+  }
+
+  static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags) {
+    if constexpr (C::CURVE_ID == 0) {
+      if (use_coop() && n >= 256) {
+        void *lists, *cnts;
+        int rc;
+        if ((rc = c.get(WS_H2C_LIST, 2 * n * 4, &lists))) return rc;
+        if ((rc = c.get(WS_H2C_CNT, 64, &cnts))) return rc;
+        HIPCHK(hipMemsetAsync(cnts, 0, 64, st));
+        uint32_t* L0 = (uint32_t*)lists;
+        uint32_t* L1 = L0 + n;
+        uint32_t* cn = (uint32_t*)cnts;
+        auto grid = [&](double expect_items, int lpm) {
+          double lanes = expect_items * lpm * 2.0 + 512.0;
+          size_t b = (size_t)(lanes / 64.0) + 1;
+          return (unsigned)(b > 8192 ? 8192 : b);
+        };
+        const double N = (double)n;
+        // (lanes per message, first counter): 1@0, 1@1, 2@2, 4@4, 16@8, 64@24, 64@88, 64@152, 64@216
+        k_h2c_bn_round<1><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, d_flags);
+        k_h2c_bn_round<1><<<grid(N / 2, 1), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, d_flags);
+        k_h2c_bn_round<2><<<grid(N / 4, 2), 64, 0, st>>>(mv, n, L1, cn + 2, 2, L0, cn + 3, 0, out, d_flags);
+        k_h2c_bn_round<4><<<grid(N / 16, 4), 64, 0, st>>>(mv, n, L0, cn + 3, 4, L1, cn + 4, 0, out, d_flags);
+        k_h2c_bn_round<16><<<grid(N / 256, 16), 64, 0, st>>>(mv, n, L1, cn + 4, 8, L0, cn + 5, 0, out, d_flags);
+        k_h2c_bn_round<64><<<grid(N / 16777216, 64), 64, 0, st>>>(mv, n, L0, cn + 5, 24, L1, cn + 6, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 88, L0, cn + 7, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 7, 152, L1, cn + 8, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 8, 216, L0, cn + 9, 1, out, d_flags);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
+    }
+    k_h2c<C><<<nblk(n, 64), 64, 0, st>>>(mv, n, out, d_flags);
+    HIPCHK(hipGetLastError());
+    return 0;
   }
 
   // wave-cooperative Miller product: groups of 6 lanes share one accumulator (coop.hpp)
@@ -848,7 +929,7 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   int rc;
   void *d_flags, *d_g2s, *d_g1s, *fa, *fb, *d_part;
   if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
-  if ((rc = c.get(WS_TMP + 1, 2 * E::G2B, &d_g2s))) return rc;
+  if ((rc = c.get(WS_TMP2, 2 * E::G2B, &d_g2s))) return rc;
   if ((rc = c.get(WS_G1S, 4 * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
   if ((rc = c.get(WS_F_A, 4 * sizeof(Fp12<C>), &fa))) return rc;
   if ((rc = c.get(WS_F_B, 4 * sizeof(Fp12<C>), &fb))) return rc;
@@ -939,7 +1020,7 @@ int hash_to_g1_t(const uint8_t* blob, const uint64_t* off, size_t n, uint8_t* ou
   if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
   MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
-  k_h2c<C><<<nblk(n, 64), 64, 0, st>>>(mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags);
+  if ((rc = E::hash_to_g1(c, st, mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags))) return rc;
   k_g1_to_bytes<C><<<nblk(n, 64), 64, 0, st>>>((const Aff<F1<C>>*)d_g1s, n, (uint8_t*)d_out);
   HIPCHK(hipGetLastError());
   uint32_t f = 0;

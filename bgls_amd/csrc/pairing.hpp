@@ -30,41 +30,81 @@ struct LineCoeffs {
   Fp2<C> c0, c1, c2;
 };
 
-template <class C>
-BGLS_FN LineCoeffs<C> dbl_step(G2Proj<C>& R) {
+// INL = true expands the Fp2 products in place (straight-line code, operands stay in VGPRs);
+// INL = false calls the shared out-of-line f2_mul / f2_sqr (small code, operands via the stack).
+template <class C, bool INL>
+BGLS_HD Fp2<C> f2m(const Fp2<C>& a, const Fp2<C>& b) {
+  if constexpr (INL) return f2_mul_inl<C>(a, b); else return f2_mul<C>(a, b);
+}
+template <class C, bool INL>
+BGLS_HD Fp2<C> f2s(const Fp2<C>& a) {
+  if constexpr (INL) return f2_sqr_inl<C>(a); else return f2_sqr<C>(a);
+}
+template <class C, bool INL>
+BGLS_HD Fp2<C> f2ms(const Fp2<C>& a, const Fp<C>& s) {      // by an Fp scalar
+  if constexpr (INL) {
+    u32 t0[2 * C::L], t1[2 * C::L];
+    mul_wide<C>(t0, a.c0.v, s.v);
+    mul_wide<C>(t1, a.c1.v, s.v);
+    return {redc<C>(t0), redc<C>(t1)};
+  } else {
+    return f2_muls<C>(a, s);
+  }
+}
+
+template <class C, bool INL>
+BGLS_HD LineCoeffs<C> dbl_step_t(G2Proj<C>& R) {
   Fp<C> half = fp_load<C>(C::HALF);
-  Fp2<C> A = f2_muls<C>(f2_mul<C>(R.X, R.Y), half);
-  Fp2<C> B = f2_sqr<C>(R.Y);
-  Fp2<C> Cc = f2_sqr<C>(R.Z);
+  Fp2<C> A = f2ms<C, INL>(f2m<C, INL>(R.X, R.Y), half);
+  Fp2<C> B = f2s<C, INL>(R.Y);
+  Fp2<C> Cc = f2s<C, INL>(R.Z);
   Fp2<C> b3 = {fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)};
-  Fp2<C> E = f2_mul<C>(b3, Cc);
+  Fp2<C> E = f2m<C, INL>(b3, Cc);
   Fp2<C> Fv = f2_mul3<C>(E);
-  Fp2<C> G = f2_muls<C>(f2_add<C>(B, Fv), half);
-  Fp2<C> H = f2_sub<C>(f2_sqr<C>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
+  Fp2<C> G = f2ms<C, INL>(f2_add<C>(B, Fv), half);
+  Fp2<C> H = f2_sub<C>(f2s<C, INL>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
   Fp2<C> I = f2_sub<C>(E, B);
-  Fp2<C> J = f2_sqr<C>(R.X);
-  Fp2<C> Esq = f2_sqr<C>(E);
-  R.X = f2_mul<C>(A, f2_sub<C>(B, Fv));
-  R.Y = f2_sub<C>(f2_sqr<C>(G), f2_mul3<C>(Esq));
-  R.Z = f2_mul<C>(B, H);
+  Fp2<C> J = f2s<C, INL>(R.X);
+  Fp2<C> Esq = f2s<C, INL>(E);
+  R.X = f2m<C, INL>(A, f2_sub<C>(B, Fv));
+  R.Y = f2_sub<C>(f2s<C, INL>(G), f2_mul3<C>(Esq));
+  R.Z = f2m<C, INL>(B, H);
   return {f2_neg<C>(H), f2_mul3<C>(J), I};
 }
 
+template <class C, bool INL>
+BGLS_HD LineCoeffs<C> add_step_t(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq) {
+  Fp2<C> th = f2_sub<C>(R.Y, f2m<C, INL>(yq, R.Z));
+  Fp2<C> la = f2_sub<C>(R.X, f2m<C, INL>(xq, R.Z));
+  Fp2<C> Cc = f2s<C, INL>(th);
+  Fp2<C> D = f2s<C, INL>(la);
+  Fp2<C> E = f2m<C, INL>(la, D);
+  Fp2<C> Fv = f2m<C, INL>(R.Z, Cc);
+  Fp2<C> G = f2m<C, INL>(R.X, D);
+  Fp2<C> Hh = f2_sub<C>(f2_add<C>(E, Fv), f2_dbl<C>(G));
+  Fp2<C> j = f2_sub<C>(f2m<C, INL>(th, xq), f2m<C, INL>(la, yq));
+  R.X = f2m<C, INL>(la, Hh);
+  R.Y = f2_sub<C>(f2m<C, INL>(th, f2_sub<C>(G, Hh)), f2m<C, INL>(E, R.Y));
+  R.Z = f2m<C, INL>(R.Z, E);
+  return {la, f2_neg<C>(th), j};
+}
+
+template <class C>
+BGLS_FN LineCoeffs<C> dbl_step(G2Proj<C>& R) {
+  return dbl_step_t<C, false>(R);
+}
 template <class C>
 BGLS_FN LineCoeffs<C> add_step(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq) {
-  Fp2<C> th = f2_sub<C>(R.Y, f2_mul<C>(yq, R.Z));
-  Fp2<C> la = f2_sub<C>(R.X, f2_mul<C>(xq, R.Z));
-  Fp2<C> Cc = f2_sqr<C>(th);
-  Fp2<C> D = f2_sqr<C>(la);
-  Fp2<C> E = f2_mul<C>(la, D);
-  Fp2<C> Fv = f2_mul<C>(R.Z, Cc);
-  Fp2<C> G = f2_mul<C>(R.X, D);
-  Fp2<C> Hh = f2_sub<C>(f2_add<C>(E, Fv), f2_dbl<C>(G));
-  Fp2<C> j = f2_sub<C>(f2_mul<C>(th, xq), f2_mul<C>(la, yq));
-  R.X = f2_mul<C>(la, Hh);
-  R.Y = f2_sub<C>(f2_mul<C>(th, f2_sub<C>(G, Hh)), f2_mul<C>(E, R.Y));
-  R.Z = f2_mul<C>(R.Z, E);
-  return {la, f2_neg<C>(th), j};
+  return add_step_t<C, false>(R, xq, yq);
+}
+// the same steps with every Fp2 product expanded in place
+template <class C>
+BGLS_FN LineCoeffs<C> dbl_step_inl(G2Proj<C>& R) {
+  return dbl_step_t<C, true>(R);
+}
+template <class C>
+BGLS_FN LineCoeffs<C> add_step_inl(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq) {
+  return add_step_t<C, true>(R, xq, yq);
 }
 
 // f * line(P)

@@ -80,7 +80,7 @@ BGLS_HD Fp2<C> f2_muls(const Fp2<C>& a, const Fp<C>& s) {  // by an Fp scalar
 // Karatsuba with lazy reduction: 3 wide products, 2 Montgomery reductions.
 // Bounds: (a0+a1)(b0+b1) < 4p^2 < 2^(64L); both reduced inputs < 2p^2 < p*2^(32L).
 template <class C>
-BGLS_FN Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
+BGLS_HD Fp2<C> f2_mul_inl(const Fp2<C>& a, const Fp2<C>& b) {
   constexpr int W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
   mul_wide<C>(v0, a.c0.v, b.c0.v);
@@ -99,7 +99,7 @@ BGLS_FN Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
 }
 
 template <class C>
-BGLS_FN Fp2<C> f2_sqr(const Fp2<C>& a) {
+BGLS_HD Fp2<C> f2_sqr_inl(const Fp2<C>& a) {
   constexpr int W = 2 * C::L;
   Fp<C> s = fp_add_nr<C>(a.c0, a.c1);
   Fp<C> d = fp_sub<C>(a.c0, a.c1);
@@ -111,6 +111,15 @@ BGLS_FN Fp2<C> f2_sqr(const Fp2<C>& a) {
   r.c0 = redc<C>(t0);
   r.c1 = redc<C>(t1);
   return r;
+}
+
+template <class C>
+BGLS_FN Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
+  return f2_mul_inl<C>(a, b);
+}
+template <class C>
+BGLS_FN Fp2<C> f2_sqr(const Fp2<C>& a) {
+  return f2_sqr_inl<C>(a);
 }
 
 // multiply by the sextic non-residue xi = XI_RE + i
