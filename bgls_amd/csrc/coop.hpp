@@ -31,7 +31,19 @@ struct Coop {
   static constexpr int GROUPS = 10;
   static constexpr int WAVE_BYTES = GROUPS * GROUP_DW * 4;
   static constexpr int LAZY_K = C::CURVE_ID == 0 ? 3 : 2;   // 12 p^2 < LAZY_K * p * 2^(32L)
+  // producer/consumer variant: a second line buffer so the point-step wave can run one step ahead
+  static constexpr int RL2 = 30 * S2;
+  static constexpr int GROUP_DW_AB = 48 * S2;
+  static constexpr int BLOCK_BYTES_AB = GROUPS * GROUP_DW_AB * 4;
 };
+
+// Ordering point for LDS traffic between the lanes of ONE wave: the DS unit executes a wave's
+// instructions in order, so only the compiler has to be kept from moving accesses across it.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __constant__ const int COOP_SH6[6] = {0, 1, 2, 3, 4, 5};
 __device__ __constant__ const int COOP_SH_D[3] = {0, 1, 3};   // D-type line: e0 + e1 w + e3 w^3
@@ -69,7 +81,7 @@ __device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a) {
 // c_j = sum_{t<NT} A[t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
 //   A[t] at dword offset a_off + t*a_stride, B from the group's RB region at rb_off.
 template <class C, int NT>
-__device__ __noinline__ Fp2<C> coop_dot(int a_off, int a_stride, int rb_off, int j, const int* sh) {
+__device__ __forceinline__ Fp2<C> coop_dot_inl(int a_off, int a_stride, int rb_off, int j, const int* sh) {
   constexpr int L = C::L, W = 2 * C::L, S2 = 2 * C::L;
   u32 v0[W], v1[W], s[W];
 #pragma unroll
@@ -102,6 +114,11 @@ __device__ __noinline__ Fp2<C> coop_dot(int a_off, int a_stride, int rb_off, int
   return r;
 }
 
+template <class C, int NT>
+__device__ __noinline__ Fp2<C> coop_dot(int a_off, int a_stride, int rb_off, int j, const int* sh) {
+  return coop_dot_inl<C, NT>(a_off, a_stride, rb_off, j, sh);
+}
+
 // publish this lane's coefficient (plain and xi-multiplied) into the group's RB region
 template <class C>
 __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v, bool live) {
@@ -109,38 +126,42 @@ __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v,
     lds_store_f2<C>(rb_off + (2 * j) * Coop<C>::S2, v);
     lds_store_f2<C>(rb_off + (2 * j + 1) * Coop<C>::S2, f2_mulxi<C>(v));
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // f <- f * g for two distributed values: g's coefficient of this lane is `gj`, f lives in RB.
-template <class C>
-__device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool live) {
+template <class C, bool INL = false>
+__device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool live, int rl = Coop<C>::RL) {
   typedef Coop<C> K;
-  if (live) lds_store_f2<C>(gb + K::RL + j * K::S2, gj);
-  __syncthreads();
-  Fp2<C> r = coop_dot<C, 6>(gb + K::RL, K::S2, gb + K::RB, j, COOP_SH6);
-  __syncthreads();
+  if (live) lds_store_f2<C>(gb + rl + j * K::S2, gj);
+  wave_sync();
+  Fp2<C> r;
+  if constexpr (INL) r = coop_dot_inl<C, 6>(gb + rl, K::S2, gb + K::RB, j, COOP_SH6);
+  else r = coop_dot<C, 6>(gb + rl, K::S2, gb + K::RB, j, COOP_SH6);
+  wave_sync();
   return r;
 }
 
 // f <- f^2, f in RB
-template <class C>
+template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_sqr(int gb, int j) {
   typedef Coop<C> K;
-  return coop_dot<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
+  if constexpr (INL) return coop_dot_inl<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
+  else return coop_dot<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
 }
 
 // f <- f * line_m, line coefficients at RL[m][0..2]
-template <class C>
-__device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m) {
+template <class C, bool INL = false>
+__device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m, int rl = Coop<C>::RL) {
   typedef Coop<C> K;
-  return coop_dot<C, 3>(gb + K::RL + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+  if constexpr (INL) return coop_dot_inl<C, 3>(gb + rl + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+  else return coop_dot<C, 3>(gb + rl + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
 }
 
 // write this lane's (scaled) line into RL[j]; an inactive pairing contributes the constant 1
 template <class C>
 __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<C>& l, const Fp<C>& xP, const Fp<C>& yP, bool valid,
-                                                bool live) {
+                                                bool live, int rl = Coop<C>::RL) {
   typedef Coop<C> K;
   Fp2<C> e0, e1, e2;
   if constexpr (C::TWIST_D) {
@@ -150,21 +171,21 @@ __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<
   }
   if (!valid) { e0 = f2_one<C>(); e1 = f2_zero<C>(); e2 = f2_zero<C>(); }
   if (live) {
-    const int o = gb + K::RL + j * 3 * K::S2;
+    const int o = gb + rl + j * 3 * K::S2;
     lds_store_f2<C>(o, e0);
     lds_store_f2<C>(o + K::S2, e1);
     lds_store_f2<C>(o + 2 * K::S2, e2);
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // fold the six published lines into f (f in RB on entry and on exit; returns this lane's coefficient)
-template <class C>
-__device__ __forceinline__ Fp2<C> coop_apply_lines(int gb, int j, bool live) {
+template <class C, bool INL = false>
+__device__ __forceinline__ Fp2<C> coop_apply_lines(int gb, int j, bool live, int rl = Coop<C>::RL) {
   Fp2<C> fj;
 #pragma unroll 1
   for (int m = 0; m < 6; ++m) {
-    fj = coop_mul_line<C>(gb, j, m);
+    fj = coop_mul_line<C, INL>(gb, j, m, rl);
     coop_publish<C>(gb + Coop<C>::RB, j, fj, live);
   }
   return fj;

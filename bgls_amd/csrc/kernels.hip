@@ -423,6 +423,120 @@ __global__ void __launch_bounds__(64) k_miller_coop(const Aff<F1<C>>* g1s, const
   if (live && G < groups_total) out[G * 6 + j] = ft;
 }
 
+// Producer/consumer form of the cooperative Miller loop: a block is TWO waves working on the same
+// 60 pairings.  Wave 0 runs the per-lane G2 point steps and publishes the lines of step s into
+// line buffer s&1; wave 1 folds them into the shared accumulators while wave 0 already computes
+// step s+1.  One workgroup barrier per step.  Doubles the number of waves for a given batch, which
+// is what a 2^16-signer batch needs to keep more than one wave per SIMD busy.
+template <class C>
+__global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long gen_at, int rounds,
+                                                   size_t groups_total, Fp2<C>* out, uint32_t* flags) {
+  typedef Coop<C> K;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const bool live = lane < 60;
+  const int g = live ? lane / 6 : 9;
+  const int j = live ? lane % 6 : lane - 60;
+  const int gb = g * K::GROUP_DW_AB;
+  const size_t G = (size_t)blockIdx.x * K::GROUPS + g;
+  if (wave == 0) {
+    // ---------------- producer: point steps + line evaluation
+    for (int r = 0; r < rounds; ++r) {
+      const size_t idx = ((size_t)r * groups_total + G) * 6 + j;
+      Aff<F2<C>> Q;
+      Aff<F1<C>> P;
+      bool valid = idx < n && G < groups_total;
+      if (valid) {
+        if ((long long)idx == gen_at) {
+          Q.x = f2_load<C>(C::G2);
+          Q.y = f2_load<C>(C::G2 + 2 * C::L);
+          Q.inf = false;
+        } else {
+          size_t k = (gen_at >= 0 && (long long)idx > gen_at) ? idx - 1 : idx;
+          bool ok = g2_from_bytes<C>(Q, g2s + k * 4 * C::FP_BYTES);
+          ok = ok && aff_on_curve<F2<C>>(Q);
+          if (!ok) atomicOr(flags, FLAG_ENC);
+        }
+        P = g1s[idx];
+        valid = !P.inf && !Q.inf;
+      }
+      if (!valid) {
+        Q.x = f2_load<C>(C::G2);
+        Q.y = f2_load<C>(C::G2 + 2 * C::L);
+        P.x = fp_load<C>(C::G1X);
+        P.y = fp_load<C>(C::G1Y);
+      }
+      G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+      const Fp2<C> nyq = f2_neg<C>(Q.y);
+      int buf = 0;
+#pragma unroll 1
+      for (int i = 1; i < C::LOOP_LEN; ++i) {
+        LineCoeffs<C> l = dbl_step_t<C, false>(T);
+        coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+        __syncthreads();
+        buf ^= 1;
+        const int d = C::LOOP_NAF[i];
+        if (d != 0) {
+          l = add_step_t<C, false>(T, Q.x, d > 0 ? Q.y : nyq);
+          coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+          __syncthreads();
+          buf ^= 1;
+        }
+      }
+      if constexpr (C::CURVE_ID == 0) {
+        Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+        Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+        Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+        Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+        LineCoeffs<C> l = add_step_t<C, false>(T, x1, y1);
+        coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+        __syncthreads();
+        buf ^= 1;
+        l = add_step_t<C, false>(T, x2, y2);
+        coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+        __syncthreads();
+        buf ^= 1;
+      }
+      __syncthreads();   // round boundary: the consumer has finished with both line buffers
+    }
+  } else {
+    // ---------------- consumer: fold the lines into the shared accumulators
+    Fp2<C> ft = j == 0 ? f2_one<C>() : f2_zero<C>();
+    for (int r = 0; r < rounds; ++r) {
+      Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
+      coop_publish<C>(gb + K::RB, j, fj, live);
+      int buf = 0;
+#pragma unroll 1
+      for (int i = 1; i < C::LOOP_LEN; ++i) {
+        __syncthreads();
+        fj = coop_sqr<C, true>(gb, j);
+        coop_publish<C>(gb + K::RB, j, fj, live);
+        fj = coop_apply_lines<C, true>(gb, j, live, buf ? K::RL2 : K::RL);
+        buf ^= 1;
+        if (C::LOOP_NAF[i] != 0) {
+          __syncthreads();
+          fj = coop_apply_lines<C, true>(gb, j, live, buf ? K::RL2 : K::RL);
+          buf ^= 1;
+        }
+      }
+      if constexpr (C::CURVE_ID == 0) {
+        __syncthreads();
+        fj = coop_apply_lines<C, true>(gb, j, live, buf ? K::RL2 : K::RL);
+        buf ^= 1;
+        __syncthreads();
+        fj = coop_apply_lines<C, true>(gb, j, live, buf ? K::RL2 : K::RL);
+        buf ^= 1;
+      } else {
+        if (j & 1) fj = f2_neg<C>(fj);
+        coop_publish<C>(gb + K::RB, j, fj, live);
+      }
+      ft = coop_mul<C, true>(gb, j, ft, live, K::RL);
+      __syncthreads();   // round boundary
+    }
+    if (live && G < groups_total) out[G * 6 + j] = ft;
+  }
+}
+
 // out[G] = prod in[G*R .. min(count, (G+1)*R))   (w-basis Fp12 arrays)
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_coop(const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
@@ -474,7 +588,7 @@ template <class C>
 __device__ __forceinline__ Fp2<C> csqr(const CoopLane<C>& ln, const Fp2<C>& a) {
   coop_publish<C>(ln.gb + Coop<C>::RB, ln.j, a, ln.live);
   Fp2<C> r = coop_sqr<C>(ln.gb, ln.j);
-  __syncthreads();
+  wave_sync();
   return r;
 }
 // a^e, public exponent, top bit set
@@ -500,9 +614,9 @@ __device__ __noinline__ Fp2<C> cinv(const CoopLane<C>& ln, const Fp2<C>& a) {
     const Fp2<C> o[6] = {fi.g.a0, fi.h.a0, fi.g.a1, fi.h.a1, fi.g.a2, fi.h.a2};
     for (int k = 0; k < 6; ++k) lds_store_f2<C>(ln.gb + K::RL + k * K::S2, o[k]);
   }
-  __syncthreads();
+  wave_sync();
   Fp2<C> r = lds_load_f2<C>(ln.gb + K::RL + ln.j * K::S2);
-  __syncthreads();
+  wave_sync();
   return r;
 }
 
@@ -653,6 +767,14 @@ Ctx& ctx() {
 
 // BGLS_KERNELS=v1 selects the round-1 thread-per-pairing kernels (kept for A/B measurements);
 // default is the wave-cooperative path (coop.hpp).
+// BGLS_MILLER=coop1 selects the single-wave cooperative kernel; default is the producer/consumer pair.
+int miller_mode() {
+  static const int v = [] {
+    const char* e = getenv("BGLS_MILLER");
+    return (e && !strcmp(e, "coop1")) ? 1 : 2;
+  }();
+  return v;
+}
 bool use_coop() {
   static const bool v = [] {
     const char* e = getenv("BGLS_KERNELS");
@@ -777,7 +899,10 @@ struct Engine {
     if ((rc = c.get(WS_F_B, (groups / 16 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
       Scope sc(c, st, ST_MILLER);
-      k_miller_coop<C><<<nblk(groups, K::GROUPS), 64, K::WAVE_BYTES, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
+      if (miller_mode() == 1)
+        k_miller_coop<C><<<nblk(groups, K::GROUPS), 64, K::WAVE_BYTES, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
+      else
+        k_miller_ab<C><<<nblk(groups, K::GROUPS), 128, K::BLOCK_BYTES_AB, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
     }
     Scope sc(c, st, ST_REDUCE);
     Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;
