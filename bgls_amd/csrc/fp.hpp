@@ -208,24 +208,49 @@ BGLS_HD void mul_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L], const u32 (&b)[C
   }
 }
 
-// N independent products with their rows interleaved in program order: a single wave then has
-// N independent mad/carry chains in flight (matters when only one or two waves share a SIMD).
-template <class C, int N>
-BGLS_HD void mul_wide_n(u32 (&t)[N][2 * C::L], const u32 (&a)[N][C::L], const u32 (&b)[N][C::L]) {
+// Two independent products with their rows interleaved: the two carry chains alternate, so the
+// 2-wait-state gap gfx950 needs between dependent v_addc's is filled with the other chain's work
+// instead of s_nop.
+template <class C>
+BGLS_HD void mul_wide2(u32 (&t0)[2 * C::L], u32 (&t1)[2 * C::L], const u32 (&a0)[C::L], const u32 (&b0)[C::L],
+                       const u32 (&a1)[C::L], const u32 (&b1)[C::L]) {
   constexpr int L = C::L;
+  {
+    u64 P[L], Q[L];
 #pragma unroll
-  for (int i = 0; i < L; ++i) {
-#pragma unroll
-    for (int q = 0; q < N; ++q) {
-      u64 P[L];
-#pragma unroll
-      for (int j = 0; j < L; ++j) P[j] = (u64)a[q][j] * b[q][i] + (i ? t[q][i + j] : 0u);
-      t[q][i] = (u32)P[0];
-      u32 c = 0;
-#pragma unroll
-      for (int j = 1; j < L; ++j) t[q][i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c);
-      t[q][i + L] = (u32)(P[L - 1] >> 32) + c;
+    for (int j = 0; j < L; ++j) {
+      P[j] = (u64)a0[j] * b0[0];
+      Q[j] = (u64)a1[j] * b1[0];
     }
+    t0[0] = (u32)P[0];
+    t1[0] = (u32)Q[0];
+    u32 c0 = 0, c1 = 0;
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+      t0[j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c0);
+      t1[j] = addc((u32)Q[j], (u32)(Q[j - 1] >> 32), c1);
+    }
+    t0[L] = (u32)(P[L - 1] >> 32) + c0;
+    t1[L] = (u32)(Q[L - 1] >> 32) + c1;
+  }
+#pragma unroll
+  for (int i = 1; i < L; ++i) {
+    u64 P[L], Q[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      P[j] = (u64)a0[j] * b0[i] + t0[i + j];
+      Q[j] = (u64)a1[j] * b1[i] + t1[i + j];
+    }
+    t0[i] = (u32)P[0];
+    t1[i] = (u32)Q[0];
+    u32 c0 = 0, c1 = 0;
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+      t0[i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c0);
+      t1[i + j] = addc((u32)Q[j], (u32)(Q[j - 1] >> 32), c1);
+    }
+    t0[i + L] = (u32)(P[L - 1] >> 32) + c0;
+    t1[i + L] = (u32)(Q[L - 1] >> 32) + c1;
   }
 }
 
@@ -394,9 +419,66 @@ BGLS_FN Fp<C> fp_pow_w4(const Fp<C>& a, const u32* e) {
   return r;
 }
 
+// Modular inverse by the binary extended Euclidean algorithm (0 -> 0).  The inverse is unique, so
+// this returns the same field element as the reference's big.Int ModInverse / a^(p-2)
+// (curves/hash.go:109,139) at a fraction of the cost of an exponentiation.
 template <class C>
-BGLS_HD Fp<C> fp_inv(const Fp<C>& a) {  // a^(p-2); 0 -> 0
-  return fp_pow_w4<C, C::L>(a, C::EXP_INV);
+BGLS_FN Fp<C> fp_inv(const Fp<C>& a) {
+  constexpr int L = C::L;
+  if (fp_is_zero<C>(a)) return a;
+  u32 u[L], v[L];
+  Fp<C> x1 = fp_zero<C>(), x2 = fp_zero<C>();
+  x1.v[0] = 1;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    u[j] = a.v[j];
+    v[j] = C::P[j];
+  }
+  auto is_one = [](const u32(&w)[L]) {
+    u32 o = w[0] ^ 1u;
+#pragma unroll
+    for (int j = 1; j < L; ++j) o |= w[j];
+    return o == 0;
+  };
+  auto shr1 = [](u32(&w)[L], u32 top) {
+#pragma unroll
+    for (int j = 0; j < L - 1; ++j) w[j] = (w[j] >> 1) | (w[j + 1] << 31);
+    w[L - 1] = (w[L - 1] >> 1) | (top << 31);
+  };
+  auto half_mod = [&](Fp<C>& x) {       // x/2 mod p
+    u32 c = 0;
+    const u32 mask = 0u - (x.v[0] & 1u);
+#pragma unroll
+    for (int j = 0; j < L; ++j) x.v[j] = addc(x.v[j], C::P[j] & mask, c);
+    shr1(x.v, c);
+  };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1u)) {
+      shr1(u, 0);
+      half_mod(x1);
+    }
+    while (!(v[0] & 1u)) {
+      shr1(v, 0);
+      half_mod(x2);
+    }
+    u32 bw = 0;
+    u32 d[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) d[j] = subb(u[j], v[j], bw);
+    if (!bw) {                           // u >= v
+#pragma unroll
+      for (int j = 0; j < L; ++j) u[j] = d[j];
+      x1 = fp_sub<C>(x1, x2);
+    } else {
+      bw = 0;
+#pragma unroll
+      for (int j = 0; j < L; ++j) v[j] = subb(v[j], u[j], bw);
+      x2 = fp_sub<C>(x2, x1);
+    }
+  }
+  Fp<C> r = is_one(u) ? x1 : x2;        // (a R)^-1 as a plain residue
+  const Fp<C> r2 = fp_load<C>(C::R2);
+  return fp_mul_inl<C>(fp_mul_inl<C>(r, r2), r2);   // -> a^-1 R
 }
 
 // candidate square root a^((p+1)/4) (calcQuadRes, curves/hash.go:178-190); caller checks r^2 == a

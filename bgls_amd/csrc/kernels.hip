@@ -20,6 +20,7 @@
 #include "pairing.hpp"
 #include "h2c.hpp"
 #include "coop.hpp"
+#include "finalexp.hpp"
 #include "../../include/bgls_hip.h"
 
 using namespace bgls;
@@ -684,6 +685,38 @@ __global__ void __launch_bounds__(64) k_final_coop(const uint8_t* partials, size
   }
 }
 
+// product of `count` serialised partials -> final exponentiation on 36 lanes (finalexp.hpp)
+template <class C>
+__global__ void __launch_bounds__(64) k_final36(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out,
+                                                uint32_t* verdict, uint32_t* flags) {
+  typedef FE<C> E;
+  const int lane = threadIdx.x;
+  const int order_pos[6] = {5, 2, 4, 1, 3, 0};
+  for (size_t k = 0; k < count; ++k) {
+    if (lane < 6) {
+      const uint8_t* b = partials + k * 12 * C::FP_BYTES + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+      Fp<C> im = fp_from_be<C>(b), re = fp_from_be<C>(b + C::FP_BYTES);
+      if (fp_geq_p<C>(im) || fp_geq_p<C>(re)) atomicOr(flags, FLAG_ENC);
+      fe_put<C>(k == 0 ? FE_F : FE_X, lane, Fp2<C>{fp_to_mont<C>(re), fp_to_mont<C>(im)});
+    }
+    wave_sync();
+    if (k > 0) fe_mul<C>(FE_F, FE_F, FE_X);
+  }
+  if (do_final_exp) fe_final_exp<C>();
+  bool is_one = true;
+  if (lane < 6) {
+    Fp2<C> v = lds_load_f2<C>(E::coef(FE_F, lane, 0));
+    is_one = lane == 0 ? f2_eq<C>(v, f2_one<C>()) : f2_is_zero<C>(v);
+    if (gt_out) {
+      uint8_t* o = gt_out + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+      fp_to_be<C>(o, fp_from_mont<C>(v.c1));
+      fp_to_be<C>(o + C::FP_BYTES, fp_from_mont<C>(v.c0));
+    }
+  }
+  const unsigned long long ball = __ballot(is_one);
+  if (lane == 0) verdict[0] = (ball == ~0ull) ? 1u : 0u;
+}
+
 // ======================================================================= host side
 namespace {
 
@@ -772,6 +805,14 @@ int miller_mode() {
   static const int v = [] {
     const char* e = getenv("BGLS_MILLER");
     return (e && !strcmp(e, "coop1")) ? 1 : 2;
+  }();
+  return v;
+}
+// BGLS_FINAL=6 selects the 6-lane final exponentiation; default is the 36-lane one.
+int final_mode() {
+  static const int v = [] {
+    const char* e = getenv("BGLS_FINAL");
+    return (e && !strcmp(e, "6")) ? 6 : 36;
   }();
   return v;
 }
@@ -949,7 +990,9 @@ struct Engine {
     HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
     {
       Scope sc(c, st, ST_FINAL);
-      if (use_coop())
+      if (use_coop() && final_mode() == 36)
+        k_final36<C><<<1, 64, FE<C>::LDS_BYTES, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      else if (use_coop())
         k_final_coop<C><<<1, 64, Coop<C>::WAVE_BYTES, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
       else
         k_final<C><<<1, 64, 0, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
