@@ -82,7 +82,8 @@ def cpu_baseline(cid, keys, msgs, sigs, n, fp, lib):
     same instance, in the reference's parallel shape: one task per hash and per FULL pairing
     (final exponentiation inside every pairing, curves/curve.go:132-134)."""
     from oracle import coracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)
     probe = min(n, 4 * cores)
 
     def run(cnt, faithful):

@@ -800,11 +800,13 @@ Ctx& ctx() {
 
 // BGLS_KERNELS=v1 selects the round-1 thread-per-pairing kernels (kept for A/B measurements);
 // default is the wave-cooperative path (coop.hpp).
-// BGLS_MILLER=coop1 selects the single-wave cooperative kernel; default is the producer/consumer pair.
+// BGLS_MILLER=coop1 / ab forces the single-wave / producer-consumer cooperative kernel; default: by batch size.
 int miller_mode() {
   static const int v = [] {
     const char* e = getenv("BGLS_MILLER");
-    return (e && !strcmp(e, "coop1")) ? 1 : 2;
+    if (e && !strcmp(e, "coop1")) return 1;
+    if (e && !strcmp(e, "ab")) return 2;
+    return 0;
   }();
   return v;
 }
@@ -940,7 +942,10 @@ struct Engine {
     if ((rc = c.get(WS_F_B, (groups / 16 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
       Scope sc(c, st, ST_MILLER);
-      if (miller_mode() == 1)
+      // producer/consumer pairs double the wave count: worth it while all blocks stay resident
+      // (5 blocks per CU by LDS); larger batches saturate the chip with the single-wave form.
+      const bool ab = miller_mode() == 2 || (miller_mode() == 0 && nblk(groups, K::GROUPS) <= 1280u);
+      if (!ab)
         k_miller_coop<C><<<nblk(groups, K::GROUPS), 64, K::WAVE_BYTES, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
       else
         k_miller_ab<C><<<nblk(groups, K::GROUPS), 128, K::BLOCK_BYTES_AB, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);

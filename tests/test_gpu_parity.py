@@ -281,3 +281,35 @@ def test_bad_encodings_are_errors_not_accepts(gpu_lib, curve):
     rc = gpu_lib.bgls_verify_aggregate(cid, B(bytes.fromhex(case["sig"])), B(bytes(keys)), B(b"".join(msgs)), offsets(msgs), len(msgs), 0)
     assert rc == -2
     assert gpu_lib.bgls_verify_aggregate(9, None, None, None, None, 0, 0) < 0
+
+
+def test_alternate_kernel_paths_agree(curve):
+    """The round-1 thread-per-pairing kernels and both cooperative Miller kernels stay selectable
+    (BGLS_KERNELS / BGLS_MILLER / BGLS_FINAL) for A/B measurements; all must give the golden GT bytes."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, json, sys
+sys.path.insert(0, %r)
+from bgls_amd import _lib
+lib = _lib.load(); assert lib.bgls_init(0) == 0
+v = json.load(open(%r))
+pp = v["pairing_product"]; n = len(pp["g1s"]); fp = %d
+B = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+o = (ctypes.c_uint8 * (12 * fp))()
+rc = lib.bgls_pairing_product(%d, B(b"".join(map(bytes.fromhex, pp["g1s"]))), B(b"".join(map(bytes.fromhex, pp["g2s"]))), n, o)
+ok = rc == 0 and bytes(o).hex() == pp["gt"]
+for case in v["aggregate_cases"][:6]:
+    keys = [bytes.fromhex(k) for k in case["keys"]]; msgs = [bytes.fromhex(m) for m in case["msgs"]]
+    if len(keys) != len(msgs): continue
+    off = (ctypes.c_uint64 * (len(msgs) + 1))(); acc = 0
+    for i, m in enumerate(msgs): off[i] = acc; acc += len(m)
+    off[len(msgs)] = acc
+    r = lib.bgls_verify_aggregate(%d, B(bytes.fromhex(case["sig"])), B(b"".join(keys)), B(b"".join(msgs)), off, len(keys), 1 if case["allow_dups"] else 0)
+    ok = ok and ((r == 1) == case["expect"])
+print("OK" if ok else "MISMATCH")
+''' % (root, os.path.join(root, "tests", "golden", "vectors_%s.json" % curve["name"]), curve["fp"], curve["id"], curve["id"])
+    for env in ({"BGLS_KERNELS": "v1"}, {"BGLS_MILLER": "coop1", "BGLS_FINAL": "6"}, {"BGLS_MILLER": "ab"}):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert out.stdout.strip().endswith("OK"), (env, out.stdout[-500:], out.stderr[-500:])
