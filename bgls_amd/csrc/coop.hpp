@@ -27,13 +27,14 @@ struct Coop {
   static constexpr int S2 = 2 * C::L;        // dwords per Fp2
   static constexpr int RB = 0;               // [6][2] Fp2: coefficient k -> {e_k, xi*e_k}
   static constexpr int RL = 12 * S2;         // [6][3] Fp2 line coefficients / [6] plain operand
-  static constexpr int GROUP_DW = 30 * S2;
+  static constexpr int PAD = 16;             // keeps the groups of a wave on different LDS banks
+  static constexpr int GROUP_DW = 30 * S2 + PAD;
   static constexpr int GROUPS = 10;
   static constexpr int WAVE_BYTES = GROUPS * GROUP_DW * 4;
   static constexpr int LAZY_K = C::CURVE_ID == 0 ? 3 : 2;   // 12 p^2 < LAZY_K * p * 2^(32L)
   // producer/consumer variant: a second line buffer so the point-step wave can run one step ahead
   static constexpr int RL2 = 30 * S2;
-  static constexpr int GROUP_DW_AB = 48 * S2;
+  static constexpr int GROUP_DW_AB = 48 * S2 + PAD;
   static constexpr int BLOCK_BYTES_AB = GROUPS * GROUP_DW_AB * 4;
 };
 
@@ -48,6 +49,47 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __constant__ const int COOP_SH6[6] = {0, 1, 2, 3, 4, 5};
 __device__ __constant__ const int COOP_SH_D[3] = {0, 1, 3};   // D-type line: e0 + e1 w + e3 w^3
 __device__ __constant__ const int COOP_SH_M[3] = {0, 2, 3};   // M-type line: e0 + e2 w^2 + e3 w^3
+
+// A region holds NENT Fp2 entries CHUNK-MAJOR: the c-th 16-byte chunk of every entry is contiguous
+// (address = base + c*NENT*4 + entry*4 dwords).  The six lanes of a group read six different
+// entries with one ds_read_b128 each, which then fall into adjacent 16-byte slots instead of the
+// same banks (entry-major slots are 64 B / 96 B apart: a 3-way .. 10-way conflict, measured 27
+// conflict cycles per LDS instruction before this layout).
+struct LReg {
+  int base, nent;
+};
+template <class C>
+__device__ __forceinline__ Fp2<C> lds_ld(LReg r, int e) {
+  extern __shared__ u32 lds[];
+  Fp2<C> o;
+  const int a = r.base + e * 4, st = r.nent * 4;
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) {
+    uint4 v = *reinterpret_cast<const uint4*>(lds + a + k * st);
+    o.c0.v[4 * k] = v.x; o.c0.v[4 * k + 1] = v.y; o.c0.v[4 * k + 2] = v.z; o.c0.v[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) {
+    uint4 v = *reinterpret_cast<const uint4*>(lds + a + (C::L / 4 + k) * st);
+    o.c1.v[4 * k] = v.x; o.c1.v[4 * k + 1] = v.y; o.c1.v[4 * k + 2] = v.z; o.c1.v[4 * k + 3] = v.w;
+  }
+  return o;
+}
+template <class C>
+__device__ __forceinline__ void lds_st(LReg r, int e, const Fp2<C>& x) {
+  extern __shared__ u32 lds[];
+  const int a = r.base + e * 4, st = r.nent * 4;
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k)
+    *reinterpret_cast<uint4*>(lds + a + k * st) = make_uint4(x.c0.v[4 * k], x.c0.v[4 * k + 1], x.c0.v[4 * k + 2], x.c0.v[4 * k + 3]);
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k)
+    *reinterpret_cast<uint4*>(lds + a + (C::L / 4 + k) * st) = make_uint4(x.c1.v[4 * k], x.c1.v[4 * k + 1], x.c1.v[4 * k + 2], x.c1.v[4 * k + 3]);
+}
+template <class C>
+__device__ __forceinline__ LReg reg_rb(int gb) { return {gb + Coop<C>::RB, 12}; }
+template <class C>
+__device__ __forceinline__ LReg reg_rl(int gb, int rl) { return {gb + rl, 18}; }
 
 template <class C>
 __device__ __forceinline__ Fp2<C> lds_load_f2(int off) {
@@ -79,10 +121,10 @@ __device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a) {
 }
 
 // c_j = sum_{t<NT} A[t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
-//   A[t] at dword offset a_off + t*a_stride, B from the group's RB region at rb_off.
+//   A[t] = entry a_e0 + t*a_es of region ra;  B = entries {2k, 2k+1} = {e_k, xi e_k} of region rb.
 template <class C, int NT>
-__device__ __forceinline__ Fp2<C> coop_dot_inl(int a_off, int a_stride, int rb_off, int j, const int* sh) {
-  constexpr int L = C::L, W = 2 * C::L, S2 = 2 * C::L;
+__device__ __forceinline__ Fp2<C> coop_dot_inl(LReg ra, int a_e0, int a_es, LReg rb, int j, const int* sh) {
+  constexpr int L = C::L, W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) v0[k] = v1[k] = s[k] = 0;
@@ -92,8 +134,8 @@ __device__ __forceinline__ Fp2<C> coop_dot_inl(int a_off, int a_stride, int rb_o
     int k = j - sht;
     const int wrap = k < 0 ? 1 : 0;
     k += 6 * wrap;
-    Fp2<C> a = lds_load_f2<C>(a_off + t * a_stride);
-    Fp2<C> b = lds_load_f2<C>(rb_off + (2 * k + wrap) * S2);
+    Fp2<C> a = lds_ld<C>(ra, a_e0 + t * a_es);
+    Fp2<C> b = lds_ld<C>(rb, 2 * k + wrap);
     u32 tmp[W];
     mul_wide<C>(tmp, a.c0.v, b.c0.v);
     w_add<W>(v0, v0, tmp);
@@ -115,16 +157,17 @@ __device__ __forceinline__ Fp2<C> coop_dot_inl(int a_off, int a_stride, int rb_o
 }
 
 template <class C, int NT>
-__device__ __noinline__ Fp2<C> coop_dot(int a_off, int a_stride, int rb_off, int j, const int* sh) {
-  return coop_dot_inl<C, NT>(a_off, a_stride, rb_off, j, sh);
+__device__ __noinline__ Fp2<C> coop_dot(LReg ra, int a_e0, int a_es, LReg rb, int j, const int* sh) {
+  return coop_dot_inl<C, NT>(ra, a_e0, a_es, rb, j, sh);
 }
 
 // publish this lane's coefficient (plain and xi-multiplied) into the group's RB region
 template <class C>
 __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v, bool live) {
   if (live) {
-    lds_store_f2<C>(rb_off + (2 * j) * Coop<C>::S2, v);
-    lds_store_f2<C>(rb_off + (2 * j + 1) * Coop<C>::S2, f2_mulxi<C>(v));
+    const LReg rb = {rb_off, 12};
+    lds_st<C>(rb, 2 * j, v);
+    lds_st<C>(rb, 2 * j + 1, f2_mulxi<C>(v));
   }
   wave_sync();
 }
@@ -133,11 +176,11 @@ __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v,
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool live, int rl = Coop<C>::RL) {
   typedef Coop<C> K;
-  if (live) lds_store_f2<C>(gb + rl + j * K::S2, gj);
+  if (live) lds_st<C>(reg_rl<C>(gb, rl), j, gj);
   wave_sync();
   Fp2<C> r;
-  if constexpr (INL) r = coop_dot_inl<C, 6>(gb + rl, K::S2, gb + K::RB, j, COOP_SH6);
-  else r = coop_dot<C, 6>(gb + rl, K::S2, gb + K::RB, j, COOP_SH6);
+  if constexpr (INL) r = coop_dot_inl<C, 6>(reg_rl<C>(gb, rl), 0, 1, reg_rb<C>(gb), j, COOP_SH6);
+  else r = coop_dot<C, 6>(reg_rl<C>(gb, rl), 0, 1, reg_rb<C>(gb), j, COOP_SH6);
   wave_sync();
   return r;
 }
@@ -146,16 +189,16 @@ __device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_sqr(int gb, int j) {
   typedef Coop<C> K;
-  if constexpr (INL) return coop_dot_inl<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
-  else return coop_dot<C, 6>(gb + K::RB, 2 * K::S2, gb + K::RB, j, COOP_SH6);
+  if constexpr (INL) return coop_dot_inl<C, 6>(reg_rb<C>(gb), 0, 2, reg_rb<C>(gb), j, COOP_SH6);
+  else return coop_dot<C, 6>(reg_rb<C>(gb), 0, 2, reg_rb<C>(gb), j, COOP_SH6);
 }
 
 // f <- f * line_m, line coefficients at RL[m][0..2]
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m, int rl = Coop<C>::RL) {
   typedef Coop<C> K;
-  if constexpr (INL) return coop_dot_inl<C, 3>(gb + rl + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
-  else return coop_dot<C, 3>(gb + rl + m * 3 * K::S2, K::S2, gb + K::RB, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+  if constexpr (INL) return coop_dot_inl<C, 3>(reg_rl<C>(gb, rl), 3 * m, 1, reg_rb<C>(gb), j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+  else return coop_dot<C, 3>(reg_rl<C>(gb, rl), 3 * m, 1, reg_rb<C>(gb), j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
 }
 
 // write this lane's (scaled) line into RL[j]; an inactive pairing contributes the constant 1
@@ -171,10 +214,10 @@ __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<
   }
   if (!valid) { e0 = f2_one<C>(); e1 = f2_zero<C>(); e2 = f2_zero<C>(); }
   if (live) {
-    const int o = gb + rl + j * 3 * K::S2;
-    lds_store_f2<C>(o, e0);
-    lds_store_f2<C>(o + K::S2, e1);
-    lds_store_f2<C>(o + 2 * K::S2, e2);
+    const LReg r = reg_rl<C>(gb, rl);
+    lds_st<C>(r, 3 * j, e0);
+    lds_st<C>(r, 3 * j + 1, e1);
+    lds_st<C>(r, 3 * j + 2, e2);
   }
   wave_sync();
 }

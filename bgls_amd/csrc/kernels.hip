@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(64) k_miller_coop(const Aff<F1<C>>* g1s, const
 // line buffer s&1; wave 1 folds them into the shared accumulators while wave 0 already computes
 // step s+1.  One workgroup barrier per step.  Doubles the number of waves for a given batch, which
 // is what a 2^16-signer batch needs to keep more than one wave per SIMD busy.
-template <class C>
+template <class C, bool STEP_INL>
 __global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long gen_at, int rounds,
                                                    size_t groups_total, Fp2<C>* out, uint32_t* flags) {
   typedef Coop<C> K;
@@ -472,13 +472,13 @@ __global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, con
       int buf = 0;
 #pragma unroll 1
       for (int i = 1; i < C::LOOP_LEN; ++i) {
-        LineCoeffs<C> l = dbl_step_t<C, false>(T);
+        LineCoeffs<C> l = dbl_step_t<C, STEP_INL>(T);
         coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
         __syncthreads();
         buf ^= 1;
         const int d = C::LOOP_NAF[i];
         if (d != 0) {
-          l = add_step_t<C, false>(T, Q.x, d > 0 ? Q.y : nyq);
+          l = add_step_t<C, STEP_INL>(T, Q.x, d > 0 ? Q.y : nyq);
           coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
           __syncthreads();
           buf ^= 1;
@@ -489,11 +489,11 @@ __global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, con
         Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
         Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
         Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-        LineCoeffs<C> l = add_step_t<C, false>(T, x1, y1);
+        LineCoeffs<C> l = add_step_t<C, STEP_INL>(T, x1, y1);
         coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
         __syncthreads();
         buf ^= 1;
-        l = add_step_t<C, false>(T, x2, y2);
+        l = add_step_t<C, STEP_INL>(T, x2, y2);
         coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
         __syncthreads();
         buf ^= 1;
@@ -609,14 +609,14 @@ __device__ __noinline__ Fp2<C> cinv(const CoopLane<C>& ln, const Fp2<C>& a) {
   coop_publish<C>(ln.gb + K::RB, ln.j, a, ln.live);
   if (ln.live && ln.j == 0) {
     Fp2<C> e[6];
-    for (int k = 0; k < 6; ++k) e[k] = lds_load_f2<C>(ln.gb + K::RB + 2 * k * K::S2);
+    for (int k = 0; k < 6; ++k) e[k] = lds_ld<C>(reg_rb<C>(ln.gb), 2 * k);
     Fp12<C> f = {{e[0], e[2], e[4]}, {e[1], e[3], e[5]}};
     Fp12<C> fi = f12_inv<C>(f);
     const Fp2<C> o[6] = {fi.g.a0, fi.h.a0, fi.g.a1, fi.h.a1, fi.g.a2, fi.h.a2};
-    for (int k = 0; k < 6; ++k) lds_store_f2<C>(ln.gb + K::RL + k * K::S2, o[k]);
+    for (int k = 0; k < 6; ++k) lds_st<C>(reg_rl<C>(ln.gb, K::RL), k, o[k]);
   }
   wave_sync();
-  Fp2<C> r = lds_load_f2<C>(ln.gb + K::RL + ln.j * K::S2);
+  Fp2<C> r = lds_ld<C>(reg_rl<C>(ln.gb, K::RL), ln.j);
   wave_sync();
   return r;
 }
@@ -948,7 +948,10 @@ struct Engine {
       if (!ab)
         k_miller_coop<C><<<nblk(groups, K::GROUPS), 64, K::WAVE_BYTES, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
       else
-        k_miller_ab<C><<<nblk(groups, K::GROUPS), 128, K::BLOCK_BYTES_AB, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
+        if (!getenv("BGLS_STEP_CALLS"))   // in-place point steps by default; BGLS_STEP_CALLS=1 keeps the out-of-line variant
+          k_miller_ab<C, true><<<nblk(groups, K::GROUPS), 128, K::BLOCK_BYTES_AB, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
+        else
+          k_miller_ab<C, false><<<nblk(groups, K::GROUPS), 128, K::BLOCK_BYTES_AB, st>>>(g1s, g2s, total, gen_at, rounds, groups, (Fp2<C>*)pa, d_flags);
     }
     Scope sc(c, st, ST_REDUCE);
     Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;

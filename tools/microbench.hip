@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(64) mb_coop(Fp2<C>* io, int iters) {       // 
   int lane = threadIdx.x; bool live = lane < 60; int g = live ? lane / 6 : 9, j = live ? lane % 6 : lane - 60; int gb = g * K::GROUP_DW;
   Fp2<C> fj = io[blockIdx.x * 64 + lane];
   coop_publish<C>(gb + K::RB, j, fj, live);
-  if (live) for (int t = 0; t < 3; ++t) lds_store_f2<C>(gb + K::RL + (j * 3 + t) * K::S2, fj);
+  if (live) for (int t = 0; t < 3; ++t) lds_st<C>(reg_rl<C>(gb, K::RL), j * 3 + t, fj);
   __syncthreads();
   for (int i = 0; i < iters; ++i) {
     fj = coop_sqr<C>(gb, j);
