@@ -106,6 +106,62 @@ def cpu_baseline(cid, keys, msgs, sigs, n, fp, lib):
                       "(reference shape); with one shared final exponentiation: %.0f pairs/s" % (cnt, cores, min(cnt, 4096) / dt_shared)}
 
 
+def bench_multisig(args, lib, cid, fp, n, dev, rank, world):
+    """BASELINE.json config 4: n signers on ONE message -- G2 key sum (AggregatePoints,
+    curves/curve.go:73-121) + hash + 2 pairings (bgls/bgls.go:59-70,89-92).  Single GPU."""
+    if world != 1:
+        raise SystemExit("multisig workload is single-GPU in this round")
+    rnd = random.Random(0xB6150000 + 4)
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+    kb = b"".join(s.to_bytes(32, "big") for s in sks)
+    g2 = (ctypes.c_uint8 * (4 * fp))()
+    check(lib.bgls_generator(cid, 2, g2), "generator")
+    keys = (ctypes.c_uint8 * (n * 4 * fp))()
+    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(kb), None, n, keys), "scale_points(G2)")
+    msg = b"\x01" + rnd.randbytes(64)
+    off = (ctypes.c_uint64 * 2)(0, len(msg))
+    h = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_hash_to_g1(cid, B(msg), off, 1, h), "hash_to_g1")
+    sig = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_scale_points(cid, 1, h, B((sum(sks) % ORDER[cid]).to_bytes(32, "big")), None, 1, sig), "scale_points(sig)")
+    t_keys = torch.frombuffer(bytearray(bytes(keys)), dtype=torch.uint8).to(dev)
+    t_sig = torch.frombuffer(bytearray(bytes(sig)), dtype=torch.uint8).to(dev)
+    t_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(nn=n):
+        return check(lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), nn, t_msg.data_ptr(), len(msg), stream), "verify_multi_dev")
+
+    if step() != 1 or step(n - 1) != 0:
+        raise RuntimeError("multisig correctness gate failed")
+    for _ in range(args.warmup):
+        step()
+    lib.bgls_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if step() != 1:
+            raise RuntimeError("verification failed inside the timed region")
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sum_ms, sum_cnt = stage(lib, "sum_points")
+    lib.bgls_profile_enable(0)
+    peak = ctypes.c_double()
+    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
+    avg_s = sum_ms / max(sum_cnt, 1) * 1e-3
+    macs = n * MULTISIG_FPMUL[cid] * 3 * MAC_PER_FPMUL[cid]          # one G2 mixed addition = 29 Fp2-level products ~ 3 Fp mults each
+    bytes_per_launch = n * 4 * fp
+    print(json.dumps({
+        "metric": "multisig-verify signers/sec", "value": n * args.steps / elapsed, "unit": "signers/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM" % (args.curve, n)},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sum_first+k_sum_next", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
+                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3,
+                     "hbm_algorithmic_GBps": bytes_per_launch / avg_s / 1e9},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +170,8 @@ def main():
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
     ap.add_argument("--n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig"],
+                    help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +189,9 @@ def main():
     fp = 32 if cid == 0 else 48
     n = args.n
     gtb = 12 * fp
+
+    if args.workload == "multisig":
+        return bench_multisig(args, lib, cid, fp, n, dev, rank, world)
 
     # ---- setup (untimed): resident shard + the global aggregate signature on rank 0
     keys, msgs, part_sig, sigs = make_shard(lib, cid, n, 0xB6150000 + 1 + 1000 * rank)
@@ -207,6 +268,19 @@ def main():
                          "whole_path_frac": value / world * PAIR_FPMUL[cid] * MAC_PER_FPMUL[cid] / peak.value if peak.value else None},
             "stage_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items()},
         }
+        if world == 1:
+            # the same verification through the host-buffer entry point (keys + messages cross PCIe inside the call)
+            off = (ctypes.c_uint64 * (n + 1))(*[64 * i for i in range(n + 1)])
+            kb_, mb_, sb_ = B(keys), B(msgs), B(bytes(agg))
+            check(lib.bgls_verify_aggregate(cid, sb_, kb_, mb_, off, n, 0), "verify_aggregate(host)")
+            t1 = time.perf_counter()
+            ok = check(lib.bgls_verify_aggregate(cid, sb_, kb_, mb_, off, n, 0), "verify_aggregate(host)")
+            dt = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"value": n / dt, "unit": "signer-pairs/s", "ms_per_call": dt * 1e3, "verdict": ok,
+                                     "note": "bgls_verify_aggregate with host buffers (pageable memory), never the headline value"}
+            pmc = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
+            if os.path.exists(pmc) and args.curve == "altbn128" and n == 1 << 16:
+                out["roofline"]["traffic"] = json.load(open(pmc))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cid, keys, msgs, sigs, n, fp, lib)
         print(json.dumps(out), flush=True)

@@ -27,7 +27,7 @@ struct Coop {
   static constexpr int S2 = 2 * C::L;        // dwords per Fp2
   static constexpr int RB = 0;               // [6][2] Fp2: coefficient k -> {e_k, xi*e_k}
   static constexpr int RL = 12 * S2;         // [6][3] Fp2 line coefficients / [6] plain operand
-  static constexpr int PAD = 16;             // keeps the groups of a wave on different LDS banks
+  static constexpr int PAD = 0;
   static constexpr int GROUP_DW = 30 * S2 + PAD;
   static constexpr int GROUPS = 10;
   static constexpr int WAVE_BYTES = GROUPS * GROUP_DW * 4;
@@ -50,41 +50,23 @@ __device__ __constant__ const int COOP_SH6[6] = {0, 1, 2, 3, 4, 5};
 __device__ __constant__ const int COOP_SH_D[3] = {0, 1, 3};   // D-type line: e0 + e1 w + e3 w^3
 __device__ __constant__ const int COOP_SH_M[3] = {0, 2, 3};   // M-type line: e0 + e2 w^2 + e3 w^3
 
-// A region holds NENT Fp2 entries CHUNK-MAJOR: the c-th 16-byte chunk of every entry is contiguous
-// (address = base + c*NENT*4 + entry*4 dwords).  The six lanes of a group read six different
-// entries with one ds_read_b128 each, which then fall into adjacent 16-byte slots instead of the
-// same banks (entry-major slots are 64 B / 96 B apart: a 3-way .. 10-way conflict, measured 27
-// conflict cycles per LDS instruction before this layout).
+// A region is an array of Fp2 entries, entry-major (each entry 2L contiguous dwords, read with
+// ds_read_b128).  A chunk-major variant (the c-th 16-byte chunk of all entries contiguous) was
+// measured: it removes no time at 2^16 and costs 45 % at 2^20, so the plain layout stays.
 struct LReg {
   int base, nent;
 };
 template <class C>
+__device__ __forceinline__ Fp2<C> lds_load_f2(int off);
+template <class C>
+__device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a);
+template <class C>
 __device__ __forceinline__ Fp2<C> lds_ld(LReg r, int e) {
-  extern __shared__ u32 lds[];
-  Fp2<C> o;
-  const int a = r.base + e * 4, st = r.nent * 4;
-#pragma unroll
-  for (int k = 0; k < C::L / 4; ++k) {
-    uint4 v = *reinterpret_cast<const uint4*>(lds + a + k * st);
-    o.c0.v[4 * k] = v.x; o.c0.v[4 * k + 1] = v.y; o.c0.v[4 * k + 2] = v.z; o.c0.v[4 * k + 3] = v.w;
-  }
-#pragma unroll
-  for (int k = 0; k < C::L / 4; ++k) {
-    uint4 v = *reinterpret_cast<const uint4*>(lds + a + (C::L / 4 + k) * st);
-    o.c1.v[4 * k] = v.x; o.c1.v[4 * k + 1] = v.y; o.c1.v[4 * k + 2] = v.z; o.c1.v[4 * k + 3] = v.w;
-  }
-  return o;
+  return lds_load_f2<C>(r.base + e * 2 * C::L);
 }
 template <class C>
 __device__ __forceinline__ void lds_st(LReg r, int e, const Fp2<C>& x) {
-  extern __shared__ u32 lds[];
-  const int a = r.base + e * 4, st = r.nent * 4;
-#pragma unroll
-  for (int k = 0; k < C::L / 4; ++k)
-    *reinterpret_cast<uint4*>(lds + a + k * st) = make_uint4(x.c0.v[4 * k], x.c0.v[4 * k + 1], x.c0.v[4 * k + 2], x.c0.v[4 * k + 3]);
-#pragma unroll
-  for (int k = 0; k < C::L / 4; ++k)
-    *reinterpret_cast<uint4*>(lds + a + (C::L / 4 + k) * st) = make_uint4(x.c1.v[4 * k], x.c1.v[4 * k + 1], x.c1.v[4 * k + 2], x.c1.v[4 * k + 3]);
+  lds_store_f2<C>(r.base + e * 2 * C::L, x);
 }
 template <class C>
 __device__ __forceinline__ LReg reg_rb(int gb) { return {gb + Coop<C>::RB, 12}; }

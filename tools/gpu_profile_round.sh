@@ -14,3 +14,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU 
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d $O/pmc_lds -o $R -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_lds.log 2>&1
 find $O -name "*.csv" | head -30
 du -sh $O
+python bench.py --workload multisig --n 1048576 --steps 5 --warmup 2 > $O/bench_multisig_altbn128_1M.json 2> $O/bench_multisig.err; tail -c 400 $O/bench_multisig_altbn128_1M.json
+python bench.py --n 1048576 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_altbn128_1M.json 2>/dev/null
+python bench.py --curve bls12 --n 1048576 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_bls12_1M.json 2>/dev/null
