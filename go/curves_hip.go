@@ -1,0 +1,264 @@
+// Copyright (C) 2018 Authors
+// distributed under Apache 2.0 license
+//
+// curves_hip.go -- cgo binding of the MI355X engine (include/bgls_hip.h) behind the reference's
+// CurveSystem / Point / PointT interfaces (curves/curve.go:12-70).  Lives INSIDE package curves
+// because CurveSystem has unexported methods (curves/curve.go:38-44).
+//
+// NOT COMPILED IN THE BUILD CONTAINER (no Go toolchain there); written against the C ABI that is
+// tested through ctypes.  Build:  CGO_CFLAGS=-I$REPO/include CGO_LDFLAGS="-L$REPO/bgls_amd -lbgls_hip" go build ./...
+package curves
+
+/*
+#cgo LDFLAGS: -lbgls_hip
+#include <stdlib.h>
+#include "bgls_hip.h"
+*/
+import "C"
+
+import (
+	"bytes"
+	"math/big"
+	"unsafe"
+)
+
+type hipCurve struct {
+	id   C.int
+	name string
+	base CurveSystem // the pure-Go curve: constants and the big.Int helpers only, never pairings
+}
+
+// AltbnHip / Bls12Hip are drop-in replacements for curves.Altbn128 / curves.Bls12.
+var AltbnHip = &hipCurve{C.BGLS_CURVE_ALTBN128, "altbn128", Altbn128}
+var Bls12Hip = &hipCurve{C.BGLS_CURVE_BLS12_381, "bls12", Bls12}
+
+type hipPoint struct {
+	c     *hipCurve
+	group C.int  // C.BGLS_G1 or C.BGLS_G2
+	raw   []byte // uncompressed wire bytes, the reference's own format
+}
+type hipPointT struct {
+	c   *hipCurve
+	raw []byte
+}
+
+func p(b []byte) *C.uint8_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
+}
+
+func (c *hipCurve) size(group C.int) int {
+	if group == C.BGLS_G1 {
+		return int(C.bgls_g1_size(c.id))
+	}
+	return int(C.bgls_g2_size(c.id))
+}
+
+// ---- Point (curves/curve.go:51-59) -------------------------------------------------------
+func (pt *hipPoint) Add(o Point) (Point, bool) {
+	q, ok := o.(*hipPoint)
+	if !ok || q.c != pt.c || q.group != pt.group {
+		return nil, false
+	}
+	out := make([]byte, len(pt.raw))
+	if C.bgls_point_add(pt.c.id, pt.group, p(pt.raw), p(q.raw), p(out)) != 0 {
+		return nil, false
+	}
+	return &hipPoint{pt.c, pt.group, out}, true
+}
+func (pt *hipPoint) Copy() Point { return &hipPoint{pt.c, pt.group, append([]byte(nil), pt.raw...)} }
+func (pt *hipPoint) Equals(o Point) bool {
+	q, ok := o.(*hipPoint)
+	return ok && q.c == pt.c && q.group == pt.group && bytes.Equal(q.raw, pt.raw)
+}
+func (pt *hipPoint) MarshalUncompressed() []byte { return append([]byte(nil), pt.raw...) }
+func (pt *hipPoint) Marshal() []byte             { return pt.MarshalUncompressed() } // compressed forms: SURVEY 8f-2
+func (pt *hipPoint) Mul(k *big.Int) Point {
+	sign := []byte{0}
+	mag := new(big.Int).Set(k) // the caller's scalar is never mutated (unlike curves/bls12_381.go:70)
+	if k.Sign() < 0 {
+		sign[0] = 1
+		mag.Neg(mag)
+	}
+	sc := make([]byte, 32)
+	mag.FillBytes(sc)
+	out := make([]byte, len(pt.raw))
+	if C.bgls_scale_points(pt.c.id, pt.group, p(pt.raw), p(sc), p(sign), 1, p(out)) != 0 {
+		return nil
+	}
+	return &hipPoint{pt.c, pt.group, out}
+}
+func (pt *hipPoint) ToAffineCoords() []*big.Int {
+	n := int(C.bgls_fp_size(pt.c.id))
+	r := make([]*big.Int, len(pt.raw)/n)
+	for i := range r {
+		r[i] = new(big.Int).SetBytes(pt.raw[i*n : (i+1)*n])
+	}
+	return r
+}
+
+// ---- PointT (curves/curve.go:62-70) ------------------------------------------------------
+func (t hipPointT) Add(o PointT) (PointT, bool) {
+	q, ok := o.(hipPointT)
+	if !ok || q.c != t.c {
+		return nil, false
+	}
+	out := make([]byte, len(t.raw))
+	if C.bgls_gt_mul(t.c.id, p(t.raw), p(q.raw), p(out)) != 0 {
+		return nil, false
+	}
+	return hipPointT{t.c, out}, true
+}
+func (t hipPointT) Copy() PointT    { return hipPointT{t.c, append([]byte(nil), t.raw...)} }
+func (t hipPointT) Marshal() []byte { return append([]byte(nil), t.raw...) }
+func (t hipPointT) Equals(o PointT) bool {
+	q, ok := o.(hipPointT)
+	return ok && bytes.Equal(q.raw, t.raw)
+}
+func (t hipPointT) Mul(k *big.Int) PointT { panic("GT exponentiation: not on the verify path (SURVEY 8f)") }
+
+// ---- CurveSystem (curves/curve.go:12-49) -------------------------------------------------
+func (c *hipCurve) Name() string { return c.name }
+
+func (c *hipCurve) unmarshal(group C.int, data []byte) (Point, bool) {
+	if len(data) != c.size(group) || C.bgls_point_check(c.id, group, p(data)) != 1 {
+		return nil, false
+	}
+	return &hipPoint{c, group, append([]byte(nil), data...)}, true
+}
+func (c *hipCurve) UnmarshalG1(d []byte) (Point, bool) { return c.unmarshal(C.BGLS_G1, d) }
+func (c *hipCurve) UnmarshalG2(d []byte) (Point, bool) { return c.unmarshal(C.BGLS_G2, d) }
+func (c *hipCurve) UnmarshalGT(d []byte) (PointT, bool) {
+	if len(d) != int(C.bgls_gt_size(c.id)) {
+		return nil, false
+	}
+	return hipPointT{c, append([]byte(nil), d...)}, true
+}
+func (c *hipCurve) makePoint(group C.int, coords []*big.Int) (Point, bool) {
+	n := int(C.bgls_fp_size(c.id))
+	if len(coords)*n != c.size(group) {
+		return nil, false
+	}
+	raw := make([]byte, len(coords)*n)
+	for i, v := range coords {
+		if v.Sign() < 0 || v.BitLen() > 8*n {
+			return nil, false
+		}
+		v.FillBytes(raw[i*n : (i+1)*n])
+	}
+	return c.unmarshal(group, raw)
+}
+func (c *hipCurve) MakeG1Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G1, co) }
+func (c *hipCurve) MakeG2Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G2, co) }
+
+func (c *hipCurve) gen(group C.int) Point {
+	out := make([]byte, c.size(group))
+	C.bgls_generator(c.id, group, p(out))
+	return &hipPoint{c, group, out}
+}
+func (c *hipCurve) GetG1() Point         { return c.gen(C.BGLS_G1) }
+func (c *hipCurve) GetG2() Point         { return c.gen(C.BGLS_G2) }
+func (c *hipCurve) GetG1Infinity() Point { return &hipPoint{c, C.BGLS_G1, make([]byte, c.size(C.BGLS_G1))} }
+func (c *hipCurve) GetG2Infinity() Point { return &hipPoint{c, C.BGLS_G2, make([]byte, c.size(C.BGLS_G2))} }
+func (c *hipCurve) GetGT() PointT        { t, _ := c.Pair(c.GetG1(), c.GetG2()); return t }
+func (c *hipCurve) GetGTIdentity() PointT {
+	out := make([]byte, int(C.bgls_gt_size(c.id)))
+	C.bgls_gt_identity(c.id, p(out))
+	return hipPointT{c, out}
+}
+
+func (c *hipCurve) HashToG1(message []byte) Point {
+	off := []C.uint64_t{0, C.uint64_t(len(message))}
+	out := make([]byte, c.size(C.BGLS_G1))
+	if C.bgls_hash_to_g1(c.id, p(message), &off[0], 1, p(out)) != 0 {
+		return nil
+	}
+	return &hipPoint{c, C.BGLS_G1, out}
+}
+
+func (c *hipCurve) Pair(a Point, b Point) (PointT, bool) {
+	return c.PairingProduct([]Point{a}, []Point{b})
+}
+
+// PairingProduct routes the whole slice through ONE C call instead of concurrentPairingProduct
+// (curves/curve.go:125-170).
+func (c *hipCurve) PairingProduct(p1 []Point, p2 []Point) (PointT, bool) {
+	if len(p1) != len(p2) {
+		return nil, false
+	}
+	g1 := make([]byte, 0, len(p1)*c.size(C.BGLS_G1))
+	g2 := make([]byte, 0, len(p2)*c.size(C.BGLS_G2))
+	for i := range p1 {
+		a, ok1 := p1[i].(*hipPoint)
+		b, ok2 := p2[i].(*hipPoint)
+		if !ok1 || !ok2 || a.c != c || b.c != c || a.group != C.BGLS_G1 || b.group != C.BGLS_G2 {
+			return nil, false
+		}
+		g1 = append(g1, a.raw...)
+		g2 = append(g2, b.raw...)
+	}
+	out := make([]byte, int(C.bgls_gt_size(c.id)))
+	if C.bgls_pairing_product(c.id, p(g1), p(g2), C.size_t(len(p1)), p(out)) != 0 {
+		return nil, false
+	}
+	return hipPointT{c, out}, true
+}
+
+func (c *hipCurve) GetG1Q() *big.Int                     { return c.base.GetG1Q() }
+func (c *hipCurve) GetG1Order() *big.Int                 { return c.base.GetG1Order() }
+func (c *hipCurve) getG1Cofactor() *big.Int              { return c.base.getG1Cofactor() }
+func (c *hipCurve) getG1A() *big.Int                     { return c.base.getG1A() }
+func (c *hipCurve) getG1B() *big.Int                     { return c.base.getG1B() }
+func (c *hipCurve) getFTHashParams() (*big.Int, *big.Int) { return c.base.getFTHashParams() }
+func (c *hipCurve) g1XToYSquared(x *big.Int) *big.Int    { return c.base.g1XToYSquared(x) }
+
+// ---- batch fast paths used by package bgls (one cgo call each) ---------------------------
+
+// HipVerifyAggregate is what bgls.verifyAggSig (bgls/bgls.go:94-119) calls when curve is a *hipCurve.
+func HipVerifyAggregate(curve CurveSystem, aggsig Point, keys []Point, msgs [][]byte, allowDuplicates bool) bool {
+	c, ok := curve.(*hipCurve)
+	s, ok2 := aggsig.(*hipPoint)
+	if !ok || !ok2 || len(keys) != len(msgs) {
+		return false
+	}
+	kb := make([]byte, 0, len(keys)*c.size(C.BGLS_G2))
+	for _, k := range keys {
+		q, ok := k.(*hipPoint)
+		if !ok || q.group != C.BGLS_G2 {
+			return false
+		}
+		kb = append(kb, q.raw...)
+	}
+	off := make([]C.uint64_t, len(msgs)+1)
+	var blob []byte
+	for i, m := range msgs {
+		off[i] = C.uint64_t(len(blob))
+		blob = append(blob, m...)
+	}
+	off[len(msgs)] = C.uint64_t(len(blob))
+	dup := C.int(0)
+	if allowDuplicates {
+		dup = 1
+	}
+	return C.bgls_verify_aggregate(c.id, p(s.raw), p(kb), p(blob), &off[0], C.size_t(len(keys)), dup) == 1
+}
+
+// HipVerifyMulti is bgls.verifyMultiSignature (bgls/bgls.go:89-92) in one call.
+func HipVerifyMulti(curve CurveSystem, aggsig Point, keys []Point, msg []byte) bool {
+	c, ok := curve.(*hipCurve)
+	s, ok2 := aggsig.(*hipPoint)
+	if !ok || !ok2 {
+		return false
+	}
+	kb := make([]byte, 0, len(keys)*c.size(C.BGLS_G2))
+	for _, k := range keys {
+		q, ok := k.(*hipPoint)
+		if !ok || q.group != C.BGLS_G2 {
+			return false
+		}
+		kb = append(kb, q.raw...)
+	}
+	return C.bgls_verify_multi(c.id, p(s.raw), p(kb), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
+}
