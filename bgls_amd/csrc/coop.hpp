@@ -204,6 +204,33 @@ __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<
   wave_sync();
 }
 
+// Emitter for dbl_step_emit / add_step_emit: scales LineCoeffs slot `which` by yP / xP and stores it as the
+// matching entry of RL[j] (D-type: c0 yP, c1 xP, c2;  M-type: c2, c1 xP, c0 yP).
+template <class C>
+struct LineEmitter {
+  LReg r;
+  int j;
+  const Fp<C>& xP;
+  const Fp<C>& yP;
+  bool valid, live;
+  __device__ __forceinline__ void operator()(int which, const Fp2<C>& v) const {
+    Fp2<C> e;
+    int entry;
+    if (which == 0) {
+      e = f2ms<C, true>(v, yP);
+      entry = C::TWIST_D ? 0 : 2;
+    } else if (which == 1) {
+      e = f2ms<C, true>(v, xP);
+      entry = 1;
+    } else {
+      e = v;
+      entry = C::TWIST_D ? 2 : 0;
+    }
+    if (!valid) e = (entry == 0) ? f2_one<C>() : f2_zero<C>();
+    if (live) lds_st<C>(r, 3 * j + entry, e);
+  }
+};
+
 // fold the six published lines into f (f in RB on entry and on exit; returns this lane's coefficient)
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_apply_lines(int gb, int j, bool live, int rl = Coop<C>::RL) {

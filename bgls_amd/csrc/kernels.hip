@@ -472,14 +472,24 @@ __global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, con
       int buf = 0;
 #pragma unroll 1
       for (int i = 1; i < C::LOOP_LEN; ++i) {
-        LineCoeffs<C> l = dbl_step_t<C, STEP_INL>(T);
-        coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+        if constexpr (STEP_INL) {
+          dbl_step_emit<C>(T, LineEmitter<C>{reg_rl<C>(gb, buf ? K::RL2 : K::RL), j, P.x, P.y, valid, live});
+          wave_sync();
+        } else {
+          LineCoeffs<C> l = dbl_step_t<C, false>(T);
+          coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+        }
         __syncthreads();
         buf ^= 1;
         const int d = C::LOOP_NAF[i];
         if (d != 0) {
-          l = add_step_t<C, STEP_INL>(T, Q.x, d > 0 ? Q.y : nyq);
-          coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+          if constexpr (STEP_INL) {
+            add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C>{reg_rl<C>(gb, buf ? K::RL2 : K::RL), j, P.x, P.y, valid, live});
+            wave_sync();
+          } else {
+            LineCoeffs<C> l = add_step_t<C, false>(T, Q.x, d > 0 ? Q.y : nyq);
+            coop_write_line<C>(gb, j, l, P.x, P.y, valid, live, buf ? K::RL2 : K::RL);
+          }
           __syncthreads();
           buf ^= 1;
         }
@@ -909,16 +919,16 @@ struct Engine {
           return (unsigned)(b > 8192 ? 8192 : b);
         };
         const double N = (double)n;
-        // (lanes per message, first counter): 1@0, 1@1, 2@2, 4@4, 16@8, 64@24, 64@88, 64@152, 64@216
+        // (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.
+        // Each round costs one try of latency, so the schedule is short: after three rounds a message is
+        // still unfinished with probability 2^-37.
         k_h2c_bn_round<1><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, d_flags);
-        k_h2c_bn_round<1><<<grid(N / 2, 1), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, d_flags);
-        k_h2c_bn_round<2><<<grid(N / 4, 2), 64, 0, st>>>(mv, n, L1, cn + 2, 2, L0, cn + 3, 0, out, d_flags);
-        k_h2c_bn_round<4><<<grid(N / 16, 4), 64, 0, st>>>(mv, n, L0, cn + 3, 4, L1, cn + 4, 0, out, d_flags);
-        k_h2c_bn_round<16><<<grid(N / 256, 16), 64, 0, st>>>(mv, n, L1, cn + 4, 8, L0, cn + 5, 0, out, d_flags);
-        k_h2c_bn_round<64><<<grid(N / 16777216, 64), 64, 0, st>>>(mv, n, L0, cn + 5, 24, L1, cn + 6, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 88, L0, cn + 7, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 7, 152, L1, cn + 8, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 8, 216, L0, cn + 9, 1, out, d_flags);
+        k_h2c_bn_round<4><<<grid(N / 2, 4), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, d_flags);
+        k_h2c_bn_round<32><<<grid(N / 32, 32), 64, 0, st>>>(mv, n, L1, cn + 2, 5, L0, cn + 3, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 3, 37, L1, cn + 4, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 4, 101, L0, cn + 5, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 5, 165, L1, cn + 6, 0, out, d_flags);
+        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 229, L0, cn + 7, 1, out, d_flags);
         HIPCHK(hipGetLastError());
         return 0;
       }

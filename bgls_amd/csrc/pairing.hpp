@@ -89,6 +89,42 @@ BGLS_HD LineCoeffs<C> add_step_t(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& y
   return {la, f2_neg<C>(th), j};
 }
 
+// Register-lean forms for the producer wave: values are consumed as early as possible and each line
+// coefficient is handed to `emit(slot, value)` the moment it exists (slot 0/1/2 = c0, c1, c2 of LineCoeffs),
+// so at most five Fp2 temporaries are live next to the running point.
+template <class C, class Emit>
+BGLS_HD void dbl_step_emit(G2Proj<C>& R, Emit&& emit) {
+  const Fp<C> half = fp_load<C>(C::HALF);
+  Fp2<C> B = f2_sqr_inl<C>(R.Y);
+  Fp2<C> Cc = f2_sqr_inl<C>(R.Z);
+  Fp2<C> H = f2_sub<C>(f2_sqr_inl<C>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
+  Fp2<C> E = f2_mul_inl<C>(Fp2<C>{fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)}, Cc);
+  emit(2, f2_sub<C>(E, B));
+  emit(0, f2_neg<C>(H));
+  emit(1, f2_mul3<C>(f2_sqr_inl<C>(R.X)));
+  Fp2<C> A = f2ms<C, true>(f2_mul_inl<C>(R.X, R.Y), half);
+  R.Z = f2_mul_inl<C>(B, H);
+  Fp2<C> Fv = f2_mul3<C>(E);
+  R.X = f2_mul_inl<C>(A, f2_sub<C>(B, Fv));
+  Fp2<C> G = f2ms<C, true>(f2_add<C>(B, Fv), half);
+  R.Y = f2_sub<C>(f2_sqr_inl<C>(G), f2_mul3<C>(f2_sqr_inl<C>(E)));
+}
+template <class C, class Emit>
+BGLS_HD void add_step_emit(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq, Emit&& emit) {
+  Fp2<C> th = f2_sub<C>(R.Y, f2_mul_inl<C>(yq, R.Z));
+  Fp2<C> la = f2_sub<C>(R.X, f2_mul_inl<C>(xq, R.Z));
+  emit(2, f2_sub<C>(f2_mul_inl<C>(th, xq), f2_mul_inl<C>(la, yq)));
+  emit(0, la);
+  emit(1, f2_neg<C>(th));
+  Fp2<C> D = f2_sqr_inl<C>(la);
+  Fp2<C> G = f2_mul_inl<C>(R.X, D);
+  Fp2<C> E = f2_mul_inl<C>(la, D);
+  Fp2<C> Hh = f2_sub<C>(f2_add<C>(E, f2_mul_inl<C>(R.Z, f2_sqr_inl<C>(th))), f2_dbl<C>(G));
+  R.X = f2_mul_inl<C>(la, Hh);
+  R.Z = f2_mul_inl<C>(R.Z, E);
+  R.Y = f2_sub<C>(f2_mul_inl<C>(th, f2_sub<C>(G, Hh)), f2_mul_inl<C>(E, R.Y));
+}
+
 template <class C>
 BGLS_FN LineCoeffs<C> dbl_step(G2Proj<C>& R) {
   return dbl_step_t<C, false>(R);

@@ -216,6 +216,9 @@ func (c *hipCurve) g1XToYSquared(x *big.Int) *big.Int    { return c.base.g1XToYS
 
 // ---- batch fast paths used by package bgls (one cgo call each) ---------------------------
 
+// IsHip reports whether curve is backed by the HIP engine.
+func IsHip(curve CurveSystem) bool { _, ok := curve.(*hipCurve); return ok }
+
 // HipVerifyAggregate is what bgls.verifyAggSig (bgls/bgls.go:94-119) calls when curve is a *hipCurve.
 func HipVerifyAggregate(curve CurveSystem, aggsig Point, keys []Point, msgs [][]byte, allowDuplicates bool) bool {
 	c, ok := curve.(*hipCurve)
