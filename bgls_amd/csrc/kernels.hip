@@ -949,7 +949,7 @@ struct Engine {
     void *pa, *pb;
     int rc;
     if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-    if ((rc = c.get(WS_F_B, (groups / 16 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
       Scope sc(c, st, ST_MILLER);
       // producer/consumer pairs double the wave count: worth it while all blocks stay resident
@@ -966,7 +966,7 @@ struct Engine {
     Scope sc(c, st, ST_REDUCE);
     Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;
     size_t cnt = groups;
-    const int R = 16;
+    const int R = 4;                       // each pass costs R-1 dependent products of latency: keep the tree shallow per pass
     while (cnt > 1) {
       size_t nout = (cnt + R - 1) / R;
       k_reduce_coop<C><<<nblk(nout, K::GROUPS), 64, K::WAVE_BYTES, st>>>(a, cnt, R, b);
