@@ -53,58 +53,173 @@ __device__ __forceinline__ void fe_put(int slot, int k, const Fp2<C>& v) {
   lds_store_f2<C>(FE<C>::coef(slot, k, 1), f2_mulxi<C>(v));
 }
 
-// dst <- a * b   (all 64 lanes must call; lanes >= 36 idle)
+// xi * c for a value whose real part sits on an even lane and imaginary part on the next lane:
+// returns this lane's half of xi*(re + i im) (re-lane: XI_RE*re - im, im-lane: XI_RE*im + re).
 template <class C>
-__device__ __noinline__ void fe_mul(int dst, int a, int b) {
+__device__ __forceinline__ Fp<C> mulxi_half(const Fp<C>& mine, bool is_im) {
+  Fp<C> other;
+#pragma unroll
+  for (int q = 0; q < C::L; ++q) other.v[q] = __shfl_xor(mine.v[q], 1);
+  Fp<C> m = mine;
+  if constexpr (C::XI_RE == 9) {
+    m = fp_dbl<C>(fp_dbl<C>(fp_dbl<C>(mine)));
+    m = fp_add<C>(m, mine);
+  }
+  return fp_select<C>(is_im, fp_add<C>(m, other), fp_sub<C>(m, other));
+}
+
+// dst <- a * b   (all 64 lanes must call; lanes >= 36 idle).  A = a (plain coefficients only), B = b (needs
+// its xi variants).  lane 6j+t: term t of coefficient j.  The six partial triples (a0 b0, a1 b1,
+// (a0+a1)(b0+b1)) of a coefficient are summed as a two-level tree through LDS: lanes t<3 absorb lane t+3,
+// then lane t=0 finishes the real part and lane t=1 the imaginary part -- the SAME instruction stream on
+// both (operand selects, no divergent branches: a lone wave pays every dependent carry chain in full).
+// want_xi = false skips the xi variants of the result (enough when it is only squared or used as A next).
+template <class C>
+__device__ __noinline__ void fe_mul(int dst, int a, int b, bool want_xi = true) {
   typedef FE<C> E;
   constexpr int W = E::W;
   extern __shared__ u32 lds[];
   const int lane = threadIdx.x & 63;
   const int j = lane / 6, t = lane % 6;
-  if (lane < 36) {
+  const bool act = lane < 36;
+  const int o = E::SCR + lane * 3 * W;
+  u32 v0[W], v1[W], s[W], tmp[W];
+  if (act) {
     int k = j - t;
     const int wrap = k < 0 ? 1 : 0;
     k += 6 * wrap;
     Fp2<C> x = lds_load_f2<C>(E::coef(a, t, 0));
     Fp2<C> y = lds_load_f2<C>(E::coef(b, k, wrap));
-    u32 tmp[W];
-    const int o = E::SCR + lane * 3 * W;
-    mul_wide<C>(tmp, x.c0.v, y.c0.v);
-    lds_store_w<W>(o, tmp);
-    mul_wide<C>(tmp, x.c1.v, y.c1.v);
-    lds_store_w<W>(o + W, tmp);
+    mul_wide<C>(v0, x.c0.v, y.c0.v);
+    mul_wide<C>(v1, x.c1.v, y.c1.v);
     Fp<C> sa = fp_add_nr<C>(x.c0, x.c1), sb = fp_add_nr<C>(y.c0, y.c1);
-    mul_wide<C>(tmp, sa.v, sb.v);
-    lds_store_w<W>(o + 2 * W, tmp);
+    mul_wide<C>(s, sa.v, sb.v);
+    if (t >= 3) {
+      lds_store_w<W>(o, v0);
+      lds_store_w<W>(o + W, v1);
+      lds_store_w<W>(o + 2 * W, s);
+    }
   }
   wave_sync();
-  if (lane < 36 && t < 2) {
-    // t == 0: real part  sum v0 - sum v1 + 6 p^2 ;  t == 1: imaginary part  sum s - sum v0 - sum v1
-    u32 pos[W], neg[W], tmp[W];
-#pragma unroll
-    for (int q = 0; q < W; ++q) pos[q] = neg[q] = 0;
+  if (act && t < 3) {
+    const int po = o + 3 * 3 * W;          // partner lane t+3
+    lds_load_w<W>(tmp, po);
+    w_add<W>(v0, v0, tmp);
+    lds_load_w<W>(tmp, po + W);
+    w_add<W>(v1, v1, tmp);
+    lds_load_w<W>(tmp, po + 2 * W);
+    w_add<W>(s, s, tmp);
+    lds_store_w<W>(o, v0);
+    lds_store_w<W>(o + W, v1);
+    lds_store_w<W>(o + 2 * W, s);
+  }
+  wave_sync();
+  if (act && t < 2) {
     const int base = E::SCR + (6 * j) * 3 * W;
-#pragma unroll 1
-    for (int u = 0; u < 6; ++u) {
-      const int o = base + u * 3 * W;
-      lds_load_w<W>(tmp, o + (t == 0 ? 0 : 2 * W));
-      w_add<W>(pos, pos, tmp);
-      lds_load_w<W>(tmp, o + W);
-      w_add<W>(neg, neg, tmp);
-      if (t == 1) {
-        lds_load_w<W>(tmp, o);
-        w_add<W>(neg, neg, tmp);
-      }
+#pragma unroll
+    for (int r = 1; r <= 2; ++r) {          // the two other partial sums (own ones are still in registers)
+      int u = t + r;
+      u -= u >= 3 ? 3 : 0;
+      const int q = base + u * 3 * W;
+      lds_load_w<W>(tmp, q);
+      w_add<W>(v0, v0, tmp);
+      lds_load_w<W>(tmp, q + W);
+      w_add<W>(v1, v1, tmp);
+      lds_load_w<W>(tmp, q + 2 * W);
+      w_add<W>(s, s, tmp);
     }
-    if (t == 0) w_add<W>(pos, pos, C::P2W6);
-    w_sub<W>(pos, pos, neg);
-    Fp<C> r = redc_k<C, E::LAZY_K>(pos);
+    // uniform form R = X + K - V:  t == 0: (sum v0) + 6 p^2 - (sum v1)      t == 1: (sum s) + 0 - (sum v0 + sum v1)
+    const u32 m0 = t == 0 ? 0xFFFFFFFFu : 0u;
+    u32 X[W], V[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      X[q] = (v0[q] & m0) | (s[q] & ~m0);
+      tmp[q] = v0[q] & ~m0;
+    }
+    w_add<W>(V, v1, tmp);
+#pragma unroll
+    for (int q = 0; q < W; ++q) tmp[q] = C::P2W6[q] & m0;
+    w_add<W>(X, X, tmp);
+    w_sub<W>(X, X, V);
+    Fp<C> r = redc_k<C, E::LAZY_K>(X);
     u32* p = lds + E::coef(dst, j, 0) + (t == 0 ? 0 : C::L);
 #pragma unroll
     for (int q = 0; q < C::L; ++q) p[q] = r.v[q];
+    if (want_xi) {
+      Fp<C> z = mulxi_half<C>(r, t == 1);
+      u32* px = lds + E::coef(dst, j, 1) + (t == 0 ? 0 : C::L);
+#pragma unroll
+      for (int q = 0; q < C::L; ++q) px[q] = z.v[q];
+    }
   }
   wave_sync();
-  if (lane < 36 && t == 2) lds_store_f2<C>(E::coef(dst, j, 1), f2_mulxi<C>(lds_load_f2<C>(E::coef(dst, j, 0))));
+}
+
+// recompute the xi variants of a slot (after a chain of want_xi = false operations)
+template <class C>
+__device__ __forceinline__ void fe_fix_xi(int slot) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 6) lds_store_f2<C>(FE<C>::coef(slot, lane, 1), f2_mulxi<C>(lds_load_f2<C>(FE<C>::coef(slot, lane, 0))));
+  wave_sync();
+}
+
+// dst <- a^2 for a in the cyclotomic subgroup (Granger-Scott, as f12_cyclo_sqr in tower.hpp).
+// Nine Fp2 squarings -- the pairs (e_q, e_{q+3}), q = 0..2, give A^2, B^2, (A+B)^2 -- on 18 lanes (one Fp
+// product + one reduction each: real part (x0+x1)(x0-x1), imaginary part 2 x0 x1), then 12 lanes
+// assemble the six coefficients, real and imaginary halves side by side.  Uniform instruction stream.
+template <class C>
+__device__ __noinline__ void fe_cyclo_sqr(int dst, int a, bool want_xi = true) {
+  typedef FE<C> E;
+  constexpr int W = E::W, L = C::L;
+  extern __shared__ u32 lds[];
+  const int lane = threadIdx.x & 63;
+  if (lane < 18) {
+    const int sq = lane >> 1, part = lane & 1, q = sq / 3, which = sq % 3;
+    Fp2<C> x = lds_load_f2<C>(E::coef(a, q, 0)), y = lds_load_f2<C>(E::coef(a, q + 3, 0));
+    Fp2<C> in = which == 0 ? x : which == 1 ? y : f2_add<C>(x, y);
+    Fp<C> X = fp_select<C>(part == 1, in.c0, fp_add_nr<C>(in.c0, in.c1));
+    Fp<C> Y = fp_select<C>(part == 1, in.c1, fp_sub<C>(in.c0, in.c1));
+    u32 tw[W], t2[W];
+    mul_wide<C>(tw, X.v, Y.v);
+    const u32 md = part ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int k = 0; k < W; ++k) t2[k] = tw[k] & md;
+    w_add<W>(tw, tw, t2);                                   // imaginary part: 2 x0 x1
+    Fp<C> r = redc<C>(tw);
+    u32* p = lds + E::SCR + sq * E::S2 + part * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = r.v[k];
+  }
+  wave_sync();
+  if (lane < 12) {
+    const int k = lane >> 1;                                // output coefficient
+    const bool im = lane & 1;
+    // e0,e3 <- pair 0; e2,e5 <- pair 1; e1,e4 <- pair 2
+    const int q = (k == 0 || k == 3) ? 0 : (k == 2 || k == 5) ? 1 : 2;
+    const int off = im ? L : 0;
+    Fp<C> t0 = fp_load<C>(lds + E::SCR + (3 * q) * E::S2 + off);
+    Fp<C> t1 = fp_load<C>(lds + E::SCR + (3 * q + 1) * E::S2 + off);
+    Fp<C> t2 = fp_load<C>(lds + E::SCR + (3 * q + 2) * E::S2 + off);
+    Fp<C> z = fp_load<C>(lds + E::coef(a, k, 0) + off);
+    Fp<C> c1 = fp_sub<C>(fp_sub<C>(t2, t0), t1);            // c1 = (A+B)^2 - A^2 - B^2
+    const bool even = (k & 1) == 0;
+    Fp<C> m = mulxi_half<C>(fp_select<C>(even, t1, c1), im); // xi*t1 (even k) or xi*c1 (k == 1)
+    Fp<C> tt = even ? fp_add<C>(m, t0) : (k == 1 ? m : c1);  // c0 = xi t1 + t0 | xi c1 | c1
+    Fp<C> r = even ? fp_sub<C>(tt, z) : fp_add<C>(tt, z);
+    r = fp_add<C>(fp_dbl<C>(r), tt);                         // 3 tt -/+ 2 z
+    wave_sync();
+    u32* p = lds + E::coef(dst, k, 0) + off;
+#pragma unroll
+    for (int w = 0; w < L; ++w) p[w] = r.v[w];
+    if (want_xi) {
+      Fp<C> zx = mulxi_half<C>(r, im);
+      u32* px = lds + E::coef(dst, k, 1) + off;
+#pragma unroll
+      for (int w = 0; w < L; ++w) px[w] = zx.v[w];
+    }
+  } else {
+    wave_sync();
+  }
   wave_sync();
 }
 
@@ -155,9 +270,10 @@ __device__ __noinline__ void fe_pow(int dst, int a, const u32* e, int nbits) {
   if (lane < 6) fe_put<C>(dst, lane, lds_load_f2<C>(FE<C>::coef(a, lane, 0)));
   wave_sync();
   for (int i = nbits - 2; i >= 0; --i) {
-    fe_mul<C>(dst, dst, dst);
-    if ((e[i >> 5] >> (i & 31)) & 1u) fe_mul<C>(dst, dst, a);
+    fe_cyclo_sqr<C>(dst, dst, false);
+    if ((e[i >> 5] >> (i & 31)) & 1u) fe_mul<C>(dst, dst, a, false);
   }
+  fe_fix_xi<C>(dst);
 }
 
 // slot FE_F <- FE_F ^ ((p^12 - 1) / r)
@@ -190,18 +306,18 @@ __device__ __noinline__ void fe_final_exp() {
     fe_frob<C>(FE_T, FE_C, 1);
     fe_mul<C>(FE_Y6, FE_C, FE_T);
     fe_conj<C>(FE_Y6, FE_Y6);
-    fe_mul<C>(FE_T0, FE_Y6, FE_Y6);
+    fe_cyclo_sqr<C>(FE_T0, FE_Y6);
     fe_mul<C>(FE_T0, FE_T0, FE_Y4);
     fe_mul<C>(FE_T0, FE_T0, FE_Y5);
     fe_mul<C>(FE_T1, FE_Y3, FE_Y5);
     fe_mul<C>(FE_T1, FE_T1, FE_T0);
     fe_mul<C>(FE_T0, FE_T0, FE_Y2);
-    fe_mul<C>(FE_T1, FE_T1, FE_T1);
+    fe_cyclo_sqr<C>(FE_T1, FE_T1);
     fe_mul<C>(FE_T1, FE_T1, FE_T0);
-    fe_mul<C>(FE_T1, FE_T1, FE_T1);
+    fe_cyclo_sqr<C>(FE_T1, FE_T1);
     fe_mul<C>(FE_T0, FE_T1, FE_Y1);
     fe_mul<C>(FE_T1, FE_T1, FE_Y0);
-    fe_mul<C>(FE_T0, FE_T0, FE_T0);
+    fe_cyclo_sqr<C>(FE_T0, FE_T0);
     fe_mul<C>(FE_F, FE_T1, FE_T0);
   } else {
     // (p^4 - p^2 + 1)/r = c (x + p)(x^2 + p^2 - 1) + 1,  c = (x-1)^2/3,  x < 0

@@ -1,0 +1,78 @@
+// C++ host-side mirror of the reference's Go package `bgls` on the hot path (bgls/bgls.go,
+// bgls/blsKosk.go): same function names and semantics, each verification = ONE batch C call.
+#pragma once
+#include "curves.hpp"
+
+namespace bgls_go {   // "package bgls"; the name bgls:: is taken by the kernels' namespace
+
+using curves::Bytes;
+using curves::CurveSystem;
+using curves::Point;
+
+// bgls/bgls.go:40-43
+inline Point LoadPublicKey(const CurveSystem* curve, const Bytes& sk_be32) { return curve->GetG2().Mul(sk_be32); }
+// bgls/bgls.go:46-56
+inline Point Sign(const CurveSystem* curve, const Bytes& sk_be32, const Bytes& msg) { return curve->HashToG1(msg).Mul(sk_be32); }
+// bgls/blsKosk.go:73-77
+inline Point KoskSign(const CurveSystem* curve, const Bytes& sk_be32, const Bytes& msg) {
+  Bytes m(1, 1);
+  m.insert(m.end(), msg.begin(), msg.end());
+  return Sign(curve, sk_be32, m);
+}
+// bgls/bgls.go:123-131
+inline Point AggregateSignatures(const std::vector<Point>& sigs) { return curves::AggregatePoints(sigs); }
+inline Point AggregateKeys(const std::vector<Point>& keys) { return curves::AggregatePoints(keys); }
+
+// verifyAggSig, bgls/bgls.go:94-119
+inline bool verifyAggSig(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys,
+                         const std::vector<Bytes>& msgs, bool allowDuplicates) {
+  if (keys.size() != msgs.size()) return false;
+  if (aggsig.curve != curve || aggsig.group != BGLS_G1) return false;
+  Bytes kb, blob;
+  std::vector<uint64_t> off(msgs.size() + 1, 0);
+  for (size_t i = 0; i < keys.size(); ++i) {
+    if (keys[i].curve != curve || keys[i].group != BGLS_G2) return false;
+    kb.insert(kb.end(), keys[i].raw.begin(), keys[i].raw.end());
+    off[i] = blob.size();
+    blob.insert(blob.end(), msgs[i].begin(), msgs[i].end());
+  }
+  off[msgs.size()] = blob.size();
+  return bgls_verify_aggregate(curve->id, aggsig.raw.data(), kb.data(), blob.data(), off.data(), keys.size(), allowDuplicates ? 1 : 0) == 1;
+}
+// bgls/bgls.go:82-84
+inline bool VerifyAggregateSignature(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys,
+                                     const std::vector<Bytes>& msgs) {
+  return verifyAggSig(curve, aggsig, keys, msgs, false);
+}
+// bgls/blsKosk.go:100-106
+inline bool KoskVerifyAggregateSignature(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys,
+                                         const std::vector<Bytes>& msgs) {
+  std::vector<Bytes> m2;
+  for (const Bytes& m : msgs) {
+    Bytes x(1, 1);
+    x.insert(x.end(), m.begin(), m.end());
+    m2.push_back(x);
+  }
+  return verifyAggSig(curve, aggsig, keys, m2, true);
+}
+// verifyMultiSignature, bgls/bgls.go:89-92
+inline bool verifyMultiSignature(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys, const Bytes& msg) {
+  Bytes kb;
+  for (const Point& k : keys) {
+    if (k.curve != curve || k.group != BGLS_G2) return false;
+    kb.insert(kb.end(), k.raw.begin(), k.raw.end());
+  }
+  return bgls_verify_multi(curve->id, aggsig.raw.data(), kb.data(), keys.size(), msg.data(), msg.size()) == 1;
+}
+// bgls/bgls.go:59-70
+inline bool VerifySingleSignature(const CurveSystem* curve, const Point& sig, const Point& pubKey, const Bytes& msg) {
+  return verifyMultiSignature(curve, sig, {pubKey}, msg);
+}
+// bgls/blsKosk.go:117-120
+inline bool KoskVerifyMultiSignature(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys, const Bytes& msg) {
+  Bytes m(1, 1);
+  m.insert(m.end(), msg.begin(), msg.end());
+  return verifyMultiSignature(curve, aggsig, keys, m);
+}
+
+}  // namespace bgls_go

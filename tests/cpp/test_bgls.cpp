@@ -1,0 +1,72 @@
+// The reference's scheme tests through the C++ host mirror (include/bgls/*.hpp == Go packages
+// `curves` / `bgls` on this path): bgls/bgls_test.go:19-77 (TestSingleSigner, TestAggregation) and
+// bgls/blsKosk_test.go:35-64 (TestKoskMultiSig).  Built and run by tests/test_gpu_cpp_mirror.py.
+#include <cstdio>
+#include <random>
+#include "bgls/bgls.hpp"
+
+using namespace curves;
+using namespace bgls_go;
+
+static std::mt19937_64 rng(20260928);
+static Bytes randBytes(size_t n) { Bytes b(n); for (auto& x : b) x = (uint8_t)rng(); return b; }
+static Bytes randScalar() { Bytes b = randBytes(32); b[0] &= 0x0f; return b; }   // < 2^252 < order
+static int failures = 0;
+#define CHECK(cond, what) do { if (!(cond)) { std::printf("FAIL %s: %s\n", curve->Name().c_str(), what); ++failures; } } while (0)
+
+static void TestSingleSigner(const CurveSystem* curve) {
+  Bytes sk = randScalar(); Point vk = LoadPublicKey(curve, sk);
+  Bytes d = randBytes(64);
+  Point sig = Sign(curve, sk, d);
+  CHECK(VerifySingleSignature(curve, sig, vk, d), "Standard BLS signature verification failed");
+  auto sig2 = sig.Copy().Add(curve->GetG1());
+  CHECK(sig2.second && !VerifySingleSignature(curve, sig2.first, vk, d), "verification succeeding when it shouldn't");
+}
+
+static void TestAggregation(const CurveSystem* curve) {
+  const int N = 6, Size = 32;
+  std::vector<Bytes> msgs; std::vector<Point> sigs, pubkeys;
+  for (int i = 0; i < N; ++i) {
+    msgs.push_back(randBytes(Size));
+    Bytes sk = randScalar();
+    pubkeys.push_back(LoadPublicKey(curve, sk)); sigs.push_back(Sign(curve, sk, msgs[i]));
+  }
+  Point aggSig = AggregateSignatures(sigs);
+  CHECK(VerifyAggregateSignature(curve, aggSig, pubkeys, msgs), "Aggregate Point1 verification failed");
+  std::vector<Point> fewer(pubkeys.begin(), pubkeys.end() - 1);
+  CHECK(!VerifyAggregateSignature(curve, aggSig, fewer, msgs), "succeeding without enough pubkeys");
+  Bytes skf = randScalar();
+  std::vector<Point> pk2 = pubkeys, sg2 = sigs; std::vector<Bytes> m2 = msgs;
+  pk2.push_back(LoadPublicKey(curve, skf)); sg2.push_back(Sign(curve, skf, msgs[0])); m2.push_back(msgs[0]);
+  Point agg2 = AggregateSignatures(sg2);
+  CHECK(!VerifyAggregateSignature(curve, agg2, pk2, m2), "succeeding with duplicate messages");
+  CHECK(KoskVerifyAggregateSignature(curve, AggregateSignatures({KoskSign(curve, skf, msgs[0])}), {pk2.back()}, {msgs[0]}), "Kosk aggregate failed");
+  CHECK(!VerifyAggregateSignature(curve, agg2, pubkeys, msgs), "succeeding with invalid signature");
+  std::vector<Bytes> sw = msgs; sw[0] = msgs[1]; sw[1] = msgs[0];
+  CHECK(!VerifyAggregateSignature(curve, aggSig, pubkeys, sw), "succeeded with messages 0 and 1 switched");
+}
+
+static void TestKoskMultiSig(const CurveSystem* curve) {
+  const int Signers = 8;
+  Bytes msg = randBytes(32);
+  std::vector<Point> signers, sigs;
+  for (int j = 0; j < Signers; ++j) { Bytes sk = randScalar(); sigs.push_back(KoskSign(curve, sk, msg)); signers.push_back(LoadPublicKey(curve, sk)); }
+  Point aggsig = AggregateSignatures(sigs);
+  CHECK(KoskVerifyMultiSignature(curve, aggsig, signers, msg), "Aggregate MultiSig verification failed");
+  CHECK(!KoskVerifyMultiSignature(curve, aggsig, signers, randBytes(32)), "succeeded on incorrect msg");
+  Point aggkey = AggregateKeys(signers);
+  CHECK(KoskVerifyMultiSignature(curve, aggsig, {aggkey}, msg), "failed with the aggkey pre-aggregated");
+  signers[0] = LoadPublicKey(curve, randScalar());
+  CHECK(!KoskVerifyMultiSignature(curve, aggsig, signers, msg), "succeeded on incorrect signers");
+  auto bad = curve->PairingProduct({curve->GetG1()}, {curve->GetG2(), curve->GetG2()});
+  CHECK(!bad.second, "PairingProduct length mismatch must be (nil,false)");
+  auto idt = curve->Pair(curve->GetG1(), curve->GetG2Infinity());
+  CHECK(idt.second && idt.first.Equals(curve->GetGTIdentity()), "Pair(g1, inf) must be the GT identity");
+}
+
+int main() {
+  if (bgls_init(0) != 0) { std::printf("bgls_init: %s\n", bgls_last_error()); return 2; }
+  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); }
+  std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}
