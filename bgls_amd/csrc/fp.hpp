@@ -208,52 +208,6 @@ BGLS_HD void mul_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L], const u32 (&b)[C
   }
 }
 
-// Two independent products with their rows interleaved: the two carry chains alternate, so the
-// 2-wait-state gap gfx950 needs between dependent v_addc's is filled with the other chain's work
-// instead of s_nop.
-template <class C>
-BGLS_HD void mul_wide2(u32 (&t0)[2 * C::L], u32 (&t1)[2 * C::L], const u32 (&a0)[C::L], const u32 (&b0)[C::L],
-                       const u32 (&a1)[C::L], const u32 (&b1)[C::L]) {
-  constexpr int L = C::L;
-  {
-    u64 P[L], Q[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      P[j] = (u64)a0[j] * b0[0];
-      Q[j] = (u64)a1[j] * b1[0];
-    }
-    t0[0] = (u32)P[0];
-    t1[0] = (u32)Q[0];
-    u32 c0 = 0, c1 = 0;
-#pragma unroll
-    for (int j = 1; j < L; ++j) {
-      t0[j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c0);
-      t1[j] = addc((u32)Q[j], (u32)(Q[j - 1] >> 32), c1);
-    }
-    t0[L] = (u32)(P[L - 1] >> 32) + c0;
-    t1[L] = (u32)(Q[L - 1] >> 32) + c1;
-  }
-#pragma unroll
-  for (int i = 1; i < L; ++i) {
-    u64 P[L], Q[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      P[j] = (u64)a0[j] * b0[i] + t0[i + j];
-      Q[j] = (u64)a1[j] * b1[i] + t1[i + j];
-    }
-    t0[i] = (u32)P[0];
-    t1[i] = (u32)Q[0];
-    u32 c0 = 0, c1 = 0;
-#pragma unroll
-    for (int j = 1; j < L; ++j) {
-      t0[i + j] = addc((u32)P[j], (u32)(P[j - 1] >> 32), c0);
-      t1[i + j] = addc((u32)Q[j], (u32)(Q[j - 1] >> 32), c1);
-    }
-    t0[i + L] = (u32)(P[L - 1] >> 32) + c0;
-    t1[i + L] = (u32)(Q[L - 1] >> 32) + c1;
-  }
-}
-
 // t = a^2: off-diagonal products once, doubled, plus the diagonal.
 template <class C>
 BGLS_HD void sqr_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L]) {

@@ -37,18 +37,6 @@ __global__ void __launch_bounds__(64) mb_fpmul(Fp<C>* io, int iters) {      // i
   io[blockIdx.x * 64 + threadIdx.x] = a;
 }
 
-template <class C>
-__global__ void __launch_bounds__(64) mb_fpmul3(Fp<C>* io, int iters) {     // two interleaved mont mul chains
-  Fp<C> a0 = io[threadIdx.x], b0 = io[threadIdx.x + 64], a1 = io[threadIdx.x + 128], b1 = io[threadIdx.x + 192];
-  for (int i = 0; i < iters; ++i) {
-    u32 t0[2 * C::L], t1[2 * C::L];
-    mul_wide2<C>(t0, t1, a0.v, b0.v, a1.v, b1.v);
-    a0 = redc<C>(t0);
-    a1 = redc<C>(t1);
-  }
-  io[blockIdx.x * 64 + threadIdx.x] = fp_add<C>(a0, a1);
-}
-
 template <class F> float run(F launch, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   launch(); hipDeviceSynchronize();
@@ -64,10 +52,9 @@ template <class C> void suite(const char* name) {
     float t2 = run([&] { mb_step<C, 0><<<blocks, 64>>>((Fp2<C>*)buf, iters); }, 3);
     float t3 = run([&] { mb_step<C, 1><<<blocks, 64>>>((Fp2<C>*)buf, iters); }, 3);
     float t4 = run([&] { mb_fpmul<C><<<blocks, 64>>>((Fp<C>*)buf, 4096); }, 3);
-    float t5 = run([&] { mb_fpmul3<C><<<blocks, 64>>>((Fp<C>*)buf, 2048); }, 3);
     double macs = (double)blocks * 64 * 4096 * (2.0 * C::L * C::L + C::L);
-    printf("%s blocks=%5d  coop(sqr+6 lines)x64: %8.3f ms | dbl_step(calls)x64: %8.3f ms | dbl_step(inline)x64: %8.3f ms | fpmul x4096: %8.3f ms = %.2f TMAC/s | 2-way interleaved: %8.3f ms = %.2f TMAC/s\n",
-           name, blocks, t1, t2, t3, t4, macs / t4 / 1e9, t5, macs / t5 / 1e9);
+    printf("%s blocks=%5d  coop(sqr+6 lines)x64: %8.3f ms | dbl_step(calls)x64: %8.3f ms | dbl_step(inline)x64: %8.3f ms | fpmul x4096: %8.3f ms = %.2f TMAC/s\n",
+           name, blocks, t1, t2, t3, t4, macs / t4 / 1e9);
   }
   hipFree(buf);
 }
