@@ -134,6 +134,36 @@ inline BGLS_FN Aff<F1<BLS381>> bls_sw_encode(const Fp<BLS381>& t_mont, bool t_pa
   return {x, y, false};
 }
 
+// ---- staged form (one work item per (message, tag); candidates x0, x1, x2 tested in separate,
+// compacted rounds so that no lane waits for another lane's extra exponentiations) ----
+// kind of a per-tag contribution
+enum : u32 { H2C_INF = 0, H2C_PLUS_G1 = 1, H2C_MINUS_G1 = 2, H2C_SW = 3, H2C_PENDING = 4 };
+
+struct BlsSwPrep {
+  Fp<BLS381> x0, x2;   // candidates (x1 = -1 - x0)
+};
+// t (Montgomery) -> candidates; t must be non-degenerate
+inline BGLS_FN BlsSwPrep bls_sw_prep(const Fp<BLS381>& t_mont) {
+  typedef BLS381 C;
+  const Fp<C> one = fp_one<C>();
+  Fp<C> t2 = fp_sqr<C>(t_mont);
+  Fp<C> u = fp_add<C>(fp_add<C>(t2, one), fp_load<C>(C::B));
+  Fp<C> v = fp_mul3<C>(t2);
+  Fp<C> I = fp_inv<C>(fp_mul<C>(u, v));
+  Fp<C> w = fp_mul<C>(fp_mul<C>(fp_load<C>(C::SQRT_M3), t_mont), fp_mul<C>(I, v));
+  BlsSwPrep r;
+  r.x0 = fp_sub<C>(fp_load<C>(C::Z_SW), fp_mul<C>(t_mont, w));
+  r.x2 = fp_sub<C>(one, fp_mul<C>(fp_mul<C>(fp_sqr<C>(u), u), I));
+  return r;
+}
+// candidate test: y = (x^3+4)^((q+1)/4); ok iff y^2 == x^3+4 (0 counts as a square, hash.go:254-265)
+inline BGLS_FN bool bls_sw_try(const Fp<BLS381>& x, Fp<BLS381>& y) {
+  typedef BLS381 C;
+  Fp<C> g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), fp_load<C>(C::B));
+  y = fp_sqrt_candidate<C>(g);
+  return fp_eq<C>(fp_sqr<C>(y), g);
+}
+
 template <class F>
 BGLS_FN Jac<F> jac_mul_jac(const Jac<F>& p, const u32* k, int nbits) {
   Jac<F> r = jac_inf<F>();

@@ -137,6 +137,62 @@ __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const
   }
 }
 
+// ---- BLS12-381 hash-to-G1 as a staged pipeline (curves/bls12_381.go:361-393, curves/hash.go:86-167) ----
+// item = 2*message + tag.  STAGE 0 hashes, classifies t and tests candidate x0; STAGE 1 tests x1 = -1 - x0
+// on the items that failed; STAGE 2 takes x2 (always a square).  Failures are compacted into work lists, so
+// every lane of every round does exactly one square-root exponentiation.
+template <int STAGE>
+__global__ void __launch_bounds__(64) k_bls_sw(MsgView mv, size_t n_items, const uint32_t* list_in, const uint32_t* count_in,
+                                               uint32_t* list_out, uint32_t* count_out, Aff<F1<BLS381>>* pts, uint32_t* kinds) {
+  typedef BLS381 C;
+  const size_t count = count_in ? (size_t)*count_in : n_items;
+  for (size_t slot = (size_t)blockIdx.x * 64 + threadIdx.x; slot < count; slot += (size_t)gridDim.x * 64) {
+    const size_t item = list_in ? list_in[slot] : slot;
+    const size_t msg = item >> 1;
+    Fp<C> tm;
+    Fp<C> t = bls_h2c_t(mv.ptr(msg), mv.size(msg), (int)(item & 1), tm);
+    if (STAGE == 0) {
+      uint32_t kind = H2C_PENDING;
+      if (fp_is_zero<C>(t)) kind = H2C_INF;
+      else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) kind = H2C_PLUS_G1;
+      else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) kind = H2C_MINUS_G1;
+      if (kind != H2C_PENDING) {
+        kinds[item] = kind;
+        continue;
+      }
+    }
+    BlsSwPrep pr = bls_sw_prep(tm);
+    Fp<C> x = STAGE == 0 ? pr.x0 : STAGE == 1 ? fp_sub<C>(fp_neg<C>(pr.x0), fp_one<C>()) : pr.x2;
+    Fp<C> y;
+    const bool ok = bls_sw_try(x, y) || STAGE == 2;
+    if (ok) {
+      if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
+      pts[item] = {x, y, false};
+      kinds[item] = H2C_SW;
+    } else {
+      list_out[atomicAdd(count_out, 1u)] = (uint32_t)item;
+    }
+  }
+}
+
+// per message: h * (sw_0 + sw_1) + special contributions, to affine
+__global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+  typedef BLS381 C;
+  typedef F1<C> F;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac<F> sw = jac_inf<F>(), special = jac_inf<F>();
+  const Aff<F> g1 = {fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t kind = kinds[2 * i + k];
+    if (kind == H2C_SW) sw = jac_add_aff<F>(sw, pts[2 * i + k]);
+    else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
+    else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
+  }
+  Jac<F> r = jac_mul_jac<F>(sw, C::COFACTOR, C::COFACTOR_BITS);
+  out[i] = jac_to_aff<F>(jac_add<F>(r, special));
+}
+
 template <class C>
 __global__ void k_g1_to_bytes(const Aff<F1<C>>* in, size_t n, uint8_t* out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -850,7 +906,7 @@ struct Scope {  // brackets the launches of one stage with events when profiling
 };
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_NUM };
 
 inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -929,6 +985,31 @@ struct Engine {
         k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 4, 101, L0, cn + 5, 0, out, d_flags);
         k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 5, 165, L1, cn + 6, 0, out, d_flags);
         k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 229, L0, cn + 7, 1, out, d_flags);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
+    }
+    if constexpr (C::CURVE_ID == 1) {
+      if (use_coop() && n >= 256) {
+        void *lists, *cnts, *pts, *kinds;
+        int rc;
+        const size_t items = 2 * n;
+        if ((rc = c.get(WS_H2C_LIST, 2 * items * 4, &lists))) return rc;
+        if ((rc = c.get(WS_H2C_CNT, 64, &cnts))) return rc;
+        if ((rc = c.get(WS_H2C_PTS, items * sizeof(Aff<G1F>), &pts))) return rc;
+        if ((rc = c.get(WS_H2C_KIND, items * 4, &kinds))) return rc;
+        HIPCHK(hipMemsetAsync(cnts, 0, 64, st));
+        uint32_t* L0 = (uint32_t*)lists;
+        uint32_t* L1 = L0 + items;
+        uint32_t* cn = (uint32_t*)cnts;
+        auto grid = [&](size_t expect) {
+          size_t b = expect / 64 + 8;
+          return (unsigned)(b > 8192 ? 8192 : b);
+        };
+        k_bls_sw<0><<<grid(items), 64, 0, st>>>(mv, items, nullptr, nullptr, L0, cn + 1, (Aff<G1F>*)pts, (uint32_t*)kinds);
+        k_bls_sw<1><<<grid(items / 2 + items / 8), 64, 0, st>>>(mv, items, L0, cn + 1, L1, cn + 2, (Aff<G1F>*)pts, (uint32_t*)kinds);
+        k_bls_sw<2><<<grid(items / 4 + items / 8), 64, 0, st>>>(mv, items, L1, cn + 2, L0, cn + 3, (Aff<G1F>*)pts, (uint32_t*)kinds);
+        k_bls_combine<<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
         HIPCHK(hipGetLastError());
         return 0;
       }
