@@ -41,6 +41,26 @@ inline BGLS_FN bool bn_h2c_try(const uint8_t* msg, size_t len, u32 counter, Fp<B
   return fp_eq<C>(fp_sqr<C>(r), y2);
 }
 
+// Candidate test by Legendre symbol: returns true when x^3+3 is a square (or 0), with x and y2 = x^3+3.
+// Accepts exactly the candidates bn_h2c_try accepts; the square root is taken later, once.
+inline BGLS_FN bool bn_h2c_test(const uint8_t* msg, size_t len, u32 counter, Fp<BN254>& x, Fp<BN254>& y2) {
+  typedef BN254 C;
+  ByteSrc src;
+  src.msg = msg;
+  src.len = len;
+  src.pre[0] = (uint8_t)counter;
+  src.npre = 1;
+  src.nsuf = 0;
+  u32 d[8];
+  keccak256_legacy(src, d);
+  Fp<C> h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
+  x = fp_to_mont<C>(h);
+  y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), fp_load<C>(C::B));
+  return fp_jacobi<C>(y2) >= 0;
+}
+
 inline BGLS_FN u32 bn_h2c_sign(const uint8_t* msg, size_t len) {
   ByteSrc src;
   src.msg = msg;

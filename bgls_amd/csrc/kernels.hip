@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) k_h2c(MsgView mv, size_t n, Aff<F1<C>>* ou
 // LPM consecutive counters of every still-unfinished message on LPM adjacent lanes; the LOWEST
 // successful counter wins (= what the sequential loop would have found), failures are appended to
 // the next round's work list.  Counters 0..255 are covered by the fixed schedule in h2c_bn().
-template <int LPM>
+template <int LPM, bool JAC>
 __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const uint32_t* list_in, const uint32_t* count_in,
                                                      uint32_t c0, uint32_t* list_out, uint32_t* count_out, int last,
                                                      Aff<F1<BN254>>* out, uint32_t* flags) {
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const
     Fp<C> x, r;
     bool ok = false;
     if (item < count) idx = list_in ? list_in[item] : item;
-    if (active) ok = bn_h2c_try(mv.ptr(idx), mv.size(idx), c, x, r);
+    if (active) ok = JAC ? bn_h2c_test(mv.ptr(idx), mv.size(idx), c, x, r) : bn_h2c_try(mv.ptr(idx), mv.size(idx), c, x, r);
     const unsigned long long ball = __ballot(ok);
     const int seg = (lane / LPM) * LPM;
     const unsigned long long segmask = LPM == 64 ? ball : ((ball >> seg) & ((1ull << (LPM & 63)) - 1ull));
@@ -130,8 +130,8 @@ __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const
           }
         }
       } else if (sub == (uint32_t)__builtin_ctzll(segmask)) {
-        if (bn_h2c_sign(mv.ptr(idx), mv.size(idx))) r = fp_neg<C>(r);
-        out[idx] = {x, r, false};
+        if (!JAC && bn_h2c_sign(mv.ptr(idx), mv.size(idx))) r = fp_neg<C>(r);
+        out[idx] = {x, r, false};             // JAC: r holds x^3+3, k_h2c_bn_finish takes the root
       }
     }
   }
@@ -173,6 +173,83 @@ __global__ void __launch_bounds__(64) k_bls_sw(MsgView mv, size_t n_items, const
       list_out[atomicAdd(count_out, 1u)] = (uint32_t)item;
     }
   }
+}
+
+// second half of the Legendre-symbol rounds: y = sqrt(x^3+3) with the reference's sign rule, once per message
+__global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<F1<BN254>>* out) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p = out[i];
+  if (p.inf) return;
+  Fp<C> r = fp_sqrt_candidate<C>(p.y);
+  if (bn_h2c_sign(mv.ptr(i), mv.size(i))) r = fp_neg<C>(r);
+  out[i].y = r;
+}
+
+// alt-bn128 try-and-increment with the acceptance test done by the Legendre symbol (fp_jacobi): the lane
+// walks the counters with cheap tests only and pays ONE square-root exponentiation, for the accepted x.
+// Same accepted counter, same (x, y) as curves/hash.go:53-77.
+__global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* msg = mv.ptr(i);
+  const size_t len = mv.size(i);
+  Fp<C> x, y2;
+  bool found = false;
+  for (u32 c = 0; c < 256 && !found; ++c) {
+    ByteSrc src;
+    src.msg = msg; src.len = len; src.pre[0] = (uint8_t)c; src.npre = 1; src.nsuf = 0;
+    u32 d[8];
+    keccak256_legacy(src, d);
+    Fp<C> h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
+    x = fp_to_mont<C>(h);
+    y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), fp_load<C>(C::B));
+    found = fp_jacobi<C>(y2) >= 0;
+  }
+  if (!found) {
+    atomicOr(flags, FLAG_HASH);
+    out[i] = {fp_zero<C>(), fp_zero<C>(), true};
+    return;
+  }
+  Fp<C> r = fp_sqrt_candidate<C>(y2);
+  if (bn_h2c_sign(msg, len)) r = fp_neg<C>(r);
+  out[i] = {x, r, false};
+}
+
+// BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
+// curves/hash.go:254-265), then exactly one square-root exponentiation.
+__global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items, Aff<F1<BLS381>>* pts, uint32_t* kinds) {
+  typedef BLS381 C;
+  size_t item = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const size_t msg = item >> 1;
+  Fp<C> tm;
+  Fp<C> t = bls_h2c_t(mv.ptr(msg), mv.size(msg), (int)(item & 1), tm);
+  uint32_t kind = H2C_SW;
+  if (fp_is_zero<C>(t)) kind = H2C_INF;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) kind = H2C_PLUS_G1;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) kind = H2C_MINUS_G1;
+  kinds[item] = kind;
+  if (kind != H2C_SW) return;
+  BlsSwPrep pr = bls_sw_prep(tm);
+  const Fp<C> b = fp_load<C>(C::B);
+  Fp<C> x = pr.x0;
+  Fp<C> g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+  if (fp_jacobi<C>(g) < 0) {
+    x = fp_sub<C>(fp_neg<C>(pr.x0), fp_one<C>());
+    g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+    if (fp_jacobi<C>(g) < 0) {
+      x = pr.x2;
+      g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+    }
+  }
+  Fp<C> y = fp_sqrt_candidate<C>(g);
+  if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
+  pts[item] = {x, y, false};
 }
 
 // per message: h * (sw_0 + sw_1) + special contributions, to affine
@@ -884,6 +961,14 @@ int final_mode() {
   }();
   return v;
 }
+// BGLS_H2C=rounds selects the exponentiation-tested compacting rounds; default: Legendre-symbol tests.
+int h2c_mode() {
+  static const int v = [] {
+    const char* e = getenv("BGLS_H2C");
+    return (e && !strcmp(e, "rounds")) ? 1 : 0;
+  }();
+  return v;
+}
 bool use_coop() {
   static const bool v = [] {
     const char* e = getenv("BGLS_KERNELS");
@@ -960,6 +1045,11 @@ struct Engine {
 
   static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags) {
     if constexpr (C::CURVE_ID == 0) {
+      if (use_coop() && n < 256 && h2c_mode() == 0) {
+        k_h2c_bn_jacobi<<<nblk(n, 64), 64, 0, st>>>(mv, n, out, d_flags);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
       if (use_coop() && n >= 256) {
         void *lists, *cnts;
         int rc;
@@ -977,20 +1067,29 @@ struct Engine {
         const double N = (double)n;
         // (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.
         // Each round costs one try of latency, so the schedule is short: after three rounds a message is
-        // still unfinished with probability 2^-37.
-        k_h2c_bn_round<1><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, d_flags);
-        k_h2c_bn_round<4><<<grid(N / 2, 4), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, d_flags);
-        k_h2c_bn_round<32><<<grid(N / 32, 32), 64, 0, st>>>(mv, n, L1, cn + 2, 5, L0, cn + 3, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 3, 37, L1, cn + 4, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 4, 101, L0, cn + 5, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 5, 165, L1, cn + 6, 0, out, d_flags);
-        k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 229, L0, cn + 7, 1, out, d_flags);
+        // still unfinished with probability 2^-37.  Default test = Legendre symbol (JAC), square root once
+        // at the end; BGLS_H2C=rounds tests by exponentiation as the reference does.
+#define BGLS_ROUNDS(JAC)                                                                                                        \
+        k_h2c_bn_round<1, JAC><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, d_flags);           \
+        k_h2c_bn_round<4, JAC><<<grid(N / 2, 4), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, d_flags);              \
+        k_h2c_bn_round<32, JAC><<<grid(N / 32, 32), 64, 0, st>>>(mv, n, L1, cn + 2, 5, L0, cn + 3, 0, out, d_flags);           \
+        k_h2c_bn_round<64, JAC><<<8, 64, 0, st>>>(mv, n, L0, cn + 3, 37, L1, cn + 4, 0, out, d_flags);                         \
+        k_h2c_bn_round<64, JAC><<<8, 64, 0, st>>>(mv, n, L1, cn + 4, 101, L0, cn + 5, 0, out, d_flags);                        \
+        k_h2c_bn_round<64, JAC><<<8, 64, 0, st>>>(mv, n, L0, cn + 5, 165, L1, cn + 6, 0, out, d_flags);                        \
+        k_h2c_bn_round<64, JAC><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 229, L0, cn + 7, 1, out, d_flags);
+        if (h2c_mode() == 0) {
+          BGLS_ROUNDS(true)
+          k_h2c_bn_finish<<<nblk(n, 64), 64, 0, st>>>(mv, n, out);
+        } else {
+          BGLS_ROUNDS(false)
+        }
+#undef BGLS_ROUNDS
         HIPCHK(hipGetLastError());
         return 0;
       }
     }
     if constexpr (C::CURVE_ID == 1) {
-      if (use_coop() && n >= 256) {
+      if (use_coop() && (n >= 256 || h2c_mode() == 0)) {
         void *lists, *cnts, *pts, *kinds;
         int rc;
         const size_t items = 2 * n;
@@ -1006,6 +1105,12 @@ struct Engine {
           size_t b = expect / 64 + 8;
           return (unsigned)(b > 8192 ? 8192 : b);
         };
+        if (h2c_mode() == 0) {
+          k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, (Aff<G1F>*)pts, (uint32_t*)kinds);
+          k_bls_combine<<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
+          HIPCHK(hipGetLastError());
+          return 0;
+        }
         k_bls_sw<0><<<grid(items), 64, 0, st>>>(mv, items, nullptr, nullptr, L0, cn + 1, (Aff<G1F>*)pts, (uint32_t*)kinds);
         k_bls_sw<1><<<grid(items / 2 + items / 8), 64, 0, st>>>(mv, items, L0, cn + 1, L1, cn + 2, (Aff<G1F>*)pts, (uint32_t*)kinds);
         k_bls_sw<2><<<grid(items / 4 + items / 8), 64, 0, st>>>(mv, items, L1, cn + 2, L0, cn + 3, (Aff<G1F>*)pts, (uint32_t*)kinds);

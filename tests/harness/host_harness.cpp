@@ -19,6 +19,8 @@ static int fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 4: r = fp_neg<C>(x); break;
     case 5: r = fp_inv<C>(x); break;
     case 6: r = fp_sqrt_candidate<C>(x); break;
+    case 7: return fp_jacobi<C>(x) + 10;
+    case 8: return fp_jacobi<C>(fp_from_mont<C>(x)) + 10;
     default: return -1;
   }
   fp_to_be<C>(out, fp_from_mont<C>(r));

@@ -57,6 +57,7 @@ def test_hash_to_g1_random_vs_oracle(gpu_lib, curve, kat):
         assert g == coracle.hash_to_g1(curve["id"], m)
     for g, r in zip(got[300:], rows):
         assert g.hex() == r["point"]
+    # the exponentiation-tested rounds (BGLS_H2C=rounds) are exercised by test_alternate_kernel_paths_agree
     # a long tail of tries / all three SW branches: 4096 more messages against the oracle
     many = [rnd.randbytes(64) for _ in range(4096)]
     got = hash_batch(gpu_lib, curve["id"], curve["fp"], many)
@@ -318,9 +319,21 @@ for case in v["aggregate_cases"][:6]:
     off[len(msgs)] = acc
     r = lib.bgls_verify_aggregate(%d, B(bytes.fromhex(case["sig"])), B(b"".join(keys)), B(b"".join(msgs)), off, len(keys), 1 if case["allow_dups"] else 0)
     ok = ok and ((r == 1) == case["expect"])
+import random
+rnd = random.Random(3)
+msgs = [rnd.randbytes(64) for _ in range(300)] + [bytes.fromhex(r["msg"]) for r in v["h2c"]]
+off = (ctypes.c_uint64 * (len(msgs) + 1))(); acc = 0
+for i, m in enumerate(msgs): off[i] = acc; acc += len(m)
+off[len(msgs)] = acc
+o = (ctypes.c_uint8 * (len(msgs) * 2 * fp))()
+blob = b"".join(msgs)
+rc = lib.bgls_hash_to_g1(%d, B(blob) if blob else None, off, len(msgs), o)
+raw = bytes(o)
+ok = ok and rc == 0 and all(raw[(300 + i) * 2 * fp:(301 + i) * 2 * fp].hex() == r["point"] for i, r in enumerate(v["h2c"]))
 print("OK" if ok else "MISMATCH")
-''' % (root, os.path.join(root, "tests", "golden", "vectors_%s.json" % curve["name"]), curve["fp"], curve["id"], curve["id"])
-    for env in ({"BGLS_KERNELS": "v1"}, {"BGLS_MILLER": "coop1", "BGLS_FINAL": "6"}, {"BGLS_MILLER": "ab"}):
+''' % (root, os.path.join(root, "tests", "golden", "vectors_%s.json" % curve["name"]), curve["fp"], curve["id"], curve["id"], curve["id"])
+    for env in ({"BGLS_KERNELS": "v1"}, {"BGLS_MILLER": "coop1", "BGLS_FINAL": "6"}, {"BGLS_MILLER": "ab", "BGLS_STEP_CALLS": "1"},
+                {"BGLS_H2C": "rounds"}):
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
         assert out.stdout.strip().endswith("OK"), (env, out.stdout[-500:], out.stderr[-500:])

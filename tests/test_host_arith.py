@@ -32,6 +32,12 @@ def test_fp_and_fp2(host_harness, curve):
             o = out(n)
             assert lib.ht_fp_op(cid, op, B(a.to_bytes(n, "big")), B(b.to_bytes(n, "big")), o) == 0
             assert int.from_bytes(bytes(o), "big") == fn(a, b), (op, a, b)
+    # Legendre symbol by the binary Jacobi algorithm == Euler criterion (hash.go:254-265), on the Montgomery
+    # residue (op 7) and on the plain residue (op 8)
+    for a in [0, 1, 2, 3, 4, p - 1, p - 2, (p + 1) // 2, 1 << 64, (1 << 200) + 12345] + [rnd.randrange(p) for _ in range(200)]:
+        want = 0 if a == 0 else (1 if pow(a, (p - 1) // 2, p) == 1 else -1)
+        for op in (7, 8):
+            assert lib.ht_fp_op(cid, op, B(a.to_bytes(n, "big")), B(bytes(n)), out(n)) - 10 == want, (op, a)
     f2b = lambda x: x[0].to_bytes(n, "big") + x[1].to_bytes(n, "big")
     for op, fn in ((0, T.f2_mul), (1, lambda a, b: T.f2_sqr(a)), (2, lambda a, b: T.f2_mulxi(a)), (3, lambda a, b: T.f2_inv(a))):
         for _ in range(16):
