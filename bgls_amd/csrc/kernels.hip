@@ -681,6 +681,180 @@ __global__ void __launch_bounds__(128, 3) k_miller_ab(const Aff<F1<C>>* g1s, con
   }
 }
 
+// ---- fixed-argument lines of the generator --------------------------------------------------------------
+// The (-sigma, g2) pair of every verification has Q = GetG2(), a curve constant (curves/altbn128.go:427-429,
+// curves/bls12_381.go:279-281): its point steps do not depend on the input, only the scaling of the line
+// by P = -sigma does.  k_gen_lines walks the Miller loop of g2 once per context and stores the unscaled
+// coefficients of every step.
+template <class C>
+__global__ void k_gen_lines(LineCoeffs<C>* table, int* nsteps) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fp2<C> qx = f2_load<C>(C::G2), qy = f2_load<C>(C::G2 + 2 * C::L);
+  G2Proj<C> T = {qx, qy, f2_one<C>()};
+  const Fp2<C> nyq = f2_neg<C>(qy);
+  int s = 0;
+  for (int i = 1; i < C::LOOP_LEN; ++i) {
+    table[s++] = dbl_step<C>(T);
+    const int d = C::LOOP_NAF[i];
+    if (d != 0) table[s++] = add_step<C>(T, qx, d > 0 ? qy : nyq);
+  }
+  if constexpr (C::CURVE_ID == 0) {
+    Fp2<C> x1 = f2_mul<C>(f2_conj<C>(qx), gamma_const<C>(1, 2));
+    Fp2<C> y1 = f2_mul<C>(f2_conj<C>(qy), gamma_const<C>(1, 3));
+    Fp2<C> x2 = f2_mul<C>(qx, gamma_const<C>(2, 2));
+    Fp2<C> y2 = f2_neg<C>(f2_mul<C>(qy, gamma_const<C>(2, 3)));
+    table[s++] = add_step<C>(T, x1, y1);
+    table[s++] = add_step<C>(T, x2, y2);
+  }
+  *nsteps = s;
+}
+
+// ---- 64 pairings per block, 256 VGPRs (two waves per SIMD, 1024 blocks = exactly one 2^16 batch) ----------
+// Same producer/consumer scheme as k_miller_ab, but the producer wave uses all 64 lanes (lane l feeds line
+// slot l/10 of group l%10, so groups 0..3 fold seven lines and the others six plus a constant 1), the
+// (-sigma, g2) pair needs no point steps (k_gen_lines table, scaled by lane 0 of block 0), and nothing
+// spills: the point-step temporaries fit the 256-register budget.
+template <class C>
+struct Coop64 {
+  static constexpr int S2 = 2 * C::L, NL = 7;
+  static constexpr int RB = 0, RL = 12 * S2, RL2 = (12 + 3 * NL) * S2;
+  static constexpr int GROUP_DW = (12 + 2 * 3 * NL) * S2;
+  static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
+};
+
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                                                        const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+  typedef Coop64<C> K;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave == 0) {
+    // ---------------- producer: 64 pairings, one per lane
+    const size_t idx = (size_t)blockIdx.x * 64 + lane;
+    const int tg = lane % 10, slot = lane / 10;
+    const int tgb = tg * K::GROUP_DW;
+    Aff<F2<C>> Q;
+    Aff<F1<C>> P;
+    bool valid = idx < n;
+    if (valid) {
+      bool ok = g2_from_bytes<C>(Q, g2s + idx * 4 * C::FP_BYTES);
+      ok = ok && aff_on_curve<F2<C>>(Q);
+      if (!ok) atomicOr(flags, FLAG_ENC);
+      P = g1s[idx];
+      valid = !P.inf && !Q.inf;
+    }
+    if (!valid) {
+      Q.x = f2_load<C>(C::G2);
+      Q.y = f2_load<C>(C::G2 + 2 * C::L);
+      P.x = fp_load<C>(C::G1X);
+      P.y = fp_load<C>(C::G1Y);
+    }
+    // the (-sigma, g2) pair rides in block 0, group 4, slot 6 (a slot no lane owns)
+    const bool sig_lane = sig_at >= 0 && blockIdx.x == 0 && lane == 0;
+    Aff<F1<C>> S;
+    bool sig_valid = false;
+    if (sig_lane) {
+      S = g1s[sig_at];
+      sig_valid = !S.inf;
+    }
+    // slots without an owner hold the constant 1 in both buffers
+    if (lane < 10) {
+      for (int b = 0; b < 2; ++b) {
+        const LReg r = {lane * K::GROUP_DW + (b ? K::RL2 : K::RL), 3 * K::NL};
+        if (lane >= 4) {
+          lds_st<C>(r, 18, f2_one<C>());
+          lds_st<C>(r, 19, f2_zero<C>());
+          lds_st<C>(r, 20, f2_zero<C>());
+        }
+      }
+    }
+    G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+    int buf = 0, step = 0;
+    auto sig_line = [&](int st, int bufsel) {
+      if (sig_lane && sig_valid) {
+        const LineCoeffs<C> l = gen_lines[st];
+        LineEmitter<C> em{LReg{4 * K::GROUP_DW + (bufsel ? K::RL2 : K::RL), 3 * K::NL}, 6, S.x, S.y, true, true};
+        em(0, l.c0);
+        em(1, l.c1);
+        em(2, l.c2);
+      }
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      dbl_step_emit<C>(T, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
+      sig_line(step++, buf);
+      wave_sync();
+      __syncthreads();
+      buf ^= 1;
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
+        sig_line(step++, buf);
+        wave_sync();
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+      add_step_emit<C>(T, x1, y1, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
+      sig_line(step++, buf);
+      wave_sync();
+      __syncthreads();
+      buf ^= 1;
+      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+      add_step_emit<C>(T, x2, y2, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
+      sig_line(step++, buf);
+      wave_sync();
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    // ---------------- consumer: 10 groups x 6 lanes, seven lines per step
+    const bool live = lane < 60;
+    const int g = live ? lane / 6 : 9;
+    const int j = live ? lane % 6 : lane - 60;
+    const int gb = g * K::GROUP_DW;
+    Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
+    coop_publish<C>(gb + K::RB, j, fj, live);
+    int buf = 0;
+    auto fold = [&](int bufsel) {
+#pragma unroll 1
+      for (int m = 0; m < K::NL; ++m) {
+        fj = coop_dot_inl<C, 3>(LReg{gb + (bufsel ? K::RL2 : K::RL), 3 * K::NL}, 3 * m, 1, LReg{gb + K::RB, 12}, j,
+                                C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+        coop_publish<C>(gb + K::RB, j, fj, live);
+      }
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      __syncthreads();
+      fj = coop_dot_inl<C, 6>(LReg{gb + K::RB, 12}, 0, 2, LReg{gb + K::RB, 12}, j, COOP_SH6);
+      coop_publish<C>(gb + K::RB, j, fj, live);
+      fold(buf);
+      buf ^= 1;
+      if (C::LOOP_NAF[i] != 0) {
+        __syncthreads();
+        fold(buf);
+        buf ^= 1;
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      __syncthreads();
+      fold(buf);
+      buf ^= 1;
+      __syncthreads();
+      fold(buf);
+      buf ^= 1;
+    } else {
+      if (j & 1) fj = f2_neg<C>(fj);
+    }
+    if (live) out[((size_t)blockIdx.x * 10 + g) * 6 + j] = fj;
+  }
+}
+
 // out[G] = prod in[G*R .. min(count, (G+1)*R))   (w-basis Fp12 arrays)
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_coop(const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
@@ -887,6 +1061,7 @@ struct Ctx {
   bool ready = false;
   hipStream_t stream = nullptr;
   std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
+  void* gen_lines[2] = {nullptr, nullptr};   // k_gen_lines tables, one per curve, built on first use
   // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
   bool prof = false;
   struct Pending { hipEvent_t a, b; int stage; };
@@ -1128,6 +1303,46 @@ struct Engine {
   static int miller_coop(Ctx& c, hipStream_t st, const Aff<G1F>* g1s, const uint8_t* g2s, size_t total, long long gen_at,
                          uint8_t* d_partial, uint32_t* d_flags) {
     typedef Coop<C> K;
+    // 64 pairings per block / 256 registers: one 2^16 batch is exactly 1024 resident blocks (alt-bn128 only:
+    // the BLS12-381 line buffers do not leave room for four blocks per CU)
+    if constexpr (C::CURVE_ID == 0) {
+      const size_t npairs = gen_at >= 0 ? total - 1 : total;
+      const size_t nb64 = (npairs + 63) / 64;
+      if (miller_mode() == 0 && !getenv("BGLS_NO_AB64") && nb64 >= 1 && nb64 <= 1024 && (gen_at < 0 || gen_at == (long long)npairs)) {
+        int rc;
+        if (!c.gen_lines[C::CURVE_ID]) {
+          void *tab, *cnt;
+          HIPCHK(hipMalloc(&tab, 160 * sizeof(LineCoeffs<C>)));
+          if ((rc = c.get(WS_OUT, 16, &cnt))) return rc;
+          k_gen_lines<C><<<1, 64, 0, st>>>((LineCoeffs<C>*)tab, (int*)cnt);
+          HIPCHK(hipGetLastError());
+          c.gen_lines[C::CURVE_ID] = tab;
+        }
+        void *pa, *pb;
+        const size_t groups64 = nb64 * 10;
+        if ((rc = c.get(WS_F_A, (groups64 + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+        if ((rc = c.get(WS_F_B, (groups64 / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+        {
+          Scope sc(c, st, ST_MILLER);
+          k_miller_ab64<C><<<(unsigned)nb64, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1s, g2s, npairs, gen_at, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID],
+                                                                             (Fp2<C>*)pa, d_flags);
+        }
+        Scope sc(c, st, ST_REDUCE);
+        Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;
+        size_t cnt = groups64;
+        while (cnt > 1) {
+          size_t nout = (cnt + 3) / 4;
+          k_reduce_coop<C><<<nblk(nout, K::GROUPS), 64, K::WAVE_BYTES, st>>>(a, cnt, 4, b);
+          Fp2<C>* t = a;
+          a = b;
+          b = t;
+          cnt = nout;
+        }
+        k_w_to_bytes<C><<<1, 64, 0, st>>>(a, d_partial);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
+    }
     const size_t max_groups = 256 * 8 * K::GROUPS;                 // 8 resident waves per CU
     size_t groups = (total + 5) / 6;
     if (groups > max_groups) groups = max_groups;
