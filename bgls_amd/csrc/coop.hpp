@@ -49,6 +49,10 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __constant__ const int COOP_SH6[6] = {0, 1, 2, 3, 4, 5};
 __device__ __constant__ const int COOP_SH_D[3] = {0, 1, 3};   // D-type line: e0 + e1 w + e3 w^3
 __device__ __constant__ const int COOP_SH_M[3] = {0, 2, 3};   // M-type line: e0 + e2 w^2 + e3 w^3
+// product of TWO lines (p + q w^a + r w^3)(p' + q' w^a + r' w^3), a = 1 (D) or 2 (M): five coefficients
+//   [pp' + xi rr', pq'+qp', qq', pr'+rp', qr'+rq'] at these powers of w
+__device__ __constant__ const int COOP_SH_D5[5] = {0, 1, 2, 3, 4};
+__device__ __constant__ const int COOP_SH_M5[5] = {0, 2, 4, 3, 5};
 
 // A region is an array of Fp2 entries, entry-major (each entry 2L contiguous dwords, read with
 // ds_read_b128).  A chunk-major variant (the c-th 16-byte chunk of all entries contiguous) was
@@ -130,7 +134,7 @@ __device__ __forceinline__ Fp2<C> coop_dot_inl(LReg ra, int a_e0, int a_es, LReg
   }
   w_sub<W>(s, s, v0);
   w_sub<W>(s, s, v1);                                   // sum (a0 b1 + a1 b0)         < 2 NT p^2
-  if constexpr (NT == 6) w_add<W>(v0, v0, C::P2W6); else w_add<W>(v0, v0, C::P2W3);
+  if constexpr (NT > 3) w_add<W>(v0, v0, C::P2W6); else w_add<W>(v0, v0, C::P2W3);
   w_sub<W>(v0, v0, v1);                                 // sum (a0 b0 - a1 b1) + NT p^2 in (0, 2 NT p^2)
   Fp2<C> r;
   r.c0 = redc_k<C, Coop<C>::LAZY_K>(v0);
@@ -230,6 +234,59 @@ struct LineEmitter {
     if (live) lds_st<C>(r, 3 * j + entry, e);
   }
 };
+
+// ---- pair-of-lines form: the producer wave multiplies the lines of two neighbouring pairings (lanes 2m,
+// 2m+1 of a group) into one 5-coefficient element, so the consumer folds three 5-term elements instead of
+// six 3-term lines.  Same total work, moved to the producer -- pays off only where the producer has the
+// registers for it (k_miller_ab64; in the 168-register kernel it was a loss).
+template <class C>
+struct LineCapture {          // emitter that keeps the scaled line (p, q, r) in registers
+  Fp2<C> e[3];
+  const Fp<C>& xP;
+  const Fp<C>& yP;
+  __device__ __forceinline__ void operator()(int which, const Fp2<C>& v) {
+    if (which == 0) e[C::TWIST_D ? 0 : 2] = f2ms<C, true>(v, yP);
+    else if (which == 1) e[1] = f2ms<C, true>(v, xP);
+    else e[C::TWIST_D ? 2 : 0] = v;
+  }
+};
+template <class C>
+__device__ __forceinline__ Fp2<C> f2_shfl_xor1(const Fp2<C>& a) {
+  Fp2<C> r;
+#pragma unroll
+  for (int k = 0; k < C::L; ++k) {
+    r.c0.v[k] = __shfl_xor(a.c0.v[k], 1);
+    r.c1.v[k] = __shfl_xor(a.c1.v[k], 1);
+  }
+  return r;
+}
+// lanes (2m, 2m+1) hold lines A (even lane) and B (odd lane); writes the five coefficients of A*B into entries
+// 5m .. 5m+4 of region rl.  Uniform instruction stream: operand selects by lane parity.
+template <class C>
+__device__ __forceinline__ void coop_write_line_pair(LReg rl, int j, const Fp2<C> (&own)[3]) {
+  const bool odd = j & 1;
+  Fp2<C> oth[3] = {f2_shfl_xor1<C>(own[0]), f2_shfl_xor1<C>(own[1]), f2_shfl_xor1<C>(own[2])};
+  // a = even lane's line, b = odd lane's line (index 2 = the w^3 coefficient)
+  // even lane: P00 = a0 b0, P11 = a1 b1, K01 = (a0+a1)(b0+b1);  odd lane: P33 = a2 b2, K03 = (a0+a2)(b0+b2), K13 = (a1+a2)(b1+b2)
+  Fp2<C> a0 = f2_select<C>(odd, oth[0], own[0]), a1 = f2_select<C>(odd, oth[1], own[1]), a2 = f2_select<C>(odd, oth[2], own[2]);
+  Fp2<C> b0 = f2_select<C>(odd, own[0], oth[0]), b1 = f2_select<C>(odd, own[1], oth[1]), b2 = f2_select<C>(odd, own[2], oth[2]);
+  Fp2<C> x1 = f2_select<C>(odd, a2, a0), y1 = f2_select<C>(odd, b2, b0);
+  Fp2<C> x2 = f2_select<C>(odd, f2_add<C>(a0, a2), a1), y2 = f2_select<C>(odd, f2_add<C>(b0, b2), b1);
+  Fp2<C> x3 = f2_add<C>(a1, f2_select<C>(odd, a2, a0)), y3 = f2_add<C>(b1, f2_select<C>(odd, b2, b0));
+  Fp2<C> p1 = f2_mul_inl<C>(x1, y1);     // even: P00   odd: P33
+  Fp2<C> p2 = f2_mul_inl<C>(x2, y2);     // even: P11   odd: K03
+  Fp2<C> p3 = f2_mul_inl<C>(x3, y3);     // even: K01   odd: K13
+  Fp2<C> q1 = f2_shfl_xor1<C>(p1), q2 = f2_shfl_xor1<C>(p2);
+  const int m = j >> 1;
+  if (!odd) {       // c0 = P00 + xi P33, c1 = K01 - P00 - P11, c2 = P11
+    lds_st<C>(rl, 5 * m + 0, f2_add<C>(p1, f2_mulxi<C>(q1)));
+    lds_st<C>(rl, 5 * m + 1, f2_sub<C>(f2_sub<C>(p3, p1), p2));
+    lds_st<C>(rl, 5 * m + 2, p2);
+  } else {          // c3 = K03 - P00 - P33, c4 = K13 - P11 - P33   (q1 = P00, q2 = P11 from the even lane)
+    lds_st<C>(rl, 5 * m + 3, f2_sub<C>(f2_sub<C>(p2, q1), p1));
+    lds_st<C>(rl, 5 * m + 4, f2_sub<C>(f2_sub<C>(p3, q2), p1));
+  }
+}
 
 // fold the six published lines into f (f in RB on entry and on exit; returns this lane's coefficient)
 template <class C, bool INL = false>

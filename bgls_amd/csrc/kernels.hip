@@ -716,12 +716,17 @@ __global__ void k_gen_lines(LineCoeffs<C>* table, int* nsteps) {
 // spills: the point-step temporaries fit the 256-register budget.
 template <class C>
 struct Coop64 {
-  static constexpr int S2 = 2 * C::L, NL = 7;
-  static constexpr int RB = 0, RL = 12 * S2, RL2 = (12 + 3 * NL) * S2;
-  static constexpr int GROUP_DW = (12 + 2 * 3 * NL) * S2;
+  static constexpr int S2 = 2 * C::L;
+  static constexpr int NENT = 18;            // per group and buffer: 3 line pairs x 5 coefficients + 1 single line x 3
+  static constexpr int RB = 0, RL = 12 * S2, RL2 = (12 + NENT) * S2;
+  static constexpr int GROUP_DW = (12 + 2 * NENT) * S2;
   static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
 };
 
+// Lanes 0..59 of the producer wave are 30 neighbour pairs (lanes 6g+2m, 6g+2m+1 -> pair m of group g): each pair
+// multiplies its two lines into one 5-coefficient element (coop_write_line_pair).  Lanes 60..63 feed the
+// single-line slot of groups 0..3, the (-sigma, g2) line goes to the single slot of group 4, groups 5..9 keep
+// the constant 1 there.  The consumer folds 3 five-term elements + 1 three-term line per step.
 template <class C>
 __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
                                                         const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
@@ -731,7 +736,9 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
   if (wave == 0) {
     // ---------------- producer: 64 pairings, one per lane
     const size_t idx = (size_t)blockIdx.x * 64 + lane;
-    const int tg = lane % 10, slot = lane / 10;
+    const bool paired = lane < 60;
+    const int tg = paired ? lane / 6 : lane - 60;
+    const int j = paired ? lane % 6 : 0;
     const int tgb = tg * K::GROUP_DW;
     Aff<F2<C>> Q;
     Aff<F1<C>> P;
@@ -749,7 +756,6 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       P.x = fp_load<C>(C::G1X);
       P.y = fp_load<C>(C::G1Y);
     }
-    // the (-sigma, g2) pair rides in block 0, group 4, slot 6 (a slot no lane owns)
     const bool sig_lane = sig_at >= 0 && blockIdx.x == 0 && lane == 0;
     Aff<F1<C>> S;
     bool sig_valid = false;
@@ -757,97 +763,106 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       S = g1s[sig_at];
       sig_valid = !S.inf;
     }
-    // slots without an owner hold the constant 1 in both buffers
-    if (lane < 10) {
+    // single-line slots without an owner hold the constant 1 in both buffers
+    if (lane >= 4 && lane < 10) {
       for (int b = 0; b < 2; ++b) {
-        const LReg r = {lane * K::GROUP_DW + (b ? K::RL2 : K::RL), 3 * K::NL};
-        if (lane >= 4) {
-          lds_st<C>(r, 18, f2_one<C>());
-          lds_st<C>(r, 19, f2_zero<C>());
-          lds_st<C>(r, 20, f2_zero<C>());
-        }
+        const LReg r = {lane * K::GROUP_DW + (b ? K::RL2 : K::RL), K::NENT};
+        lds_st<C>(r, 15, f2_one<C>());
+        lds_st<C>(r, 16, f2_zero<C>());
+        lds_st<C>(r, 17, f2_zero<C>());
       }
     }
     G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
     int buf = 0, step = 0;
-    auto sig_line = [&](int st, int bufsel) {
+    auto publish = [&](LineCapture<C>& cap) {
+      if (!valid) { cap.e[0] = f2_one<C>(); cap.e[1] = f2_zero<C>(); cap.e[2] = f2_zero<C>(); }
+      const LReg r = {tgb + (buf ? K::RL2 : K::RL), K::NENT};
+      if (paired) {
+        coop_write_line_pair<C>(r, j, cap.e);
+      } else {
+        lds_st<C>(r, 15, cap.e[0]);
+        lds_st<C>(r, 16, cap.e[1]);
+        lds_st<C>(r, 17, cap.e[2]);
+      }
       if (sig_lane && sig_valid) {
-        const LineCoeffs<C> l = gen_lines[st];
-        LineEmitter<C> em{LReg{4 * K::GROUP_DW + (bufsel ? K::RL2 : K::RL), 3 * K::NL}, 6, S.x, S.y, true, true};
+        const LineCoeffs<C> l = gen_lines[step];
+        LineEmitter<C> em{LReg{4 * K::GROUP_DW + (buf ? K::RL2 : K::RL), K::NENT}, 5, S.x, S.y, true, true};   // entries 15..17
         em(0, l.c0);
         em(1, l.c1);
         em(2, l.c2);
       }
+      ++step;
+      wave_sync();
+      __syncthreads();
+      buf ^= 1;
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      dbl_step_emit<C>(T, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
-      sig_line(step++, buf);
-      wave_sync();
-      __syncthreads();
-      buf ^= 1;
+      {
+        LineCapture<C> cap{{}, P.x, P.y};
+        dbl_step_emit<C>(T, cap);
+        publish(cap);
+      }
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
-        sig_line(step++, buf);
-        wave_sync();
-        __syncthreads();
-        buf ^= 1;
+        LineCapture<C> cap{{}, P.x, P.y};
+        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), cap);
+        publish(cap);
       }
     }
     if constexpr (C::CURVE_ID == 0) {
-      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
-      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-      add_step_emit<C>(T, x1, y1, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
-      sig_line(step++, buf);
-      wave_sync();
-      __syncthreads();
-      buf ^= 1;
-      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
-      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-      add_step_emit<C>(T, x2, y2, LineEmitter<C>{LReg{tgb + (buf ? K::RL2 : K::RL), 3 * K::NL}, slot, P.x, P.y, valid, true});
-      sig_line(step++, buf);
-      wave_sync();
-      __syncthreads();
-      buf ^= 1;
+      {
+        Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+        Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+        LineCapture<C> cap{{}, P.x, P.y};
+        add_step_emit<C>(T, x1, y1, cap);
+        publish(cap);
+      }
+      {
+        Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+        Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+        LineCapture<C> cap{{}, P.x, P.y};
+        add_step_emit<C>(T, x2, y2, cap);
+        publish(cap);
+      }
     }
   } else {
-    // ---------------- consumer: 10 groups x 6 lanes, seven lines per step
+    // ---------------- consumer: 10 groups x 6 lanes; per step 3 line pairs + 1 single line
     const bool live = lane < 60;
     const int g = live ? lane / 6 : 9;
     const int j = live ? lane % 6 : lane - 60;
     const int gb = g * K::GROUP_DW;
+    const LReg rb = {gb + K::RB, 12};
     Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
     coop_publish<C>(gb + K::RB, j, fj, live);
     int buf = 0;
-    auto fold = [&](int bufsel) {
+    auto fold = [&]() {
+      const LReg rl = {gb + (buf ? K::RL2 : K::RL), K::NENT};
 #pragma unroll 1
-      for (int m = 0; m < K::NL; ++m) {
-        fj = coop_dot_inl<C, 3>(LReg{gb + (bufsel ? K::RL2 : K::RL), 3 * K::NL}, 3 * m, 1, LReg{gb + K::RB, 12}, j,
-                                C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+      for (int m = 0; m < 3; ++m) {
+        fj = coop_dot_inl<C, 5>(rl, 5 * m, 1, rb, j, C::TWIST_D ? COOP_SH_D5 : COOP_SH_M5);
         coop_publish<C>(gb + K::RB, j, fj, live);
       }
+      fj = coop_dot_inl<C, 3>(rl, 15, 1, rb, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+      coop_publish<C>(gb + K::RB, j, fj, live);
+      buf ^= 1;
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();
-      fj = coop_dot_inl<C, 6>(LReg{gb + K::RB, 12}, 0, 2, LReg{gb + K::RB, 12}, j, COOP_SH6);
+      fj = coop_dot_inl<C, 6>(rb, 0, 2, rb, j, COOP_SH6);
       coop_publish<C>(gb + K::RB, j, fj, live);
-      fold(buf);
-      buf ^= 1;
+      fold();
       if (C::LOOP_NAF[i] != 0) {
         __syncthreads();
-        fold(buf);
-        buf ^= 1;
+        fold();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
       __syncthreads();
-      fold(buf);
-      buf ^= 1;
+      fold();
       __syncthreads();
-      fold(buf);
-      buf ^= 1;
+      fold();
     } else {
       if (j & 1) fj = f2_neg<C>(fj);
     }
