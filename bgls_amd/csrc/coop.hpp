@@ -147,6 +147,46 @@ __device__ __noinline__ Fp2<C> coop_dot(LReg ra, int a_e0, int a_es, LReg rb, in
   return coop_dot_inl<C, NT>(ra, a_e0, a_es, rb, j, sh);
 }
 
+// f^2 with the symmetric terms merged: c_j = sum over i <= k, i + k = j (mod 6) of (2 if i != k) a_i a_k xi^[i+k >= 6]:
+// 4 products per lane instead of 6 (odd j have only 3; the 4th slot is masked out).  Table entry per term:
+// bits 0-2 = i (7 = unused slot), bits 3-5 = k, bit 6 = wrap, bit 7 = doubled.
+__device__ __constant__ const unsigned COOP_SQ_TAB[6] = {0x5be2e900u, 0xffe3ea88u, 0x64eb0990u, 0xffec9198u, 0x6d1299a0u, 0xff9aa1a8u};
+template <class C>
+__device__ __forceinline__ Fp2<C> coop_sqr_sym_inl(LReg rb, int j) {
+  constexpr int L = C::L, W = 2 * C::L;
+  u32 v0[W], v1[W], s[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) v0[k] = v1[k] = s[k] = 0;
+  const unsigned row = COOP_SQ_TAB[j];
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const unsigned e = (row >> (8 * t)) & 0xFFu;
+    const int i = e & 7u, k = (e >> 3) & 7u;
+    const bool used = i != 7;
+    Fp2<C> a = lds_ld<C>(rb, 2 * (used ? i : 0));
+    Fp2<C> b = lds_ld<C>(rb, used ? (2 * k + (int)((e >> 6) & 1u)) : 0);
+    b = f2_select<C>((e >> 7) & 1u, f2_dbl<C>(b), b);
+    a = f2_select<C>(used, a, f2_zero<C>());
+    u32 tmp[W];
+    mul_wide<C>(tmp, a.c0.v, b.c0.v);
+    w_add<W>(v0, v0, tmp);
+    mul_wide<C>(tmp, a.c1.v, b.c1.v);
+    w_add<W>(v1, v1, tmp);
+    Fp<C> sa = fp_add_nr<C>(a.c0, a.c1);
+    Fp<C> sb = fp_add_nr<C>(b.c0, b.c1);
+    mul_wide<C>(tmp, sa.v, sb.v);
+    w_add<W>(s, s, tmp);
+  }
+  w_sub<W>(s, s, v0);
+  w_sub<W>(s, s, v1);
+  w_add<W>(v0, v0, C::P2W6);
+  w_sub<W>(v0, v0, v1);
+  Fp2<C> r;
+  r.c0 = redc_k<C, Coop<C>::LAZY_K>(v0);
+  r.c1 = redc_k<C, Coop<C>::LAZY_K>(s);
+  return r;
+}
+
 // publish this lane's coefficient (plain and xi-multiplied) into the group's RB region
 template <class C>
 __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v, bool live) {

@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();
-      fj = coop_dot_inl<C, 6>(rb, 0, 2, rb, j, COOP_SH6);
+      fj = coop_sqr_sym_inl<C>(rb, j);
       coop_publish<C>(gb + K::RB, j, fj, live);
       fold();
       if (C::LOOP_NAF[i] != 0) {
