@@ -211,12 +211,15 @@ __device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool
   return r;
 }
 
+template <class C>
+__device__ __noinline__ Fp2<C> coop_sqr_sym(LReg rb, int j) {
+  return coop_sqr_sym_inl<C>(rb, j);
+}
 // f <- f^2, f in RB
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_sqr(int gb, int j) {
-  typedef Coop<C> K;
-  if constexpr (INL) return coop_dot_inl<C, 6>(reg_rb<C>(gb), 0, 2, reg_rb<C>(gb), j, COOP_SH6);
-  else return coop_dot<C, 6>(reg_rb<C>(gb), 0, 2, reg_rb<C>(gb), j, COOP_SH6);
+  if constexpr (INL) return coop_sqr_sym_inl<C>(reg_rb<C>(gb), j);
+  else return coop_sqr_sym<C>(reg_rb<C>(gb), j);
 }
 
 // f <- f * line_m, line coefficients at RL[m][0..2]
