@@ -307,25 +307,25 @@ __device__ __forceinline__ Fp2<C> f2_shfl_xor1(const Fp2<C>& a) {
 // 5m .. 5m+4 of region rl.  Uniform instruction stream: operand selects by lane parity.
 template <class C>
 __device__ __forceinline__ void coop_write_line_pair(LReg rl, int j, const Fp2<C> (&own)[3]) {
-  const bool odd = j & 1;
-  Fp2<C> oth[3] = {f2_shfl_xor1<C>(own[0]), f2_shfl_xor1<C>(own[1]), f2_shfl_xor1<C>(own[2])};
   // a = even lane's line, b = odd lane's line (index 2 = the w^3 coefficient)
-  // even lane: P00 = a0 b0, P11 = a1 b1, K01 = (a0+a1)(b0+b1);  odd lane: P33 = a2 b2, K03 = (a0+a2)(b0+b2), K13 = (a1+a2)(b1+b2)
-  Fp2<C> a0 = f2_select<C>(odd, oth[0], own[0]), a1 = f2_select<C>(odd, oth[1], own[1]), a2 = f2_select<C>(odd, oth[2], own[2]);
-  Fp2<C> b0 = f2_select<C>(odd, own[0], oth[0]), b1 = f2_select<C>(odd, own[1], oth[1]), b2 = f2_select<C>(odd, own[2], oth[2]);
-  Fp2<C> x1 = f2_select<C>(odd, a2, a0), y1 = f2_select<C>(odd, b2, b0);
-  Fp2<C> x2 = f2_select<C>(odd, f2_add<C>(a0, a2), a1), y2 = f2_select<C>(odd, f2_add<C>(b0, b2), b1);
-  Fp2<C> x3 = f2_add<C>(a1, f2_select<C>(odd, a2, a0)), y3 = f2_add<C>(b1, f2_select<C>(odd, b2, b0));
-  Fp2<C> p1 = f2_mul_inl<C>(x1, y1);     // even: P00   odd: P33
-  Fp2<C> p2 = f2_mul_inl<C>(x2, y2);     // even: P11   odd: K03
-  Fp2<C> p3 = f2_mul_inl<C>(x3, y3);     // even: K01   odd: K13
+  //   even lane: P00 = a0 b0, P11 = a1 b1, K01 = (a0+a1)(b0+b1);   odd lane: P22 = a2 b2, K02 = (a0+a2)(b0+b2), K12 = (a1+a2)(b1+b2)
+  // Each lane forms its left operand from its own line and receives exactly the matching right operand from
+  // its neighbour, one Fp2 at a time (keeps the live set small).
+  const bool odd = j & 1;
+  // what the neighbour needs from me: it has the opposite parity
+  Fp2<C> p1 = f2_mul_inl<C>(f2_select<C>(odd, own[2], own[0]),
+                            f2_shfl_xor1<C>(f2_select<C>(odd, own[0], own[2])));            // even: P00   odd: P22
+  Fp2<C> p2 = f2_mul_inl<C>(f2_select<C>(odd, f2_add<C>(own[0], own[2]), own[1]),
+                            f2_shfl_xor1<C>(f2_select<C>(odd, own[1], f2_add<C>(own[0], own[2]))));   // even: P11   odd: K02
+  Fp2<C> p3 = f2_mul_inl<C>(f2_add<C>(own[1], f2_select<C>(odd, own[2], own[0])),
+                            f2_shfl_xor1<C>(f2_add<C>(own[1], f2_select<C>(odd, own[0], own[2]))));  // even: K01   odd: K12
   Fp2<C> q1 = f2_shfl_xor1<C>(p1), q2 = f2_shfl_xor1<C>(p2);
   const int m = j >> 1;
-  if (!odd) {       // c0 = P00 + xi P33, c1 = K01 - P00 - P11, c2 = P11
+  if (!odd) {       // c0 = P00 + xi P22, c1 = K01 - P00 - P11, c2 = P11
     lds_st<C>(rl, 5 * m + 0, f2_add<C>(p1, f2_mulxi<C>(q1)));
     lds_st<C>(rl, 5 * m + 1, f2_sub<C>(f2_sub<C>(p3, p1), p2));
     lds_st<C>(rl, 5 * m + 2, p2);
-  } else {          // c3 = K03 - P00 - P33, c4 = K13 - P11 - P33   (q1 = P00, q2 = P11 from the even lane)
+  } else {          // c3 = K02 - P00 - P22, c4 = K12 - P11 - P22   (q1 = P00, q2 = P11 from the even lane)
     lds_st<C>(rl, 5 * m + 3, f2_sub<C>(f2_sub<C>(p2, q1), p1));
     lds_st<C>(rl, 5 * m + 4, f2_sub<C>(f2_sub<C>(p3, q2), p1));
   }
