@@ -337,3 +337,37 @@ print("OK" if ok else "MISMATCH")
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
         assert out.stdout.strip().endswith("OK"), (env, out.stdout[-500:], out.stderr[-500:])
+
+
+def test_randomised_sizes_and_corruptions(gpu_lib, curve):
+    """Ragged batch sizes around every kernel's tile boundaries (60/64 pairings per block, 6 per group, 256-message
+    hashing threshold, reduction fan-in 4): valid instances verify, any single corruption rejects, and the
+    pairing product equals the oracle's bytes."""
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(2026 + cid)
+    sizes = [1, 2, 5, 6, 7, 59, 60, 61, 63, 64, 65, 119, 120, 121, 255, 256, 257, 600, 641] + [rnd.randrange(1, 1500) for _ in range(6)]
+    for n in sizes:
+        agg, keys, msgs = make_instance(gpu_lib, cid, n_fp, n, 9000 + n, msg_len=rnd.choice((8, 32, 64, 100)))   # >= 8 bytes: duplicates would (correctly) reject
+        blob = b"".join(msgs)
+        assert gpu_lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(blob), offsets(msgs), n, 0) == 1, n
+        which = rnd.randrange(3)
+        if which == 0:                                    # flip one message bit
+            bad = bytearray(blob); bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+            r = gpu_lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(bytes(bad)), offsets(msgs), n, 1)
+        elif which == 1 and n > 1:                        # swap two keys
+            i, k = rnd.sample(range(n), 2)
+            kk = bytearray(keys); s = 4 * n_fp
+            kk[i * s:(i + 1) * s], kk[k * s:(k + 1) * s] = keys[k * s:(k + 1) * s], keys[i * s:(i + 1) * s]
+            r = gpu_lib.bgls_verify_aggregate(cid, B(agg), B(bytes(kk)), B(blob), offsets(msgs), n, 0)
+        else:                                             # signature of a different instance
+            other, _, _ = make_instance(gpu_lib, cid, n_fp, 1, 77, msg_len=8)
+            r = gpu_lib.bgls_verify_aggregate(cid, B(other), B(keys), B(blob), offsets(msgs), n, 0)
+        assert r == 0, (n, which)
+    # pairing products of ragged sizes against the oracle
+    g1 = bytes.fromhex(curve["vec"]["pairings"][3]["g1"]); g2 = bytes.fromhex(curve["vec"]["pairings"][3]["g2"])
+    for n in (2, 7, 61, 64, 65, 130):
+        g1s = b"".join(coracle.scale_point(cid, 1, g1, rnd.randrange(1, 1 << 200)) for _ in range(n))
+        g2s = b"".join(coracle.scale_point(cid, 2, g2, rnd.randrange(1, 1 << 200)) for _ in range(n))
+        o = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, B(g1s), B(g2s), n, o) == 0
+        assert bytes(o) == coracle.pairing_product(cid, g1s, g2s, n, threads=8), n
