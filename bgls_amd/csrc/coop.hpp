@@ -108,7 +108,7 @@ __device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a) {
 
 // c_j = sum_{t<NT} A[t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
 //   A[t] = entry a_e0 + t*a_es of region ra;  B = entries {2k, 2k+1} = {e_k, xi e_k} of region rb.
-template <class C, int NT>
+template <class C, int NT, bool XF = false>
 __device__ __forceinline__ Fp2<C> coop_dot_inl(LReg ra, int a_e0, int a_es, LReg rb, int j, const int* sh) {
   constexpr int L = C::L, W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
@@ -121,7 +121,8 @@ __device__ __forceinline__ Fp2<C> coop_dot_inl(LReg ra, int a_e0, int a_es, LReg
     const int wrap = k < 0 ? 1 : 0;
     k += 6 * wrap;
     Fp2<C> a = lds_ld<C>(ra, a_e0 + t * a_es);
-    Fp2<C> b = lds_ld<C>(rb, 2 * k + wrap);
+    Fp2<C> b = lds_ld<C>(rb, XF ? k : 2 * k + wrap);
+    if constexpr (XF) b = f2_select<C>(wrap != 0, f2_mulxi<C>(b), b);   // region holds plain coefficients only
     u32 tmp[W];
     mul_wide<C>(tmp, a.c0.v, b.c0.v);
     w_add<W>(v0, v0, tmp);
@@ -151,7 +152,7 @@ __device__ __noinline__ Fp2<C> coop_dot(LReg ra, int a_e0, int a_es, LReg rb, in
 // 4 products per lane instead of 6 (odd j have only 3; the 4th slot is masked out).  Table entry per term:
 // bits 0-2 = i (7 = unused slot), bits 3-5 = k, bit 6 = wrap, bit 7 = doubled.
 __device__ __constant__ const unsigned COOP_SQ_TAB[6] = {0x5be2e900u, 0xffe3ea88u, 0x64eb0990u, 0xffec9198u, 0x6d1299a0u, 0xff9aa1a8u};
-template <class C>
+template <class C, bool XF = false>
 __device__ __forceinline__ Fp2<C> coop_sqr_sym_inl(LReg rb, int j) {
   constexpr int L = C::L, W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
@@ -163,8 +164,9 @@ __device__ __forceinline__ Fp2<C> coop_sqr_sym_inl(LReg rb, int j) {
     const unsigned e = (row >> (8 * t)) & 0xFFu;
     const int i = e & 7u, k = (e >> 3) & 7u;
     const bool used = i != 7;
-    Fp2<C> a = lds_ld<C>(rb, 2 * (used ? i : 0));
-    Fp2<C> b = lds_ld<C>(rb, used ? (2 * k + (int)((e >> 6) & 1u)) : 0);
+    Fp2<C> a = lds_ld<C>(rb, (XF ? 1 : 2) * (used ? i : 0));
+    Fp2<C> b = lds_ld<C>(rb, used ? (XF ? k : 2 * k + (int)((e >> 6) & 1u)) : 0);
+    if constexpr (XF) b = f2_select<C>(((e >> 6) & 1u) != 0, f2_mulxi<C>(b), b);
     b = f2_select<C>((e >> 7) & 1u, f2_dbl<C>(b), b);
     a = f2_select<C>(used, a, f2_zero<C>());
     u32 tmp[W];
@@ -188,12 +190,16 @@ __device__ __forceinline__ Fp2<C> coop_sqr_sym_inl(LReg rb, int j) {
 }
 
 // publish this lane's coefficient (plain and xi-multiplied) into the group's RB region
-template <class C>
+template <class C, bool XF = false>
 __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v, bool live) {
   if (live) {
     const LReg rb = {rb_off, 12};
-    lds_st<C>(rb, 2 * j, v);
-    lds_st<C>(rb, 2 * j + 1, f2_mulxi<C>(v));
+    if constexpr (XF) {
+      lds_st<C>(rb, j, v);
+    } else {
+      lds_st<C>(rb, 2 * j, v);
+      lds_st<C>(rb, 2 * j + 1, f2_mulxi<C>(v));
+    }
   }
   wave_sync();
 }

@@ -718,8 +718,12 @@ template <class C>
 struct Coop64 {
   static constexpr int S2 = 2 * C::L;
   static constexpr int NENT = 18;            // per group and buffer: 3 line pairs x 5 coefficients + 1 single line x 3
-  static constexpr int RB = 0, RL = 12 * S2, RL2 = (12 + NENT) * S2;
-  static constexpr int GROUP_DW = (12 + 2 * NENT) * S2;
+  // BLS12-381: xi = 1+i costs two additions, so the accumulator region keeps the plain coefficients only and
+  // the wrap-around factor is applied after the load; that is what lets four blocks share a CU's 160 KB.
+  static constexpr bool XF = C::XI_RE == 1;
+  static constexpr int RBN = XF ? 6 : 12;
+  static constexpr int RB = 0, RL = RBN * S2, RL2 = (RBN + NENT) * S2;
+  static constexpr int GROUP_DW = (RBN + 2 * NENT) * S2;
   static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
 };
 
@@ -834,24 +838,24 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     const int gb = g * K::GROUP_DW;
     const LReg rb = {gb + K::RB, 12};
     Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
-    coop_publish<C>(gb + K::RB, j, fj, live);
+    coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
     int buf = 0;
     auto fold = [&]() {
       const LReg rl = {gb + (buf ? K::RL2 : K::RL), K::NENT};
 #pragma unroll 1
       for (int m = 0; m < 3; ++m) {
-        fj = coop_dot_inl<C, 5>(rl, 5 * m, 1, rb, j, C::TWIST_D ? COOP_SH_D5 : COOP_SH_M5);
-        coop_publish<C>(gb + K::RB, j, fj, live);
+        fj = coop_dot_inl<C, 5, K::XF>(rl, 5 * m, 1, rb, j, C::TWIST_D ? COOP_SH_D5 : COOP_SH_M5);
+        coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
       }
-      fj = coop_dot_inl<C, 3>(rl, 15, 1, rb, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
-      coop_publish<C>(gb + K::RB, j, fj, live);
+      fj = coop_dot_inl<C, 3, K::XF>(rl, 15, 1, rb, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
       buf ^= 1;
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();
-      fj = coop_sqr_sym_inl<C>(rb, j);
-      coop_publish<C>(gb + K::RB, j, fj, live);
+      fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
+      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
       fold();
       if (C::LOOP_NAF[i] != 0) {
         __syncthreads();
@@ -864,7 +868,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       __syncthreads();
       fold();
     } else {
-      if (j & 1) fj = f2_neg<C>(fj);
+      if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
     }
     if (live) out[((size_t)blockIdx.x * 10 + g) * 6 + j] = fj;
   }
@@ -1318,9 +1322,8 @@ struct Engine {
   static int miller_coop(Ctx& c, hipStream_t st, const Aff<G1F>* g1s, const uint8_t* g2s, size_t total, long long gen_at,
                          uint8_t* d_partial, uint32_t* d_flags) {
     typedef Coop<C> K;
-    // 64 pairings per block / 256 registers: one 2^16 batch is exactly 1024 resident blocks (alt-bn128 only:
-    // the BLS12-381 line buffers do not leave room for four blocks per CU)
-    if constexpr (C::CURVE_ID == 0) {
+    // 64 pairings per block / 256 registers: one 2^16 batch is exactly 1024 resident blocks
+    {
       const size_t npairs = gen_at >= 0 ? total - 1 : total;
       const size_t nb64 = (npairs + 63) / 64;
       if (miller_mode() == 0 && !getenv("BGLS_NO_AB64") && nb64 >= 1 && nb64 <= 1024 && (gen_at < 0 || gen_at == (long long)npairs)) {
