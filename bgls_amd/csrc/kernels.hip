@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items
   pts[item] = {x, y, false};
 }
 
-// per message: h * (sw_0 + sw_1) + special contributions, to affine
+// per message: h * (sw_0 + sw_1) + special contributions, to affine.  The sum is normalised once (one
+// Euclidean inversion) so that the 126-bit cofactor multiplication runs on a signed-digit (NAF) chain with
+// mixed additions: 125 doublings + 42 additions of 11 field products instead of 63 of 16.
 __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
   typedef BLS381 C;
   typedef F1<C> F;
@@ -266,7 +268,14 @@ __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS38
     else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
     else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
   }
-  Jac<F> r = jac_mul_jac<F>(sw, C::COFACTOR, C::COFACTOR_BITS);
+  const Aff<F> S = jac_to_aff<F>(sw);
+  const Aff<F> nS = aff_neg<F>(S);
+  Jac<F> r = jac_inf<F>();
+  for (int d = 0; d < C::COFACTOR_NAF_LEN; ++d) {
+    r = jac_dbl<F>(r);
+    const int dig = C::COFACTOR_NAF[d];
+    if (dig != 0) r = jac_add_aff<F>(r, dig > 0 ? S : nS);
+  }
   out[i] = jac_to_aff<F>(jac_add<F>(r, special));
 }
 

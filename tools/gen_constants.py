@@ -126,6 +126,9 @@ def main():
         o += arr("FT_ROOT1", limbs(root1, L)) + arr("FT_ROOT2", limbs(p_bls - root1, L))   # plain (compared before Montgomery conversion)
         o += arr("COFACTOR", limbs(cof, 4))
         o += "  static constexpr int COFACTOR_BITS = %d;\n" % cof.bit_length()
+        cn = naf(cof)
+        o += "  static constexpr int COFACTOR_NAF_LEN = %d;\n" % len(cn)
+        o += "  static constexpr int8_t COFACTOR_NAF[%d] = {%s};\n" % (len(cn), ", ".join(str(d) for d in cn))
         o += arr("R3", limbs((1 << (32 * L)) ** 3 % p_bls, L))    # to Montgomery-convert a 2L-limb value: redc(wide) * R3
         return o
 
