@@ -19,8 +19,11 @@ struct FE {
   static constexpr int SLOT = 12 * S2;
   static constexpr int NSLOT = 16;
   static constexpr int SCR = NSLOT * SLOT;            // 36 lanes x 3 wide products
-  static constexpr int LDS_DW = SCR + 36 * 3 * W;
+  static constexpr int SCR_DW = 36 * 3 * W;
+  static constexpr int LDS_DW = SCR + SCR_DW;
   static constexpr int LDS_BYTES = LDS_DW * 4;
+  static constexpr int LDS_BYTES2 = (SCR + 2 * SCR_DW) * 4;      // two waves, each with its own scratch (and its own slots)
+  __device__ static __forceinline__ int scr() { return SCR + (int)(threadIdx.x >> 6) * SCR_DW; }
   static constexpr int LAZY_K = Coop<C>::LAZY_K;
   __device__ static __forceinline__ int coef(int slot, int k, int xi) { return slot * SLOT + (2 * k + xi) * S2; }
 };
@@ -82,7 +85,7 @@ __device__ __noinline__ void fe_mul(int dst, int a, int b, bool want_xi = true) 
   const int lane = threadIdx.x & 63;
   const int j = lane / 6, t = lane % 6;
   const bool act = lane < 36;
-  const int o = E::SCR + lane * 3 * W;
+  const int o = E::scr() + lane * 3 * W;
   u32 v0[W], v1[W], s[W], tmp[W];
   if (act) {
     int k = j - t;
@@ -115,7 +118,7 @@ __device__ __noinline__ void fe_mul(int dst, int a, int b, bool want_xi = true) 
   }
   wave_sync();
   if (act && t < 2) {
-    const int base = E::SCR + (6 * j) * 3 * W;
+    const int base = E::scr() + (6 * j) * 3 * W;
 #pragma unroll
     for (int r = 1; r <= 2; ++r) {          // the two other partial sums (own ones are still in registers)
       int u = t + r;
@@ -186,7 +189,7 @@ __device__ __noinline__ void fe_cyclo_sqr(int dst, int a, bool want_xi = true) {
     for (int k = 0; k < W; ++k) t2[k] = tw[k] & md;
     w_add<W>(tw, tw, t2);                                   // imaginary part: 2 x0 x1
     Fp<C> r = redc<C>(tw);
-    u32* p = lds + E::SCR + sq * E::S2 + part * L;
+    u32* p = lds + E::scr() + sq * E::S2 + part * L;
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = r.v[k];
   }
@@ -197,9 +200,9 @@ __device__ __noinline__ void fe_cyclo_sqr(int dst, int a, bool want_xi = true) {
     // e0,e3 <- pair 0; e2,e5 <- pair 1; e1,e4 <- pair 2
     const int q = (k == 0 || k == 3) ? 0 : (k == 2 || k == 5) ? 1 : 2;
     const int off = im ? L : 0;
-    Fp<C> t0 = fp_load<C>(lds + E::SCR + (3 * q) * E::S2 + off);
-    Fp<C> t1 = fp_load<C>(lds + E::SCR + (3 * q + 1) * E::S2 + off);
-    Fp<C> t2 = fp_load<C>(lds + E::SCR + (3 * q + 2) * E::S2 + off);
+    Fp<C> t0 = fp_load<C>(lds + E::scr() + (3 * q) * E::S2 + off);
+    Fp<C> t1 = fp_load<C>(lds + E::scr() + (3 * q + 1) * E::S2 + off);
+    Fp<C> t2 = fp_load<C>(lds + E::scr() + (3 * q + 2) * E::S2 + off);
     Fp<C> z = fp_load<C>(lds + E::coef(a, k, 0) + off);
     Fp<C> c1 = fp_sub<C>(fp_sub<C>(t2, t0), t1);            // c1 = (A+B)^2 - A^2 - B^2
     const bool even = (k & 1) == 0;

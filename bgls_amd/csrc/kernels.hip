@@ -255,18 +255,28 @@ __global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items
 // per message: h * (sw_0 + sw_1) + special contributions, to affine.  The sum is normalised once (one
 // Euclidean inversion) so that the 126-bit cofactor multiplication runs on a signed-digit (NAF) chain with
 // mixed additions: 125 doublings + 42 additions of 11 field products instead of 63 of 16.
+//
+// RAW = true is the verification path's form: the cofactor is NOT cleared here.  The reduced ate pairing is
+// bilinear in its first argument on all of E(Fp), e(h S, Q) = e(S, Q)^h, so the whole batch shares ONE
+// exponentiation by h in GT (k_cofactor_epilogue) instead of n 126-bit scalar multiplications; the rare
+// "+-generator" outcomes enter as +-G1K, G1K = (h^-1 mod r) g1.
+template <bool RAW>
 __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
   typedef BLS381 C;
   typedef F1<C> F;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Jac<F> sw = jac_inf<F>(), special = jac_inf<F>();
-  const Aff<F> g1 = {fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+  const Aff<F> g1 = {fp_load<C>(RAW ? C::G1KX : C::G1X), fp_load<C>(RAW ? C::G1KY : C::G1Y), false};
   for (int k = 0; k < 2; ++k) {
     const uint32_t kind = kinds[2 * i + k];
     if (kind == H2C_SW) sw = jac_add_aff<F>(sw, pts[2 * i + k]);
     else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
     else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
+  }
+  if constexpr (RAW) {
+    out[i] = jac_to_aff<F>(jac_add<F>(sw, special));
+    return;
   }
   const Aff<F> S = jac_to_aff<F>(sw);
   const Aff<F> nS = aff_neg<F>(S);
@@ -1062,6 +1072,80 @@ __global__ void __launch_bounds__(64) k_final36(const uint8_t* partials, size_t 
   if (lane == 0) verdict[0] = (ball == ~0ull) ? 1u : 0u;
 }
 
+// BLS12-381 epilogue of the cofactor-in-GT verification path: out = miller(-sigma, g2) * rest^h, h = the G1
+// cofactor, where rest = prod_i miller(S_i, pk_i) over the UNCLEARED hash points (k_bls_combine<true>).  Both
+// factors are serial chains with no batch dimension, so they run side by side on the two waves of one block
+// with the 36-lane arithmetic of finalexp.hpp: wave 0 raises rest to h (general squarings -- rest is not
+// unitary before the final exponentiation), wave 1 walks the fixed-argument lines of g2 (k_gen_lines table)
+// for the signature pair.  The result is an ordinary partial product: the final exponentiation maps it to the
+// same GT element as the reference's prod e(H(m_i), pk_i) * e(-sigma, g2).
+template <class C>
+__global__ void __launch_bounds__(128) k_cofactor_epilogue(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines,
+                                                           uint8_t* out) {
+  typedef FE<C> E;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  enum { S_BASE = 0, S_ACC = 1, S_SIG = 8, S_LINE = 9 };
+  if (wave == 0) {
+    if (lane < 6) {
+      const Fp2<C> v = rest[lane];
+      fe_put<C>(S_BASE, lane, v);
+      fe_put<C>(S_ACC, lane, v);
+    }
+    wave_sync();
+    for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
+      fe_mul<C>(S_ACC, S_ACC, S_ACC);
+      if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) fe_mul<C>(S_ACC, S_ACC, S_BASE);
+    }
+  } else {
+    if (lane < 6) {
+      fe_put<C>(S_SIG, lane, lane == 0 ? f2_one<C>() : f2_zero<C>());
+      fe_put<C>(S_LINE, lane, f2_zero<C>());
+    }
+    wave_sync();
+    const bool have = sig != nullptr && !sig->inf;          // uniform
+    if (have) {
+      const Fp<C> xP = sig->x, yP = sig->y;
+      int step = 0;
+      auto apply = [&]() {
+        if (lane < 3) {
+          const LineCoeffs<C> l = gen_lines[step];
+          // D-type: c0 yP + c1 xP w + c2 w^3     M-type: c2 + c1 xP w^2 + c0 yP w^3   (coop.hpp COOP_SH_D / COOP_SH_M)
+          const Fp2<C> e = lane == 0 ? (C::TWIST_D ? f2_muls<C>(l.c0, yP) : l.c2)
+                         : lane == 1 ? f2_muls<C>(l.c1, xP)
+                                     : (C::TWIST_D ? l.c2 : f2_muls<C>(l.c0, yP));
+          const int k = lane == 0 ? 0 : lane == 1 ? (C::TWIST_D ? 1 : 2) : 3;
+          fe_put<C>(S_LINE, k, e);
+        }
+        ++step;
+        wave_sync();
+        fe_mul<C>(S_SIG, S_SIG, S_LINE);
+      };
+      for (int i = 1; i < C::LOOP_LEN; ++i) {
+        if (i > 1) fe_mul<C>(S_SIG, S_SIG, S_SIG);
+        apply();
+        if (C::LOOP_NAF[i] != 0) apply();
+      }
+      if constexpr (C::CURVE_ID == 0) {
+        apply();
+        apply();
+      } else {
+        fe_conj<C>(S_SIG, S_SIG);                            // x < 0
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    fe_mul<C>(S_ACC, S_ACC, S_SIG);
+    if (lane < 6) {
+      const int order_pos[6] = {5, 2, 4, 1, 3, 0};
+      const Fp2<C> v = lds_load_f2<C>(E::coef(S_ACC, lane, 0));
+      uint8_t* o = out + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+      fp_to_be<C>(o, fp_from_mont<C>(v.c1));
+      fp_to_be<C>(o + C::FP_BYTES, fp_from_mont<C>(v.c0));
+    }
+  }
+}
+
 // ======================================================================= host side
 namespace {
 
@@ -1209,6 +1293,7 @@ struct Engine {
   static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
                             int check_dups, uint8_t* d_partial, uint32_t* d_flags) {
     const size_t total = n + (d_sig ? 1 : 0);
+    const bool raw = bls_raw(n);          // BLS12-381: uncleared hash points, cofactor applied once in GT
     void *g1s, *fa, *fb;
     int rc;
     if ((rc = c.get(WS_G1S, (total + 1) * sizeof(Aff<G1F>), &g1s))) return rc;
@@ -1225,7 +1310,7 @@ struct Engine {
     }
     if (n) {
       Scope sc(c, st, ST_H2C);
-      int rc2 = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags);
+      int rc2 = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags, raw);
       if (rc2) return rc2;
     }
     if (d_sig) k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
@@ -1235,6 +1320,7 @@ struct Engine {
       HIPCHK(hipMemcpyAsync(d_partial + GTB - 1, &one, 1, hipMemcpyHostToDevice, st));
       return 0;
     }
+    if (raw) return miller_coop(c, st, (const Aff<G1F>*)g1s, d_keys, n, -1LL, d_partial, d_flags, true, d_sig ? (const Aff<G1F>*)g1s + n : nullptr);
     if (use_coop())
       return miller_coop(c, st, (const Aff<G1F>*)g1s, d_keys, total, d_sig ? (long long)n : -1LL, d_partial, d_flags);
     {
@@ -1246,7 +1332,11 @@ struct Engine {
     return reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, total, d_partial);
   }
 
-  static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags) {
+  // raw (BLS12-381 only, see bls_raw): points before cofactor clearing, for the cofactor-in-GT verification path
+  static bool bls_raw(size_t n) {
+    return C::CURVE_ID == 1 && use_coop() && n > 0 && (n >= 256 || h2c_mode() == 0) && !getenv("BGLS_G1_COFACTOR");
+  }
+  static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags, bool raw = false) {
     if constexpr (C::CURVE_ID == 0) {
       if (use_coop() && n < 256 && h2c_mode() == 0) {
         k_h2c_bn_jacobi<<<nblk(n, 64), 64, 0, st>>>(mv, n, out, d_flags);
@@ -1310,14 +1400,16 @@ struct Engine {
         };
         if (h2c_mode() == 0) {
           k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, (Aff<G1F>*)pts, (uint32_t*)kinds);
-          k_bls_combine<<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
+          if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
+        else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
           HIPCHK(hipGetLastError());
           return 0;
         }
         k_bls_sw<0><<<grid(items), 64, 0, st>>>(mv, items, nullptr, nullptr, L0, cn + 1, (Aff<G1F>*)pts, (uint32_t*)kinds);
         k_bls_sw<1><<<grid(items / 2 + items / 8), 64, 0, st>>>(mv, items, L0, cn + 1, L1, cn + 2, (Aff<G1F>*)pts, (uint32_t*)kinds);
         k_bls_sw<2><<<grid(items / 4 + items / 8), 64, 0, st>>>(mv, items, L1, cn + 2, L0, cn + 3, (Aff<G1F>*)pts, (uint32_t*)kinds);
-        k_bls_combine<<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
+        if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
+        else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, (const Aff<G1F>*)pts, (const uint32_t*)kinds, out);
         HIPCHK(hipGetLastError());
         return 0;
       }
@@ -1328,8 +1420,36 @@ struct Engine {
   }
 
   // wave-cooperative Miller product: groups of 6 lanes share one accumulator (coop.hpp)
+  static int ensure_gen_lines(Ctx& c, hipStream_t st) {
+    if (c.gen_lines[C::CURVE_ID]) return 0;
+    void *tab, *cnt;
+    int rc;
+    HIPCHK(hipMalloc(&tab, 160 * sizeof(LineCoeffs<C>)));
+    if ((rc = c.get(WS_OUT, 16, &cnt))) return rc;
+    k_gen_lines<C><<<1, 64, 0, st>>>((LineCoeffs<C>*)tab, (int*)cnt);
+    HIPCHK(hipGetLastError());
+    c.gen_lines[C::CURVE_ID] = tab;
+    return 0;
+  }
+  // serialise the reduced product; with `cofactor` (BLS12-381 raw hash points) raise it to h and fold the signature pair in
+  static int emit_partial(Ctx& c, hipStream_t st, const Fp2<C>* w, bool cofactor, const Aff<G1F>* sig, uint8_t* d_partial) {
+    if (!cofactor) {
+      k_w_to_bytes<C><<<1, 64, 0, st>>>(w, d_partial);
+    } else {
+      if constexpr (C::CURVE_ID == 1) {
+        int rc;
+        if ((rc = ensure_gen_lines(c, st))) return rc;
+        k_cofactor_epilogue<C><<<1, 128, FE<C>::LDS_BYTES2, st>>>(w, sig, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID], d_partial);
+      } else {
+        return fail(BGLS_ERR_ARG, "cofactor epilogue on a cofactor-1 curve");
+      }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
   static int miller_coop(Ctx& c, hipStream_t st, const Aff<G1F>* g1s, const uint8_t* g2s, size_t total, long long gen_at,
-                         uint8_t* d_partial, uint32_t* d_flags) {
+                         uint8_t* d_partial, uint32_t* d_flags, bool cofactor = false, const Aff<G1F>* cof_sig = nullptr) {
     typedef Coop<C> K;
     // 64 pairings per block / 256 registers: one 2^16 batch is exactly 1024 resident blocks
     {
@@ -1337,14 +1457,7 @@ struct Engine {
       const size_t nb64 = (npairs + 63) / 64;
       if (miller_mode() == 0 && !getenv("BGLS_NO_AB64") && nb64 >= 1 && nb64 <= 1024 && (gen_at < 0 || gen_at == (long long)npairs)) {
         int rc;
-        if (!c.gen_lines[C::CURVE_ID]) {
-          void *tab, *cnt;
-          HIPCHK(hipMalloc(&tab, 160 * sizeof(LineCoeffs<C>)));
-          if ((rc = c.get(WS_OUT, 16, &cnt))) return rc;
-          k_gen_lines<C><<<1, 64, 0, st>>>((LineCoeffs<C>*)tab, (int*)cnt);
-          HIPCHK(hipGetLastError());
-          c.gen_lines[C::CURVE_ID] = tab;
-        }
+        if ((rc = ensure_gen_lines(c, st))) return rc;
         void *pa, *pb;
         const size_t groups64 = nb64 * 10;
         if ((rc = c.get(WS_F_A, (groups64 + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
@@ -1365,9 +1478,7 @@ struct Engine {
           b = t;
           cnt = nout;
         }
-        k_w_to_bytes<C><<<1, 64, 0, st>>>(a, d_partial);
-        HIPCHK(hipGetLastError());
-        return 0;
+        return emit_partial(c, st, a, cofactor, cof_sig, d_partial);
       }
     }
     const size_t max_groups = 256 * 8 * K::GROUPS;                 // 8 resident waves per CU
@@ -1403,9 +1514,7 @@ struct Engine {
       b = t;
       cnt = nout;
     }
-    k_w_to_bytes<C><<<1, 64, 0, st>>>(a, d_partial);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return emit_partial(c, st, a, cofactor, cof_sig, d_partial);
   }
 
   static int reduce_to_bytes(hipStream_t st, Fp12<C>* a, Fp12<C>* b, size_t cnt, uint8_t* d_out) {

@@ -129,6 +129,30 @@ def main():
         cn = naf(cof)
         o += "  static constexpr int COFACTOR_NAF_LEN = %d;\n" % len(cn)
         o += "  static constexpr int8_t COFACTOR_NAF[%d] = {%s};\n" % (len(cn), ", ".join(str(d) for d in cn))
+        # G1K = (cof^-1 mod r) * g1: the verification path pairs UNCLEARED hash points and raises the product to
+        # the cofactor in GT instead (e(h S, Q) = e(S, Q)^h on all of E(Fp)), so the rare "+-generator" outcomes
+        # of the hash (curves/bls12_381.go:197-216) enter as +-G1K.
+        def ec_add(P, Q):
+            if P is None: return Q
+            if Q is None: return P
+            if P[0] == Q[0]:
+                if (P[1] + Q[1]) % p_bls == 0: return None
+                lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, p_bls) % p_bls
+            else:
+                lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p_bls) % p_bls
+            x3 = (lam * lam - P[0] - Q[0]) % p_bls
+            return (x3, (lam * (P[0] - x3) - P[1]) % p_bls)
+        def ec_mul(P, k):
+            R = None
+            for bit in bin(k)[2:]:
+                R = ec_add(R, R)
+                if bit == "1": R = ec_add(R, P)
+            return R
+        assert ec_mul((g1x, g1y), r_bls) is None
+        kinv = pow(cof, -1, r_bls)
+        g1k = ec_mul((g1x, g1y), kinv)
+        assert ec_mul(g1k, cof) == (g1x, g1y)
+        o += arr("G1KX", limbs(M(g1k[0]), L)) + arr("G1KY", limbs(M(g1k[1]), L))
         o += arr("R3", limbs((1 << (32 * L)) ** 3 % p_bls, L))    # to Montgomery-convert a 2L-limb value: redc(wide) * R3
         return o
 
