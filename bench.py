@@ -252,6 +252,9 @@ def main():
         macs_per_launch = (n + 1) * MILLER_FPMUL[cid] * MAC_PER_FPMUL[cid]
         achieved = macs_per_launch / mil_avg_s / 1e12 if mil_avg_s > 0 else 0.0
         value = world * n * args.steps / elapsed
+        cname = "BN254" if cid == 0 else "BLS381"
+        # the library's dispatch rule (Engine::miller_coop): 64 pairings per block while one launch stays resident
+        miller_kernel = ("k_miller_ab64<%s>" % cname) if (n + 63) // 64 <= 1024 else ("k_miller_coop<%s>" % cname)
         out = {
             "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -259,9 +262,11 @@ def main():
             "config": {"workload": "%s VerifyAggregateSignature, %d signers per GPU (%d total), distinct 64-byte messages, "
                                    "keys and messages resident in HBM" % (args.curve, n, world * n),
                        "curve": args.curve, "signers_per_gpu": n, "parallelism": "signer-shards x%d + all-gather of GT partials" % world},
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_miller", "achieved": achieved, "peak": peak.value / 1e12,
+            "roofline": {"bound": "valu-int32-mac", "kernel": miller_kernel, "achieved": achieved, "peak": peak.value / 1e12,
                          "unit": "TMAC/s", "frac": achieved / (peak.value / 1e12) if peak.value else None, "traffic": None,
                          "launch_ms": mil_avg_s * 1e3, "macs_per_launch": macs_per_launch,
+                         "hbm_side": {"achieved": n * ALGO_BYTES_PER_PAIR[cid] / mil_avg_s / 1e9 if mil_avg_s > 0 else None, "peak": 8000.0,
+                                      "unit": "GB/s", "note": "algorithmic bytes of one Miller launch / its duration"},
                          "note": "integer bignum path: bounded by v_mad_u64_u32 issue, not HBM or MFMA (SURVEY 8d); peak measured "
                                  "live by bgls_probe_mad_peak; HBM side: %.3f GB/s algorithmic of 8000 peak"
                                  % (value * ALGO_BYTES_PER_PAIR[cid] / world / 1e9),

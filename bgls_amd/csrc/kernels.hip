@@ -750,7 +750,9 @@ struct Coop64 {
 // multiplies its two lines into one 5-coefficient element (coop_write_line_pair).  Lanes 60..63 feed the
 // single-line slot of groups 0..3, the (-sigma, g2) line goes to the single slot of group 4, groups 5..9 keep
 // the constant 1 there.  The consumer folds 3 five-term elements + 1 three-term line per step.
-template <class C>
+// DBG (development only, BGLS_AB64_DBG): 1 = producer work only, 2 = consumer work only -- wrong results, used to
+// time the two halves of the pipeline separately.
+template <class C, int DBG = 0>
 __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
                                                         const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
   typedef Coop64<C> K;
@@ -798,6 +800,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
     int buf = 0, step = 0;
     auto publish = [&](LineCapture<C>& cap) {
+      if constexpr (DBG == 2) { ++step; __syncthreads(); buf ^= 1; return; }
       if (!valid) { cap.e[0] = f2_one<C>(); cap.e[1] = f2_zero<C>(); cap.e[2] = f2_zero<C>(); }
       const LReg r = {tgb + (buf ? K::RL2 : K::RL), K::NENT};
       if (paired) {
@@ -823,13 +826,13 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       {
         LineCapture<C> cap{{}, P.x, P.y};
-        dbl_step_emit<C>(T, cap);
+        if constexpr (DBG != 2) dbl_step_emit<C>(T, cap);
         publish(cap);
       }
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
         LineCapture<C> cap{{}, P.x, P.y};
-        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), cap);
+        if constexpr (DBG != 2) add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), cap);
         publish(cap);
       }
     }
@@ -838,14 +841,14 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
         Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
         Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
         LineCapture<C> cap{{}, P.x, P.y};
-        add_step_emit<C>(T, x1, y1, cap);
+        if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, cap);
         publish(cap);
       }
       {
         Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
         Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
         LineCapture<C> cap{{}, P.x, P.y};
-        add_step_emit<C>(T, x2, y2, cap);
+        if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, cap);
         publish(cap);
       }
     }
@@ -860,6 +863,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
     int buf = 0;
     auto fold = [&]() {
+      if constexpr (DBG == 1) { buf ^= 1; return; }
       const LReg rl = {gb + (buf ? K::RL2 : K::RL), K::NENT};
 #pragma unroll 1
       for (int m = 0; m < 3; ++m) {
@@ -873,8 +877,10 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();
-      fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
-      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
+      if constexpr (DBG != 1) {
+        fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
+        coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
+      }
       fold();
       if (C::LOOP_NAF[i] != 0) {
         __syncthreads();
@@ -1464,6 +1470,12 @@ struct Engine {
         if ((rc = c.get(WS_F_B, (groups64 / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
         {
           Scope sc(c, st, ST_MILLER);
+          const char* dbg = getenv("BGLS_AB64_DBG");
+          if (C::CURVE_ID == 0 && dbg && dbg[0] == '1')
+            k_miller_ab64<BN254, 1><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags);
+          else if (C::CURVE_ID == 0 && dbg && dbg[0] == '2')
+            k_miller_ab64<BN254, 2><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags);
+          else
           k_miller_ab64<C><<<(unsigned)nb64, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1s, g2s, npairs, gen_at, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID],
                                                                              (Fp2<C>*)pa, d_flags);
         }
