@@ -57,8 +57,9 @@ static uint64_t ror(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 #define G(a, b, c, d, x, y) do { v[a] += v[b] + (x); v[d] = ror(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 24); \
   v[a] += v[b] + (y); v[d] = ror(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 63); } while (0)
 
-void blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) {
-  uint64_t h[8]; memcpy(h, IV, sizeof h); h[0] ^= 0x01010040ull;
+/* BLAKE2b, unkeyed, explicit parameter words p[0..2] XORed into h[0..2] (RFC 7693 2.5); digest bytes = p0 & 0xff */
+static void blake2b_core(const uint8_t* in, size_t len, uint64_t p0, uint64_t p1, uint64_t p2, uint8_t* out, size_t outlen) {
+  uint64_t h[8]; memcpy(h, IV, sizeof h); h[0] ^= p0; h[1] ^= p1; h[2] ^= p2;
   size_t nblk = len == 0 ? 1 : (len + 127) / 128;
   for (size_t b = 0; b < nblk; b++) {
     uint8_t blk[128]; memset(blk, 0, 128);
@@ -74,5 +75,24 @@ void blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) {
       G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]); }
     for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
   }
-  for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(h[i] >> (8 * k));
+  uint8_t full[64];
+  for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) full[8 * i + k] = (uint8_t)(h[i] >> (8 * k));
+  memcpy(out, full, outlen);
+}
+
+void blake2b512(const uint8_t* in, size_t len, uint8_t out[64]) { blake2b_core(in, len, 0x01010040ull, 0, 0, out, 64); }
+
+/* BLAKE2Xb, unkeyed (golang.org/x/crypto/blake2b NewXOF(out_len, nil), called by bgls/blsHAE.go:81): root digest with the
+ * XOF length in parameter bytes 12..15, then block i = BLAKE2b(root; digest min(64, rest), fanout 0, depth 0, leaf 64,
+ * node offset i, XOF length, inner length 64). */
+int oracle_blake2xb(const uint8_t* in, size_t len, uint32_t out_len, uint8_t* out) {
+  uint8_t root[64];
+  blake2b_core(in, len, 0x01010040ull, (uint64_t)out_len << 32, 0, root, 64);
+  uint32_t got = 0, i = 0;
+  while (got < out_len) {
+    uint32_t take = out_len - got < 64 ? out_len - got : 64;
+    blake2b_core(root, 64, (uint64_t)take | (64ull << 32), (uint64_t)i | ((uint64_t)out_len << 32), 64ull << 8, out + got, take);
+    got += take; i++;
+  }
+  return 0;
 }

@@ -95,3 +95,39 @@ def gt_mul(curve, a, b):
     o = (ctypes.c_uint8 * (12 * FP[curve]))()
     assert lib().oracle_gt_mul(curve, _b(a), _b(b), o) == 0
     return bytes(o)
+
+
+# ---- hashed aggregation exponents / multiplicities (bgls/blsHAE.go, bgls/blsKosk.go:137-150), composed from the C pieces ----
+def blake2xb(data, out_len):
+    o = (ctypes.c_uint8 * max(1, out_len))()
+    assert lib().oracle_blake2xb(_b(data), ctypes.c_size_t(len(data)), ctypes.c_uint32(out_len), o) == 0
+    return bytes(o)[:out_len]
+
+
+def hae_exponents(curve, keys, n):
+    """blsHAE.go:80-93 over the uncompressed G2 wire bytes of the keys."""
+    raw = blake2xb(bytes(keys), 16 * n)
+    return [int.from_bytes(raw[16 * i:16 * i + 16], "big") for i in range(n)]
+
+
+def _scaled(curve, group, pts, n, ks):
+    size = (2 if group == 1 else 4) * FP[curve]
+    return b"".join(scale_point(curve, group, pts[i * size:(i + 1) * size], ks[i]) for i in range(n))
+
+
+def aggregate_signatures_hae(curve, sigs, keys, n):
+    return aggregate_points(curve, 1, _scaled(curve, 1, bytes(sigs), n, hae_exponents(curve, keys, n)), n)
+
+
+def verify_multi_hae(curve, sig, keys, n, msg):
+    apk = aggregate_points(curve, 2, _scaled(curve, 2, bytes(keys), n, hae_exponents(curve, keys, n)), n)
+    return verify_multi(curve, sig, apk, 1, msg)
+
+
+def verify_aggregate_hae(curve, sig, keys, msgs):
+    n = len(msgs)
+    return verify_aggregate(curve, sig, _scaled(curve, 2, bytes(keys), n, hae_exponents(curve, keys, n)), msgs, allow_dups=True)
+
+
+def verify_multi_multiplicity(curve, sig, keys, n, mult, msg):
+    return verify_multi(curve, sig, _scaled(curve, 2, bytes(keys), n, list(mult)), n, b"\x01" + msg)

@@ -67,3 +67,46 @@ def kosk_verify_multi_signature(curve, aggsig, keys, msg):
 
 def kosk_verify_aggregate_signature(curve, aggsig, keys, msgs):
     return verify_agg(curve, aggsig, keys, [b"\x01" + m for m in msgs], True)
+
+
+# ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---------------
+def hash_pubkeys_to_exponents(curve, keys):
+    """blsHAE.go:80-93: t_i = i-th 16-byte big-endian chunk of BLAKE2Xb(MarshalUncompressed(pk_0) || ... , 16 n)."""
+    from .hashes import blake2xb
+    G = pairing_for(curve).G
+    raw = blake2xb(b"".join(G.g2_bytes(k) for k in keys), 16 * len(keys))
+    return [int.from_bytes(raw[16 * i:16 * i + 16], "big") for i in range(len(keys))]
+
+
+def aggregate_signatures_hae(curve, sigs, keys):
+    """blsHAE.go:39-46 (nil on a length mismatch)."""
+    if len(sigs) != len(keys):
+        return None
+    G = pairing_for(curve).G
+    t = hash_pubkeys_to_exponents(curve, keys)
+    return G.g1_sum([G.g1_mul(s, k) for s, k in zip(sigs, t)])
+
+
+def verify_aggregate_signature_hae(curve, aggsig, keys, msgs):
+    """blsHAE.go:49-53: keys scaled by their exponents, duplicates allowed."""
+    G = pairing_for(curve).G
+    t = hash_pubkeys_to_exponents(curve, keys)
+    return verify_agg(curve, aggsig, [G.g2_mul(k, e) for k, e in zip(keys, t)], msgs, True)
+
+
+def verify_multi_signature_hae(curve, aggsig, keys, msg):
+    """blsHAE.go:56-58,74-77."""
+    G = pairing_for(curve).G
+    t = hash_pubkeys_to_exponents(curve, keys)
+    return verify_single(curve, aggsig, G.g2_sum([G.g2_mul(k, e) for k, e in zip(keys, t)]), msg)
+
+
+def kosk_verify_multi_signature_with_multiplicity(curve, aggsig, keys, multiplicity, msg):
+    """blsKosk.go:137-150; ScalePoints with a negative factor negates the point first (curves/curve.go:190-214)."""
+    if multiplicity is None:
+        return kosk_verify_multi_signature(curve, aggsig, keys, msg)
+    if len(keys) != len(multiplicity):
+        return False
+    G = pairing_for(curve).G
+    scaled = [G.g2_mul(G.g2_neg(k), -m) if m < 0 else G.g2_mul(k, m) for k, m in zip(keys, multiplicity)]
+    return kosk_verify_multi_signature(curve, aggsig, scaled, msg)
