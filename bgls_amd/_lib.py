@@ -24,6 +24,11 @@ SIGNATURES = {
     "bgls_verify_aggregate": (ci, [ci, u8p, u8p, u8p, u64p, sz, ci]),
     "bgls_verify_multi": (ci, [ci, u8p, u8p, sz, u8p, sz]),
     "bgls_pairing_product": (ci, [ci, u8p, u8p, sz, u8p]),
+    "bgls_hae_exponents": (ci, [ci, u8p, sz, u8p]),
+    "bgls_aggregate_signatures_hae": (ci, [ci, u8p, u8p, sz, u8p]),
+    "bgls_verify_multi_hae": (ci, [ci, u8p, u8p, sz, u8p, sz]),
+    "bgls_verify_aggregate_hae": (ci, [ci, u8p, u8p, u8p, u64p, sz]),
+    "bgls_verify_multi_multiplicity": (ci, [ci, u8p, u8p, ctypes.POINTER(ctypes.c_int64), sz, u8p, sz]),
     "bgls_hash_to_g1": (ci, [ci, u8p, u64p, sz, u8p]),
     "bgls_aggregate_points": (ci, [ci, ci, u8p, sz, u8p]),
     "bgls_scale_points": (ci, [ci, ci, u8p, u8p, u8p, sz, u8p]),

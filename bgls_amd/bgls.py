@@ -94,3 +94,73 @@ class MultiSig:                                               # bgls/bgls.go:15-
 
     def Verify(self, curve):
         return KoskVerifyMultiSignature(curve, self.sig, self.keys, self.msg)
+
+
+# ---- hashed aggregation exponents (bgls/blsHAE.go) -----------------------------------------------------------
+def _g2_keys_ok(curve, keys):
+    return all(isinstance(k, Point) and k.curve is curve and k.group == G2 for k in keys)
+
+
+def hashPubKeysToExponents(pubkeys):                          # bgls/blsHAE.go:80-93
+    if not pubkeys:
+        return []
+    curve = pubkeys[0].curve
+    o = _lib.out(16 * len(pubkeys))
+    rc = _lib.load().bgls_hae_exponents(curve.id, _lib.buf(b"".join(k.raw for k in pubkeys)), len(pubkeys), o)
+    if rc != 0:
+        raise RuntimeError("bgls_hae_exponents: %s" % _lib.last_error())
+    raw = bytes(o)
+    return [int.from_bytes(raw[16 * i:16 * i + 16], "big") for i in range(len(pubkeys))]
+
+
+def AggregateSignaturesWithHAE(sigs, pubkeys):                # bgls/blsHAE.go:39-46
+    if len(pubkeys) != len(sigs):
+        return None
+    if not sigs:
+        return AggregatePoints(sigs)
+    curve = sigs[0].curve
+    if not _g2_keys_ok(curve, pubkeys) or not all(isinstance(s, Point) and s.curve is curve and s.group == G1 for s in sigs):
+        return None
+    o = _lib.out(len(sigs[0].raw))
+    rc = _lib.load().bgls_aggregate_signatures_hae(curve.id, _lib.buf(b"".join(s.raw for s in sigs)),
+                                                   _lib.buf(b"".join(k.raw for k in pubkeys)), len(sigs), o)
+    return Point(curve, G1, bytes(o)) if rc == 0 else None
+
+
+def VerifyAggregateSignatureWithHAE(curve, aggsig, pubkeys, msgs):   # bgls/blsHAE.go:49-53
+    if len(pubkeys) != len(msgs) or not _g2_keys_ok(curve, pubkeys):
+        return False
+    if not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False
+    n = len(pubkeys)
+    off = (ctypes.c_uint64 * (n + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        off[i] = acc
+        acc += len(m)
+    off[n] = acc
+    rc = _lib.load().bgls_verify_aggregate_hae(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in pubkeys)),
+                                               _lib.buf(b"".join(bytes(m) for m in msgs)), off, n)
+    return rc == 1
+
+
+def VerifyMultiSignatureWithHAE(curve, aggsig, pubkeys, msg):        # bgls/blsHAE.go:56-58
+    if not _g2_keys_ok(curve, pubkeys) or not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False
+    rc = _lib.load().bgls_verify_multi_hae(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in pubkeys)), len(pubkeys),
+                                           _lib.buf(msg), len(msg))
+    return rc == 1
+
+
+def KoskVerifyMultiSignatureWithMultiplicity(curve, aggsig, keys, multiplicity, msg):   # bgls/blsKosk.go:137-150
+    if multiplicity is None:
+        return KoskVerifyMultiSignature(curve, aggsig, keys, msg)
+    if len(keys) != len(multiplicity):
+        return False
+    if not _g2_keys_ok(curve, keys) or not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False
+    m2 = b"\x01" + bytes(msg)
+    mult = (ctypes.c_int64 * max(1, len(keys)))(*[int(m) for m in multiplicity])
+    rc = _lib.load().bgls_verify_multi_multiplicity(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in keys)), mult,
+                                                    len(keys), _lib.buf(m2), len(m2))
+    return rc == 1

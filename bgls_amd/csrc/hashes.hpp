@@ -131,6 +131,31 @@ BGLS_HD void blake2b_g(u64 (&v)[16], int a, int b, int c, int d, u64 x, u64 y) {
   v[b] = rotr64(v[b] ^ v[c], 63);
 }
 
+// one compression (RFC 7693 3.2): h <- F(h, m, t, last)
+inline BGLS_FN void blake2b_compress(u64 (&h)[8], const u64 (&m)[16], u64 t, bool last) {
+  u64 v[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = h[i];
+    v[i + 8] = BLAKE2B_IV[i];
+  }
+  v[12] ^= t;
+  if (last) v[14] = ~v[14];
+  for (int r = 0; r < 12; ++r) {
+    const uint8_t* s = BLAKE2B_SIGMA[r];
+    blake2b_g(v, 0, 4, 8, 12, m[s[0]], m[s[1]]);
+    blake2b_g(v, 1, 5, 9, 13, m[s[2]], m[s[3]]);
+    blake2b_g(v, 2, 6, 10, 14, m[s[4]], m[s[5]]);
+    blake2b_g(v, 3, 7, 11, 15, m[s[6]], m[s[7]]);
+    blake2b_g(v, 0, 5, 10, 15, m[s[8]], m[s[9]]);
+    blake2b_g(v, 1, 6, 11, 12, m[s[10]], m[s[11]]);
+    blake2b_g(v, 2, 7, 8, 13, m[s[12]], m[s[13]]);
+    blake2b_g(v, 3, 4, 9, 14, m[s[14]], m[s[15]]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+
 // out_be[0..16): the 64 digest bytes as big-endian u32 words, out_be[0] most significant
 inline BGLS_FN void blake2b512(const ByteSrc& src, u32 (&out_be)[16]) {
   u64 h[8];
@@ -152,28 +177,7 @@ inline BGLS_FN void blake2b512(const ByteSrc& src, u32 (&out_be)[16]) {
       m[i] = w;
     }
     const bool last = (blk + 1 == nblk);
-    const u64 t = last ? (u64)total : (u64)(blk + 1) * 128;
-    u64 v[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] = h[i];
-      v[i + 8] = BLAKE2B_IV[i];
-    }
-    v[12] ^= t;
-    if (last) v[14] = ~v[14];
-    for (int r = 0; r < 12; ++r) {
-      const uint8_t* s = BLAKE2B_SIGMA[r];
-      blake2b_g(v, 0, 4, 8, 12, m[s[0]], m[s[1]]);
-      blake2b_g(v, 1, 5, 9, 13, m[s[2]], m[s[3]]);
-      blake2b_g(v, 2, 6, 10, 14, m[s[4]], m[s[5]]);
-      blake2b_g(v, 3, 7, 11, 15, m[s[6]], m[s[7]]);
-      blake2b_g(v, 0, 5, 10, 15, m[s[8]], m[s[9]]);
-      blake2b_g(v, 1, 6, 11, 12, m[s[10]], m[s[11]]);
-      blake2b_g(v, 2, 7, 8, 13, m[s[12]], m[s[13]]);
-      blake2b_g(v, 3, 4, 9, 14, m[s[14]], m[s[15]]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+    blake2b_compress(h, m, last ? (u64)total : (u64)(blk + 1) * 128, last);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -181,6 +185,32 @@ inline BGLS_FN void blake2b512(const ByteSrc& src, u32 (&out_be)[16]) {
     out_be[2 * i] = __builtin_bswap32(lo);
     out_be[2 * i + 1] = __builtin_bswap32(hi);
   }
+}
+
+// ---- BLAKE2Xb, unkeyed (golang.org/x/crypto/blake2b NewXOF(size, nil), the hash of bgls/blsHAE.go:80-93) ----
+// Root: BLAKE2b-512 of the input whose parameter block carries the XOF length in bytes 12..15 (h[1] ^= len << 32).
+// The root is a sequential chain over the whole input, so it is computed where the bytes are produced (host side of
+// the boundary, blake2xb_root); the expansion nodes are independent and run one per lane (k_blake2x_expand).
+BGLS_HD void blake2xb_root_init(u64 (&h)[8], u32 xof_len) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = BLAKE2B_IV[i];
+  h[0] ^= 0x01010040ull;
+  h[1] ^= (u64)xof_len << 32;
+}
+// node i: BLAKE2b(root; digest = take, fanout 0, depth 0, leaf length 64, node offset i, XOF length, inner length 64)
+inline BGLS_FN void blake2xb_node(const u64 (&root)[8], u32 i, u32 xof_len, u32 take, u64 (&out)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[k] = BLAKE2B_IV[k];
+  out[0] ^= (u64)take | (64ull << 32);
+  out[1] ^= (u64)i | ((u64)xof_len << 32);
+  out[2] ^= 64ull << 8;
+  u64 m[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    m[k] = root[k];
+    m[k + 8] = 0;
+  }
+  blake2b_compress(out, m, 64, true);
 }
 
 }  // namespace bgls

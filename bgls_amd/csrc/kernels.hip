@@ -424,7 +424,7 @@ __global__ void k_jac_to_bytes(const Jac<F>* in, size_t n, uint8_t* out, int pt_
 // ---- ScalePoints ----
 template <class F, int PT_BYTES>
 __global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
-                                              uint8_t* out, uint32_t* flags) {
+                                              uint8_t* out, uint32_t* flags, int sbytes = 32) {   // sbytes: 32 or 16, big-endian
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff<F> p;
@@ -437,17 +437,68 @@ __global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t*
     return;
   }
   u32 k[8];
-  const uint8_t* s = scalars + i * 32;
+  const uint8_t* s = scalars + i * (size_t)sbytes;
+  const int nw = sbytes / 4;
   int top = -1;
   for (int j = 0; j < 8; ++j) {
-    const uint8_t* q = s + 4 * (7 - j);
-    k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    k[j] = 0;
+    if (j < nw) {
+      const uint8_t* q = s + 4 * (nw - 1 - j);
+      k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
   }
   for (int j = 7; j >= 0 && top < 0; --j)
     if (k[j]) top = j * 32 + (31 - __clz(k[j]));
   if (sg == 1) p = aff_neg<F>(p);
   Jac<F> r = jac_mul<F>(p, k, top + 1);
   aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(r));
+}
+
+// ---- hashed aggregation exponents (bgls/blsHAE.go) and weighted key sums ----
+// BLAKE2Xb expansion: node i of the XOF is one compression of the 64-byte root with its own parameter block
+// (hashes.hpp blake2xb_node); one lane per node.  The root itself is a sequential chain over all key bytes and is
+// produced on the host side of the boundary (host_blake2xb_root below).
+__global__ void __launch_bounds__(64) k_blake2x_expand(const u64* root, u32 xof_len, uint8_t* out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nnodes = (xof_len + 63u) / 64u;
+  if (i >= nnodes) return;
+  u64 r[8], o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = root[k];
+  const u32 rest = xof_len - 64u * i;
+  const u32 take = rest < 64u ? rest : 64u;
+  blake2xb_node(r, i, xof_len, take, o);
+  for (u32 b = 0; b < take; ++b) out[(size_t)64 * i + b] = (uint8_t)(o[b >> 3] >> (8 * (b & 7)));
+}
+
+// First pass of sum_i k_i P_i: getAggregatePubKey (blsHAE.go:74-77) = AggregatePoints(ScalePoints(keys, t)) without
+// materialising the scaled points: thread t accumulates its R products in Jacobian form.  Weights are 16-byte
+// big-endian magnitudes with optional sign bytes (1 = negate the point first, curves/curve.go:190-214).
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_wsum_first(const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, int R,
+                                                   Jac<F>* out, uint32_t* flags) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = jac_inf<F>();
+  for (size_t i = lo; i < hi; ++i) {
+    Aff<F> p;
+    bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+    ok = ok && aff_on_curve<F>(p);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+    u32 k[4];
+    int top = -1;
+    for (int j = 0; j < 4; ++j) {
+      const uint8_t* q = w16 + i * 16 + 4 * (3 - j);
+      k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    for (int j = 3; j >= 0 && top < 0; --j)
+      if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+    if (signs && signs[i] == 1) p = aff_neg<F>(p);
+    acc = jac_add<F>(acc, jac_mul<F>(p, k, top + 1));
+  }
+  out[t] = acc;
 }
 
 template <class F, int PT_BYTES>
@@ -1211,7 +1262,7 @@ struct Ctx {
     if (device >= cnt) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreate(&stream));
-    ws.assign(24, {nullptr, 0});
+    ws.assign(40, {nullptr, 0});   // >= WS_NUM
     ready = true;
     return 0;
   }
@@ -1284,7 +1335,7 @@ struct Scope {  // brackets the launches of one stage with events when profiling
 };
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_NUM };
 
 inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -1941,6 +1992,230 @@ int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, co
   return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len);
 }
 
+// ---- hashed aggregation exponents / weighted sums: host flows -------------------------------------------------
+// Root digest of BLAKE2Xb (hashes.hpp has the device-side tables; these are the host's own copies).  One sequential
+// compression chain over all key bytes -- by construction not parallel -- computed while the keys travel to the device.
+namespace host_blake2 {
+const uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                        0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+const uint8_t SIGMA[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+inline uint64_t ror(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+inline void compress(uint64_t h[8], const uint8_t* block, uint64_t t, bool last) {
+  uint64_t m[16], v[16];
+  memcpy(m, block, 128);                                     // little-endian host
+  for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+  v[12] ^= t;
+  if (last) v[14] = ~v[14];
+#define BGLS_G(a, b, c, d, x, y)                                                    \
+  v[a] += v[b] + (x); v[d] = ror(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 24); \
+  v[a] += v[b] + (y); v[d] = ror(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 63);
+  for (int r = 0; r < 12; ++r) {
+    const uint8_t* s = SIGMA[r];
+    BGLS_G(0, 4, 8, 12, m[s[0]], m[s[1]]) BGLS_G(1, 5, 9, 13, m[s[2]], m[s[3]])
+    BGLS_G(2, 6, 10, 14, m[s[4]], m[s[5]]) BGLS_G(3, 7, 11, 15, m[s[6]], m[s[7]])
+    BGLS_G(0, 5, 10, 15, m[s[8]], m[s[9]]) BGLS_G(1, 6, 11, 12, m[s[10]], m[s[11]])
+    BGLS_G(2, 7, 8, 13, m[s[12]], m[s[13]]) BGLS_G(3, 4, 9, 14, m[s[14]], m[s[15]])
+  }
+#undef BGLS_G
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+// h <- BLAKE2Xb root of data[0..len) for an XOF of xof_len bytes (x/crypto/blake2b/blake2x.go Reset + Write + finalize)
+void xb_root(const uint8_t* data, size_t len, uint32_t xof_len, uint64_t h[8]) {
+  for (int i = 0; i < 8; ++i) h[i] = IV[i];
+  h[0] ^= 0x01010040ull;
+  h[1] ^= (uint64_t)xof_len << 32;
+  size_t off = 0;
+  while (len - off > 128) {
+    compress(h, data + off, (uint64_t)off + 128, false);
+    off += 128;
+  }
+  uint8_t lastb[128];
+  memset(lastb, 0, 128);
+  if (len > off) memcpy(lastb, data + off, len - off);
+  compress(h, lastb, (uint64_t)len, true);
+}
+}  // namespace host_blake2
+
+// d_t (WS_HAE_T) <- the n 16-byte exponents of hashPubKeysToExponents (blsHAE.go:80-93) for the keys' wire bytes
+template <class C>
+int hae_exponents_dev(Ctx& c, hipStream_t st, const uint8_t* h_keys, size_t n, void** d_t) {
+  typedef Engine<C> E;
+  if (n >= (1ull << 28)) return fail(BGLS_ERR_ARG, "XOF length 16 n must fit a uint32 (blsHAE.go:81)");
+  int rc;
+  void* d_root;
+  if ((rc = c.get(WS_HAE_ROOT, 64, &d_root))) return rc;
+  if ((rc = c.get(WS_HAE_T, n * 16, d_t))) return rc;
+  if (n == 0) return 0;
+  uint64_t root[8];
+  const uint32_t xof_len = (uint32_t)(16 * n);
+  host_blake2::xb_root(h_keys, n * E::G2B, xof_len, root);
+  HIPCHK(hipMemcpyAsync(d_root, root, 64, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));                          // root[] is a stack buffer
+  k_blake2x_expand<<<nblk((xof_len + 63) / 64, 64), 64, 0, st>>>((const u64*)d_root, xof_len, (uint8_t*)*d_t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <class C>
+int hae_exponents_t(const uint8_t* keys, size_t n, uint8_t* t_out) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  void* d_t;
+  if ((rc = hae_exponents_dev<C>(c, c.stream, keys, n, &d_t))) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(t_out, d_t, n * 16, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// d_out (affine bytes) <- sum_i w_i P_i over device-resident points and 16-byte weights
+template <class C, class F, int PTB>
+int weighted_sum_dev(Ctx& c, hipStream_t st, const uint8_t* d_pts, const uint8_t* d_w16, const uint8_t* d_signs, size_t n,
+                     uint8_t* d_out, uint32_t* d_flags) {
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
+    return 0;
+  }
+  const int R = 16;
+  void *ja, *jb;
+  int rc;
+  Scope sc(c, st, ST_SUM);
+  if ((rc = c.get(WS_JAC_A, (n + 1) * sizeof(Jac<F>), &ja))) return rc;
+  if ((rc = c.get(WS_JAC_B, (n / R + 2) * sizeof(Jac<F>), &jb))) return rc;
+  k_wsum_first<F, PTB><<<nblk(n, 64), 64, 0, st>>>(d_pts, d_w16, d_signs, n, 1, (Jac<F>*)ja, d_flags);
+  Jac<F>*a = (Jac<F>*)ja, *b = (Jac<F>*)jb;
+  size_t cnt = n;
+  while (cnt > 1) {
+    size_t nout = (cnt + R - 1) / R;
+    k_sum_next<F><<<nblk(nout, 64), 64, 0, st>>>(a, cnt, R, b);
+    Jac<F>* t = a;
+    a = b;
+    b = t;
+    cnt = nout;
+  }
+  k_jac_to_bytes<F><<<1, 64, 0, st>>>(a, 1, d_out, PTB);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// verify_multi with apk = sum w_i pk_i: VerifyMultiSignatureWithHAE (blsHAE.go:56-58; weights hashed from the keys) when
+// mult == nullptr, the core of KoskVerifyMultiSignatureWithMultiplicity (blsKosk.go:137-150) otherwise.
+template <class C>
+int verify_multi_weighted_t(const uint8_t* sig, const uint8_t* keys, const int64_t* mult, size_t n, const uint8_t* msg, size_t msg_len) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sig, *d_keys, *d_msg, *d_apk, *d_fl2, *d_t = nullptr, *d_sg = nullptr;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, msg_len, &d_msg))) return rc;
+  if ((rc = c.get(WS_HAE_APK, E::G2B, &d_apk))) return rc;
+  if ((rc = c.get(WS_FLAGS2, 16, &d_fl2))) return rc;
+  HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (msg_len) HIPCHK(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+  if (!mult) {
+    if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  } else {
+    std::vector<uint8_t> w(n * 16, 0), sg(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      const int64_t m = mult[i];
+      uint64_t mag = m < 0 ? (uint64_t)0 - (uint64_t)m : (uint64_t)m;
+      sg[i] = m < 0 ? 1 : 0;
+      for (int b = 0; b < 8; ++b) w[i * 16 + 15 - b] = (uint8_t)(mag >> (8 * b));
+    }
+    if ((rc = c.get(WS_HAE_T, n * 16, &d_t))) return rc;
+    if ((rc = c.get(WS_HAE_SIGN, n, &d_sg))) return rc;
+    if (n) {
+      HIPCHK(hipMemcpyAsync(d_t, w.data(), n * 16, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(d_sg, sg.data(), n, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));                      // w, sg are locals
+    }
+  }
+  if ((rc = weighted_sum_dev<C, F2<C>, (int)E::G2B>(c, st, (const uint8_t*)d_keys, (const uint8_t*)d_t, (const uint8_t*)d_sg, n,
+                                                   (uint8_t*)d_apk, (uint32_t*)d_fl2)))
+    return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_fl2, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if ((rc = flags_to_rc(f))) return rc;
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_apk, 1, (const uint8_t*)d_msg, msg_len);
+}
+
+// VerifyAggregateSignatureWithHAE (blsHAE.go:49-53): keys scaled by their exponents, then verifyAggSig with duplicates allowed
+template <class C>
+int verify_aggregate_hae_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* blob, const uint64_t* off, size_t n) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = n ? off[n] : 0;
+  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part, *d_scaled, *d_t;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  if ((rc = c.get(WS_HAE_KEYS, n * E::G2B, &d_scaled))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  if (n) {
+    k_scale<F2<C>, (int)E::G2B><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_keys, (const uint8_t*)d_t, nullptr, n, (uint8_t*)d_scaled,
+                                                             (uint32_t*)d_flags, 16);
+    HIPCHK(hipGetLastError());
+  }
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_scaled, mv, n, 0, (uint8_t*)d_part, (uint32_t*)d_flags)))
+    return rc;
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+// AggregateSignaturesWithHAE (blsHAE.go:39-46): sum_i t_i sigma_i
+template <class C>
+int aggregate_signatures_hae_t(const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sigs, *d_out, *d_flags, *d_t;
+  if ((rc = c.get(WS_IN_B, n * E::G1B, &d_sigs))) return rc;
+  if ((rc = c.get(WS_OUT, E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_sigs, sigs, n * E::G1B, hipMemcpyHostToDevice, st));
+  if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  if ((rc = weighted_sum_dev<C, F1<C>, (int)E::G1B>(c, st, (const uint8_t*)d_sigs, (const uint8_t*)d_t, nullptr, n, (uint8_t*)d_out,
+                                                   (uint32_t*)d_flags)))
+    return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
 bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
 
 }  // namespace
@@ -2109,6 +2384,35 @@ int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size
                           void* stream) {
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
+}
+
+/* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */
+int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out) {
+  if (n && (!keys || !t_out)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, hae_exponents_t<CV>(keys, n, t_out));
+}
+
+int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+  if (!out || (n && (!sigs || !keys))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, aggregate_signatures_hae_t<CV>(sigs, keys, n, out));
+}
+
+int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, nullptr, n, msg, msg_len));
+}
+
+int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                              size_t n) {
+  if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_aggregate_hae_t<CV>(sig, keys, msg_blob, msg_off, n));
+}
+
+int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity, size_t n,
+                                   const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (!multiplicity) DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
+  DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, multiplicity, n, msg, msg_len));
 }
 
 }  // extern "C"

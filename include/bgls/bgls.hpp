@@ -75,4 +75,68 @@ inline bool KoskVerifyMultiSignature(const CurveSystem* curve, const Point& aggs
   return verifyMultiSignature(curve, aggsig, keys, m);
 }
 
+// ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ----
+namespace detail {
+inline bool g2_bytes(const CurveSystem* curve, const std::vector<Point>& keys, Bytes& kb) {
+  for (const Point& k : keys) {
+    if (k.curve != curve || k.group != BGLS_G2) return false;
+    kb.insert(kb.end(), k.raw.begin(), k.raw.end());
+  }
+  return true;
+}
+}  // namespace detail
+// hashPubKeysToExponents, bgls/blsHAE.go:80-93: n exponents as 16-byte big-endian strings
+inline std::vector<Bytes> hashPubKeysToExponents(const std::vector<Point>& pubkeys) {
+  std::vector<Bytes> t;
+  if (pubkeys.empty()) return t;
+  Bytes kb, out(16 * pubkeys.size());
+  if (!detail::g2_bytes(pubkeys[0].curve, pubkeys, kb)) return t;
+  if (bgls_hae_exponents(pubkeys[0].curve->id, kb.data(), pubkeys.size(), out.data()) != 0) return t;
+  for (size_t i = 0; i < pubkeys.size(); ++i) t.emplace_back(out.begin() + 16 * i, out.begin() + 16 * (i + 1));
+  return t;
+}
+// AggregateSignaturesWithHAE, bgls/blsHAE.go:39-46 (invalid Point = nil on a length mismatch)
+inline Point AggregateSignaturesWithHAE(const std::vector<Point>& sigs, const std::vector<Point>& pubkeys) {
+  if (sigs.size() != pubkeys.size() || sigs.empty()) return Point{};
+  const CurveSystem* curve = sigs[0].curve;
+  Bytes sb, kb;
+  for (const Point& s : sigs) {
+    if (s.curve != curve || s.group != BGLS_G1) return Point{};
+    sb.insert(sb.end(), s.raw.begin(), s.raw.end());
+  }
+  if (!detail::g2_bytes(curve, pubkeys, kb)) return Point{};
+  Bytes out(curve->size(BGLS_G1));
+  if (bgls_aggregate_signatures_hae(curve->id, sb.data(), kb.data(), sigs.size(), out.data()) != 0) return Point{};
+  return Point{curve, BGLS_G1, out};
+}
+// VerifyAggregateSignatureWithHAE, bgls/blsHAE.go:49-53
+inline bool VerifyAggregateSignatureWithHAE(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& pubkeys,
+                                            const std::vector<Bytes>& msgs) {
+  if (pubkeys.size() != msgs.size() || aggsig.curve != curve || aggsig.group != BGLS_G1) return false;
+  Bytes kb, blob;
+  if (!detail::g2_bytes(curve, pubkeys, kb)) return false;
+  std::vector<uint64_t> off(msgs.size() + 1, 0);
+  for (size_t i = 0; i < msgs.size(); ++i) {
+    blob.insert(blob.end(), msgs[i].begin(), msgs[i].end());
+    off[i + 1] = blob.size();
+  }
+  return bgls_verify_aggregate_hae(curve->id, aggsig.raw.data(), kb.data(), blob.data(), off.data(), msgs.size()) == 1;
+}
+// VerifyMultiSignatureWithHAE, bgls/blsHAE.go:56-58
+inline bool VerifyMultiSignatureWithHAE(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& pubkeys, const Bytes& msg) {
+  Bytes kb;
+  if (aggsig.curve != curve || aggsig.group != BGLS_G1 || !detail::g2_bytes(curve, pubkeys, kb)) return false;
+  return bgls_verify_multi_hae(curve->id, aggsig.raw.data(), kb.data(), pubkeys.size(), msg.data(), msg.size()) == 1;
+}
+// KoskVerifyMultiSignatureWithMultiplicity, bgls/blsKosk.go:137-150 (multiplicity == nullptr: plain KoskVerifyMultiSignature)
+inline bool KoskVerifyMultiSignatureWithMultiplicity(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys,
+                                                     const std::vector<int64_t>* multiplicity, const Bytes& msg) {
+  if (!multiplicity) return KoskVerifyMultiSignature(curve, aggsig, keys, msg);
+  if (keys.size() != multiplicity->size()) return false;
+  Bytes kb, m(1, 1);
+  if (aggsig.curve != curve || aggsig.group != BGLS_G1 || !detail::g2_bytes(curve, keys, kb)) return false;
+  m.insert(m.end(), msg.begin(), msg.end());
+  return bgls_verify_multi_multiplicity(curve->id, aggsig.raw.data(), kb.data(), multiplicity->data(), keys.size(), m.data(), m.size()) == 1;
+}
+
 }  // namespace bgls_go

@@ -99,6 +99,30 @@ int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, ui
 int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs,
                       size_t n, uint8_t* out);
 
+/* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */
+/* hashPubKeysToExponents (bgls/blsHAE.go:80-93): t_out = n 16-byte big-endian exponents read from BLAKE2Xb
+ * (golang.org/x/crypto/blake2b NewXOF(16 n, nil)) over MarshalUncompressed(pk_0) || ... || pk_{n-1}, i.e. over the
+ * n x bgls_g2_size bytes of `keys` (curves/altbn128.go:223-225; BLS12-381's upstream layout is unpinned).
+ * The root digest is one sequential compression chain over all key bytes (host side of the boundary); the XOF
+ * expansion runs on the device.  n < 2^28 (the XOF length is a uint32). */
+int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out);
+/* AggregateSignaturesWithHAE (bgls/blsHAE.go:39-46): out = sum_i t_i * sigs[i] (G1); the caller checks the lengths. */
+int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out);
+/* VerifyMultiSignatureWithHAE (bgls/blsHAE.go:56-58) -> getAggregatePubKey (:74-77): apk = sum_i t_i * keys[i], then
+ * VerifySingleSignature (bgls/bgls.go:59-70). */
+int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg,
+                          size_t msg_len);
+/* VerifyAggregateSignatureWithHAE (bgls/blsHAE.go:49-53): keys scaled by their exponents (ScalePoints), then
+ * verifyAggSig with duplicate messages allowed. */
+int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob,
+                              const uint64_t* msg_off, size_t n);
+/* verifyMultiSignature over ScalePoints(keys, multiplicity) -- the body of KoskVerifyMultiSignatureWithMultiplicity
+ * (bgls/blsKosk.go:137-150; that function prepends 0x01 to msg like KoskVerifyMultiSignature, the host mirror does
+ * the same).  multiplicity: n int64 factors, negative = negate-then-multiply (curves/curve.go:190-214); NULL = plain
+ * bgls_verify_multi. */
+int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity,
+                                   size_t n, const uint8_t* msg, size_t msg_len);
+
 /* ---- per-point operations backing the Go Point / PointT methods --------------------------- */
 /* Point.Add (curves/altbn128.go:59-66,181-188; curves/bls12_381.go:33-41,94-102) */
 int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out);

@@ -64,9 +64,42 @@ static void TestKoskMultiSig(const CurveSystem* curve) {
   CHECK(idt.second && idt.first.Equals(curve->GetGTIdentity()), "Pair(g1, inf) must be the GT identity");
 }
 
+// bgls/blsHAE_test.go:58-82 TestMultiSigWithHAE + :14-56 TestAggregationWithHAE (one trial each) and the multiplicity path
+static void TestHAE(const CurveSystem* curve) {
+  const int Signers = 6;
+  Bytes msg = randBytes(32);
+  std::vector<Point> signers, sigs;
+  for (int j = 0; j < Signers; ++j) { Bytes sk = randScalar(); sigs.push_back(Sign(curve, sk, msg)); signers.push_back(LoadPublicKey(curve, sk)); }
+  CHECK(hashPubKeysToExponents(signers).size() == (size_t)Signers, "exponent count");
+  Point aggSig = AggregateSignaturesWithHAE(sigs, signers);
+  CHECK(aggSig.valid() && VerifyMultiSignatureWithHAE(curve, aggSig, signers, msg), "HAE MultiSig verification failed");
+  CHECK(!VerifyMultiSignatureWithHAE(curve, aggSig, signers, randBytes(32)), "HAE MultiSig succeeded on incorrect msg");
+  CHECK(!VerifyMultiSignatureWithHAE(curve, AggregateSignatures(sigs), signers, msg), "plain aggregate accepted by the HAE verifier");
+  std::vector<Point> fewer(signers.begin(), signers.end() - 1);
+  CHECK(!AggregateSignaturesWithHAE(sigs, fewer).valid(), "aggregation succeeded with differing numbers of signatures and pubkeys");
+  std::vector<Bytes> msgs; std::vector<Point> s2;
+  for (int j = 0; j < Signers; ++j) { msgs.push_back(j == Signers - 1 ? msgs[0] : randBytes(32)); }
+  std::vector<Bytes> sks; std::vector<Point> pk2;
+  for (int j = 0; j < Signers; ++j) { Bytes sk = randScalar(); s2.push_back(Sign(curve, sk, msgs[j])); pk2.push_back(LoadPublicKey(curve, sk)); }
+  Point agg2 = AggregateSignaturesWithHAE(s2, pk2);
+  CHECK(VerifyAggregateSignatureWithHAE(curve, agg2, pk2, msgs), "HAE aggregate failing with duplicate messages");
+  std::vector<Bytes> sw = msgs; sw[1] = msgs[2]; sw[2] = msgs[1];
+  CHECK(!VerifyAggregateSignatureWithHAE(curve, agg2, pk2, sw), "HAE aggregate succeeded with messages switched");
+  // multiplicities
+  std::vector<int64_t> mult = {2, 1, -1, 0, 3, 1};
+  std::vector<Point> ks, scaled;
+  Bytes kmsg = randBytes(32);
+  std::vector<Point> ksign;
+  for (int j = 0; j < Signers; ++j) { Bytes sk = randScalar(); ks.push_back(LoadPublicKey(curve, sk)); scaled.push_back(KoskSign(curve, sk, kmsg).MulInt(mult[j])); }
+  Point am = AggregateSignatures(scaled);
+  CHECK(KoskVerifyMultiSignatureWithMultiplicity(curve, am, ks, &mult, kmsg), "multiplicity verification failed");
+  mult[0] += 1;
+  CHECK(!KoskVerifyMultiSignatureWithMultiplicity(curve, am, ks, &mult, kmsg), "multiplicity verification succeeded on wrong factors");
+}
+
 int main() {
   if (bgls_init(0) != 0) { std::printf("bgls_init: %s\n", bgls_last_error()); return 2; }
-  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); }
+  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); TestHAE(curve); }
   std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -5,6 +5,8 @@
                      curves/testcases/altbn128G1Hash.dat, curves/testcases/bls12G1Hash.dat,
                      curves/altbn128_test.go:16-21 (Solidity point), curves/bls12_test.go:57-67,
                      curves/altbn128_test.go:26-38 (G2 generator coordinates).
+ hae_<curve>.json    BLAKE2Xb outputs, hashed aggregation exponents and accept/reject cases of the HAE /
+                     multiplicity flows (bgls/blsHAE.go, bgls/blsKosk.go:137-150) from the Python oracle.
  vectors_<curve>.json  outputs of the Python oracle (oracle/pyref) on seeded inputs: Miller / GT
                      values, pairing products, group sums, scalar multiples, extra hash-to-G1
                      messages, end-to-end accept/reject cases mirroring bgls/bgls_test.go:40-77 and
@@ -123,8 +125,73 @@ def vectors(c, seed):
     json.dump(v, open(os.path.join(HERE, "vectors_%s.json" % c.name), "w"), indent=0)
 
 
+def hae(c, seed):
+    """hae_<curve>.json: BLAKE2Xb vectors, hashPubKeysToExponents, and accept/reject cases mirroring
+    bgls/blsHAE_test.go:14-82 and bgls/blsKosk_test.go:66-94, all from the Python oracle."""
+    from oracle.pyref import hashes
+    rnd = random.Random(seed)
+    PR = Pairing(c); G = PR.G
+    v = {"curve": c.name, "xof": []}
+    for ln, ol in ((0, 16), (1, 1), (64, 64), (128, 65), (129, 160), (1000, 333)):
+        d = rnd.randbytes(ln)
+        v["xof"].append({"in": d.hex(), "out_len": ol, "out": hashes.blake2xb(d, ol).hex()})
+    n = 5
+    sks = [rnd.randrange(1, c.r) for _ in range(n + 1)]
+    keys = [scheme.load_public_key(c, sk) for sk in sks]
+    kb = lambda ks: [G.g2_bytes(k).hex() for k in ks]
+    v["exponents"] = {"keys": kb(keys[:n]), "t": ["%032x" % t for t in scheme.hash_pubkeys_to_exponents(c, keys[:n])]}
+    # multi-signature with HAE (TestMultiSigWithHAE)
+    msg = rnd.randbytes(32)
+    sigs = [scheme.sign(c, sk, msg) for sk in sks[:n]]
+    agg = scheme.aggregate_signatures_hae(c, sigs, keys[:n])
+    v["aggregate_signatures"] = {"sigs": [G.g1_bytes(s).hex() for s in sigs], "keys": kb(keys[:n]), "out": G.g1_bytes(agg).hex()}
+    mc = [{"name": "valid", "sig": G.g1_bytes(agg).hex(), "keys": kb(keys[:n]), "msg": msg.hex(), "expect": True},
+          {"name": "wrong_msg", "sig": G.g1_bytes(agg).hex(), "keys": kb(keys[:n]), "msg": rnd.randbytes(32).hex(), "expect": False},
+          {"name": "wrong_signer", "sig": G.g1_bytes(agg).hex(), "keys": kb([keys[n]] + keys[1:n]), "msg": msg.hex(), "expect": False},
+          {"name": "plain_aggregate_rejected", "sig": G.g1_bytes(G.g1_sum(sigs)).hex(), "keys": kb(keys[:n]), "msg": msg.hex(), "expect": False}]
+    for c_ in mc:
+        got = scheme.verify_multi_signature_hae(c, G.g1_from_bytes(bytes.fromhex(c_["sig"])), [G.g2_from_bytes(bytes.fromhex(k)) for k in c_["keys"]], bytes.fromhex(c_["msg"]))
+        assert got == c_["expect"], c_["name"]
+    v["multi_cases"] = mc
+    # aggregate over distinct (and duplicated) messages with HAE (TestAggregationWithHAE)
+    n2 = 4
+    msgs = [rnd.randbytes(32) for _ in range(n2)]
+    msgs.append(msgs[0])                                    # duplicate allowed under HAE
+    sg = [scheme.sign(c, sks[i], msgs[i]) for i in range(n2 + 1)]
+    a4 = scheme.aggregate_signatures_hae(c, sg[:n2], keys[:n2])
+    a5 = scheme.aggregate_signatures_hae(c, sg, keys[:n2 + 1])
+    ac = [{"name": "valid", "sig": G.g1_bytes(a4).hex(), "keys": kb(keys[:n2]), "msgs": [m.hex() for m in msgs[:n2]], "expect": True},
+          {"name": "missing_key", "sig": G.g1_bytes(a4).hex(), "keys": kb(keys[:n2 - 1]), "msgs": [m.hex() for m in msgs[:n2]], "expect": False},
+          {"name": "duplicate_message_ok", "sig": G.g1_bytes(a5).hex(), "keys": kb(keys[:n2 + 1]), "msgs": [m.hex() for m in msgs], "expect": True},
+          {"name": "stale_signature", "sig": G.g1_bytes(a5).hex(), "keys": kb(keys[:n2]), "msgs": [m.hex() for m in msgs[:n2]], "expect": False},
+          {"name": "swapped_messages", "sig": G.g1_bytes(a4).hex(), "keys": kb(keys[:n2]), "msgs": [m.hex() for m in [msgs[1], msgs[0]] + msgs[2:n2]], "expect": False}]
+    for c_ in ac:
+        got = scheme.verify_aggregate_signature_hae(c, G.g1_from_bytes(bytes.fromhex(c_["sig"])), [G.g2_from_bytes(bytes.fromhex(k)) for k in c_["keys"]], [bytes.fromhex(m) for m in c_["msgs"]])
+        assert got == c_["expect"], c_["name"]
+    v["aggregate_cases"] = ac
+    # multiplicities (TestKoskMultiSigWithMultiplicity shape; negative and zero factors exercise curve.go:190-214)
+    mult = [3, 1, -2, 0, 7]
+    msg = rnd.randbytes(32)
+    ks = [scheme.kosk_sign(c, sk, msg) for sk in sks[:n]]
+    aggm = G.g1_sum([G.g1_mul(G.g1_neg(s), -m) if m < 0 else G.g1_mul(s, m) for s, m in zip(ks, mult)])
+    pc = [{"name": "valid", "sig": G.g1_bytes(aggm).hex(), "keys": kb(keys[:n]), "mult": mult, "msg": msg.hex(), "expect": True},
+          {"name": "wrong_multiplicity", "sig": G.g1_bytes(aggm).hex(), "keys": kb(keys[:n]), "mult": [3, 1, 2, 0, 7], "msg": msg.hex(), "expect": False},
+          {"name": "length_mismatch", "sig": G.g1_bytes(aggm).hex(), "keys": kb(keys[:n]), "mult": mult[:n - 1], "msg": msg.hex(), "expect": False},
+          {"name": "nil_multiplicity_is_plain_kosk", "sig": G.g1_bytes(G.g1_sum(ks)).hex(), "keys": kb(keys[:n]), "mult": None, "msg": msg.hex(), "expect": True}]
+    for c_ in pc:
+        got = scheme.kosk_verify_multi_signature_with_multiplicity(c, G.g1_from_bytes(bytes.fromhex(c_["sig"])), [G.g2_from_bytes(bytes.fromhex(k)) for k in c_["keys"]], c_["mult"], bytes.fromhex(c_["msg"]))
+        assert got == c_["expect"], c_["name"]
+    v["multiplicity_cases"] = pc
+    json.dump(v, open(os.path.join(HERE, "hae_%s.json" % c.name), "w"), indent=0)
+
+
 if __name__ == "__main__":
+    if "--hae-only" in sys.argv:
+        hae(BN254, 20260930); hae(BLS381, 20261001)
+        print("hae fixtures written"); sys.exit(0)
     kat()
     vectors(BN254, 20260928)
     vectors(BLS381, 20260929)
+    hae(BN254, 20260930)
+    hae(BLS381, 20261001)
     print("golden fixtures written")
