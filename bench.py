@@ -27,7 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from bgls_amd import _lib  # noqa: E402
-from bgls_amd.sharding import all_gather_bytes  # noqa: E402
+from bgls_amd.sharding import all_gather_bytes, gather_partials_and_flags, global_duplicate_scan  # noqa: E402
 
 # Algorithmic work model (SURVEY.md 8d / DESIGN.md): 32x32->64 MACs per unit.
 MAC_PER_FPMUL = {0: 136, 1: 300}                       # CIOS 2L^2+L, L = 8 / 12
@@ -162,6 +162,66 @@ def bench_multisig(args, lib, cid, fp, n, dev, rank, world):
     }), flush=True)
 
 
+def bench_multisig_hae(args, lib, cid, fp, n, rank, world):
+    """VerifyMultiSignatureWithHAE (bgls/blsHAE.go:56-58) -- exponents from BLAKE2Xb over all keys (root
+    digest on the host while the keys upload, expansion on the device), apk = sum t_i pk_i as one fused weighted sum, then
+    a single-signature check.  Host-buffer entry point: the hash needs the key bytes on the host, so this figure is
+    PCIe- and host-hash-inclusive by construction."""
+    if world != 1:
+        raise SystemExit("multisig-hae workload is single-GPU in this round")
+    rnd = random.Random(0xB6150000 + 6)
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+    g2 = (ctypes.c_uint8 * (4 * fp))()
+    check(lib.bgls_generator(cid, 2, g2), "generator")
+    keys = (ctypes.c_uint8 * (n * 4 * fp))()
+    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(b"".join(s.to_bytes(32, "big") for s in sks)), None, n, keys), "scale_points(G2)")
+    t_raw = (ctypes.c_uint8 * (16 * n))()
+    t0 = time.perf_counter()
+    check(lib.bgls_hae_exponents(cid, keys, n, t_raw), "hae_exponents")
+    t_hash = time.perf_counter() - t0
+    tb = bytes(t_raw)
+    e = sum(sk * int.from_bytes(tb[16 * i:16 * i + 16], "big") for i, sk in enumerate(sks)) % ORDER[cid]
+    msg = rnd.randbytes(64)
+    off = (ctypes.c_uint64 * 2)(0, len(msg))
+    h = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_hash_to_g1(cid, B(msg), off, 1, h), "hash_to_g1")
+    sig = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_scale_points(cid, 1, h, B(e.to_bytes(32, "big")), None, 1, sig), "scale_points(sig)")
+    mb = B(msg)
+
+    def step(nn=n):
+        return check(lib.bgls_verify_multi_hae(cid, sig, keys, nn, mb, len(msg)), "verify_multi_hae")
+
+    if step() != 1 or step(n - 1) != 0:
+        raise RuntimeError("multisig-hae correctness gate failed")
+    for _ in range(args.warmup):
+        step()
+    lib.bgls_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if step() != 1:
+            raise RuntimeError("verification failed inside the timed region")
+    elapsed = time.perf_counter() - t0
+    sum_ms, sum_cnt = stage(lib, "sum_points")
+    lib.bgls_profile_enable(0)
+    peak = ctypes.c_double()
+    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
+    avg_s = sum_ms / args.steps * 1e-3
+    fpmul_per_signer = 127 * 18 + 64 * 29                 # 128-bit double-and-add on G2: doubling ~ 18 m, mixed addition ~ 29 m
+    macs = n * fpmul_per_signer * MAC_PER_FPMUL[cid]
+    print(json.dumps({
+        "metric": "multisig-hae-verify signers/sec", "value": n * args.steps / elapsed, "unit": "signers/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s VerifyMultiSignatureWithHAE, %d signers on one message, host buffers (keys cross PCIe and are "
+                               "hashed on the host inside the call)" % (args.curve, n)},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_wsum_first (+k_sum_next)", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
+                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3},
+        "host_side": {"blake2xb_root_plus_expansion_ms": t_hash * 1e3, "key_bytes": n * 4 * fp,
+                      "note": "the BLAKE2Xb root is one sequential compression chain over all key bytes (blsHAE.go:81-84)"},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +230,7 @@ def main():
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
     ap.add_argument("--n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig"],
+    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
 
@@ -192,6 +252,8 @@ def main():
 
     if args.workload == "multisig":
         return bench_multisig(args, lib, cid, fp, n, dev, rank, world)
+    if args.workload == "multisig-hae":
+        return bench_multisig_hae(args, lib, cid, fp, n, rank, world)
 
     # ---- setup (untimed): resident shard + the global aggregate signature on rank 0
     keys, msgs, part_sig, sigs = make_shard(lib, cid, n, 0xB6150000 + 1 + 1000 * rank)
@@ -206,12 +268,19 @@ def main():
     t_flags = torch.zeros(1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    def scan(buf, count):
+        return check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, t_flags.data_ptr(), stream), "duplicate_scan_dev")
+
     def step(msgs_t=t_msgs):
         t_flags.zero_()
+        if world > 1:                     # duplicates may straddle shards: exact scan over every rank's messages
+            global_duplicate_scan(scan, msgs_t, n, world)
         check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
-                                          64, 64, n, 1, t_part.data_ptr(), t_flags.data_ptr(), stream), "miller_product_dev")
-        parts = all_gather_bytes(t_part, world)
-        return check(lib.bgls_final_verify_dev(cid, parts.data_ptr(), world, t_flags.data_ptr(), stream), "final_verify_dev")
+                                          64, 64, n, 1 if world == 1 else 0, t_part.data_ptr(), t_flags.data_ptr(), stream), "miller_product_dev")
+        if world == 1:
+            return check(lib.bgls_final_verify_dev(cid, t_part.data_ptr(), 1, t_flags.data_ptr(), stream), "final_verify_dev")
+        parts, merged = gather_partials_and_flags(t_part, t_flags, world)
+        return check(lib.bgls_final_verify_dev(cid, parts.data_ptr(), world, merged.data_ptr(), stream), "final_verify_dev")
 
     def sync():
         if world > 1:

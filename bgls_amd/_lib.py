@@ -39,6 +39,7 @@ SIGNATURES = {
     "bgls_gt_mul": (ci, [ci, u8p, u8p, u8p]),
     "bgls_gt_identity": (ci, [ci, u8p]),
     "bgls_miller_product_dev": (ci, [ci, vp, vp, vp, sz, sz, sz, ci, vp, vp, vp]),
+    "bgls_duplicate_scan_dev": (ci, [vp, sz, sz, sz, vp, vp]),
     "bgls_final_verify_dev": (ci, [ci, vp, sz, vp, vp]),
     "bgls_aggregate_points_dev": (ci, [ci, ci, vp, sz, vp, vp]),
     "bgls_verify_multi_dev": (ci, [ci, vp, vp, sz, vp, sz, vp]),

@@ -1949,6 +1949,26 @@ int miller_product_dev_t(const void* d_sig, const void* d_keys, const void* d_ms
                            (uint32_t*)d_flags);
 }
 
+// containsDuplicateMessage (bgls/bgls.go:139-150) over device-resident fixed-stride messages: exact byte comparison
+int duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  if (n < 2) return 0;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  uint32_t cap = 1;
+  while (cap < 2 * n) cap <<= 1;
+  void* tab;
+  if ((rc = c.get(WS_TABLE, (size_t)cap * 4, &tab))) return rc;
+  Scope sc(c, st, ST_DUP);
+  HIPCHK(hipMemsetAsync(tab, 0, (size_t)cap * 4, st));
+  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, (uint32_t*)tab, cap - 1, (uint32_t*)d_flags);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <class C>
 int final_verify_dev_t(const void* d_partials, size_t count, const void* d_flags, void* stream) {
   typedef Engine<C> E;
@@ -2368,6 +2388,12 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
   if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
                                            d_flags, stream));
+}
+
+int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+  if (!d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (n >= (1ull << 30)) return fail(BGLS_ERR_ARG, "too many messages for one scan");
+  return duplicate_scan_dev(d_msgs, msg_len, msg_stride, n, d_flags, stream);
 }
 
 int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {

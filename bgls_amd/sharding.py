@@ -23,3 +23,27 @@ def all_gather_bytes(part, world):
     out = torch.empty(world * part.numel(), dtype=torch.uint8, device=part.device)
     dist.all_gather_into_tensor(out, part.contiguous().reshape(-1))
     return out.reshape(world, part.numel())
+
+
+def gather_partials_and_flags(part, flags, world):
+    """One all-gather carries every rank's partial product AND its status word (duplicate / bad encoding / hash failure
+    bits, include/bgls_hip.h): a malformed key seen by one rank must make EVERY rank answer false, as the single-GPU call
+    does.  part: uint8[gt_size]; flags: int32[1] on the same device.  Returns (uint8[world * gt_size] in rank order,
+    int32[1] = OR over ranks)."""
+    g = part.numel()
+    both = all_gather_bytes(torch.cat([part.reshape(-1), flags.reshape(-1).view(torch.uint8)]), world)
+    parts = both[:, :g].contiguous().reshape(-1)
+    words = both[:, g:].contiguous().view(torch.int32).reshape(-1)
+    merged = words[0:1].clone()
+    for r in range(1, world):
+        merged |= words[r:r + 1]
+    return parts, merged
+
+
+def global_duplicate_scan(scan, msgs, n_local, world):
+    """containsDuplicateMessage (bgls/bgls.go:139-150) is a property of the WHOLE message list: two equal messages may sit
+    in different shards.  Every rank all-gathers the (fixed-stride, equal-count) message bytes and runs the exact scan
+    over all world * n_local of them; `scan(buffer, count)` is bgls_duplicate_scan_dev on the GPU path."""
+    if world == 1:
+        return scan(msgs, n_local)
+    return scan(all_gather_bytes(msgs, world).reshape(-1), world * n_local)

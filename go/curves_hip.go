@@ -265,3 +265,109 @@ func HipVerifyMulti(curve CurveSystem, aggsig Point, keys []Point, msg []byte) b
 	}
 	return C.bgls_verify_multi(c.id, p(s.raw), p(kb), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
 }
+
+func hipKeyBytes(c *hipCurve, keys []Point) ([]byte, bool) {
+	kb := make([]byte, 0, len(keys)*c.size(C.BGLS_G2))
+	for _, k := range keys {
+		q, ok := k.(*hipPoint)
+		if !ok || q.group != C.BGLS_G2 {
+			return nil, false
+		}
+		kb = append(kb, q.raw...)
+	}
+	return kb, true
+}
+
+// HipHashPubKeysToExponents is bgls.hashPubKeysToExponents (bgls/blsHAE.go:80-93): BLAKE2Xb over the keys'
+// uncompressed bytes, n 16-byte big-endian exponents.
+func HipHashPubKeysToExponents(curve CurveSystem, pubkeys []Point) []*big.Int {
+	c, ok := curve.(*hipCurve)
+	kb, ok2 := hipKeyBytes(c, pubkeys)
+	if !ok || !ok2 || len(pubkeys) == 0 {
+		return nil
+	}
+	out := make([]byte, 16*len(pubkeys))
+	if C.bgls_hae_exponents(c.id, p(kb), C.size_t(len(pubkeys)), p(out)) != 0 {
+		return nil
+	}
+	t := make([]*big.Int, len(pubkeys))
+	for i := range t {
+		t[i] = new(big.Int).SetBytes(out[16*i : 16*i+16])
+	}
+	return t
+}
+
+// HipVerifyMultiHAE is bgls.VerifyMultiSignatureWithHAE (bgls/blsHAE.go:56-58) in one call.
+func HipVerifyMultiHAE(curve CurveSystem, aggsig Point, pubkeys []Point, msg []byte) bool {
+	c, ok := curve.(*hipCurve)
+	s, ok2 := aggsig.(*hipPoint)
+	if !ok || !ok2 {
+		return false
+	}
+	kb, ok3 := hipKeyBytes(c, pubkeys)
+	if !ok3 {
+		return false
+	}
+	return C.bgls_verify_multi_hae(c.id, p(s.raw), p(kb), C.size_t(len(pubkeys)), p(msg), C.size_t(len(msg))) == 1
+}
+
+// HipVerifyAggregateHAE is bgls.VerifyAggregateSignatureWithHAE (bgls/blsHAE.go:49-53) in one call.
+func HipVerifyAggregateHAE(curve CurveSystem, aggsig Point, pubkeys []Point, msgs [][]byte) bool {
+	c, ok := curve.(*hipCurve)
+	s, ok2 := aggsig.(*hipPoint)
+	if !ok || !ok2 || len(pubkeys) != len(msgs) {
+		return false
+	}
+	kb, ok3 := hipKeyBytes(c, pubkeys)
+	if !ok3 {
+		return false
+	}
+	off := make([]C.uint64_t, len(msgs)+1)
+	var blob []byte
+	for i, m := range msgs {
+		off[i] = C.uint64_t(len(blob))
+		blob = append(blob, m...)
+	}
+	off[len(msgs)] = C.uint64_t(len(blob))
+	return C.bgls_verify_aggregate_hae(c.id, p(s.raw), p(kb), p(blob), &off[0], C.size_t(len(pubkeys))) == 1
+}
+
+// HipAggregateSignaturesHAE is bgls.AggregateSignaturesWithHAE (bgls/blsHAE.go:39-46) in one call.
+func HipAggregateSignaturesHAE(curve CurveSystem, sigs []Point, pubkeys []Point) Point {
+	c, ok := curve.(*hipCurve)
+	if !ok || len(sigs) != len(pubkeys) || len(sigs) == 0 {
+		return nil
+	}
+	kb, ok2 := hipKeyBytes(c, pubkeys)
+	if !ok2 {
+		return nil
+	}
+	sb := make([]byte, 0, len(sigs)*c.size(C.BGLS_G1))
+	for _, x := range sigs {
+		q, ok := x.(*hipPoint)
+		if !ok || q.group != C.BGLS_G1 {
+			return nil
+		}
+		sb = append(sb, q.raw...)
+	}
+	out := make([]byte, c.size(C.BGLS_G1))
+	if C.bgls_aggregate_signatures_hae(c.id, p(sb), p(kb), C.size_t(len(sigs)), p(out)) != 0 {
+		return nil
+	}
+	return &hipPoint{c, C.BGLS_G1, out}
+}
+
+// HipVerifyMultiWithMultiplicity is the body of bgls.KoskVerifyMultiSignatureWithMultiplicity (bgls/blsKosk.go:137-150);
+// msg must already carry the Kosk 0x01 prefix.
+func HipVerifyMultiWithMultiplicity(curve CurveSystem, aggsig Point, keys []Point, multiplicity []int64, msg []byte) bool {
+	c, ok := curve.(*hipCurve)
+	s, ok2 := aggsig.(*hipPoint)
+	if !ok || !ok2 || len(keys) != len(multiplicity) || len(keys) == 0 {
+		return false
+	}
+	kb, ok3 := hipKeyBytes(c, keys)
+	if !ok3 {
+		return false
+	}
+	return C.bgls_verify_multi_multiplicity(c.id, p(s.raw), p(kb), (*C.int64_t)(&multiplicity[0]), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
+}

@@ -151,6 +151,12 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
                             size_t msg_len, size_t msg_stride, size_t n, int check_duplicates,
                             void* d_partial_out, void* d_flags, void* stream);
 
+/* containsDuplicateMessage (bgls/bgls.go:139-150) on its own: sets bit 0 of *d_flags when two of the n device-resident
+ * fixed-stride messages are byte-identical.  The multi-GPU path runs it over the all-gathered messages of every shard
+ * (a duplicate may straddle two shards); the per-shard scan inside bgls_miller_product_dev covers one GPU. */
+int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags,
+                            void* stream);
+
 /* Multiply `count` partial products (count x bgls_gt_size bytes, e.g. the all-gathered shards),
  * apply the single shared final exponentiation and compare with 1.  Returns 1 / 0 / < 0.
  * d_flags (may be NULL) is read: any bit set forces 0 (duplicate) or the matching error. */

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import coracle
-from bgls_amd.sharding import shard_range, all_gather_bytes
+from bgls_amd.sharding import shard_range, all_gather_bytes, gather_partials_and_flags, global_duplicate_scan
 
 
 def _free_port():
@@ -59,3 +59,49 @@ def test_shard_range_covers_everything():
         for w in (1, 2, 4, 8):
             rs = [shard_range(n, r, w) for r in range(w)]
             assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+
+
+def _worker_flags(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (1) status words travel with the partials: only rank 1 saw a bad encoding, both ranks must end up with the bit
+    part = torch.full((384,), rank + 1, dtype=torch.uint8)
+    flags = torch.tensor([2 if rank == 1 else 0], dtype=torch.int32)
+    parts, merged = gather_partials_and_flags(part, flags, world)
+    ok1 = int(merged.item()) == 2 and parts.numel() == 2 * 384 and bytes(parts[:384].numpy()) == b"\x01" * 384 \
+        and bytes(parts[384:].numpy()) == b"\x02" * 384
+    # (2) a duplicate that straddles the two shards is invisible to per-shard scans and visible to the global one
+    n_local, ln = 4, 64
+    msgs = bytearray(b"".join(bytes([16 * rank + i]) * ln for i in range(n_local)))
+    if rank == 1:
+        msgs[2 * ln:3 * ln] = bytes([1]) * ln                 # equals message 1 of rank 0
+    seen = {}
+
+    def scan(buf, count):
+        raw = bytes(buf.numpy())
+        items = [raw[i * ln:(i + 1) * ln] for i in range(count)]
+        seen["count"] = count
+        seen["dup"] = len(set(items)) != len(items)           # exact, like bgls/bgls.go:139-150
+        return 0
+
+    t = torch.frombuffer(msgs, dtype=torch.uint8)
+    scan(t, n_local)
+    local_dup = seen["dup"]
+    global_duplicate_scan(scan, t, n_local, world)
+    q.put((rank, ok1, local_dup, seen["dup"], seen["count"]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_flags_and_cross_shard_duplicates():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flags, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok1, local_dup, global_dup, count in res:
+        assert ok1 and not local_dup and global_dup and count == 8, (rank, ok1, local_dup, global_dup, count)

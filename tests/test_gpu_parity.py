@@ -371,3 +371,29 @@ def test_randomised_sizes_and_corruptions(gpu_lib, curve):
         o = out(12 * n_fp)
         assert gpu_lib.bgls_pairing_product(cid, B(g1s), B(g2s), n, o) == 0
         assert bytes(o) == coracle.pairing_product(cid, g1s, g2s, n, threads=8), n
+
+
+def test_duplicate_scan_across_shards(gpu_lib):
+    """bgls_duplicate_scan_dev: exact duplicate detection over device-resident messages -- the multi-GPU path's global
+    scan.  A duplicate that straddles two shards escapes both per-shard scans and is caught by the scan over all messages;
+    messages that differ in one bit anywhere (first/last byte) are not duplicates."""
+    import torch
+    dev = torch.device("cuda:0")
+    rnd = random.Random(77)
+    n, ln = 5000, 64
+    msgs = [rnd.randbytes(ln) for _ in range(n)]
+    near = bytearray(msgs[10]); near[-1] ^= 1
+    msgs[4000] = bytes(near)                                   # one-bit neighbour, not a duplicate
+    def scan(buf, count, stride=ln, length=ln):
+        t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+        f = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert gpu_lib.bgls_duplicate_scan_dev(t.data_ptr(), length, stride, count, f.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        return int(f.item())
+    assert scan(b"".join(msgs), n) == 0
+    msgs[4321] = msgs[123]                                     # shards [0, 2500) and [2500, 5000)
+    assert scan(b"".join(msgs[:2500]), 2500) == 0 and scan(b"".join(msgs[2500:]), 2500) == 0
+    assert scan(b"".join(msgs), n) & 1
+    # stride > length: only the first `length` bytes of each slot count
+    assert scan(b"".join(m[:32] + bytes(32) for m in msgs), n, 64, 32) & 1
+    assert scan(b"".join(msgs[:2]), 2) == 0 and scan(msgs[0] + msgs[0], 2) & 1 and scan(msgs[0], 1) == 0
