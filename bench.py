@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
-    ap.add_argument("--n", type=int, default=1 << 16, help="signers per GPU")
+    ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
@@ -239,10 +239,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch N > 1 with torch.distributed.run" % (world, args.gpus))
+    share = os.environ.get("BGLS_BENCH_SHARE_GPU") == "1"   # development: all ranks on cuda:0 over gloo, to exercise the
+    if share:                                               # N > 1 code path on a one-GPU box (numbers meaningless)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     check(lib.bgls_init(local_rank), "bgls_init")
     cid = 0 if args.curve == "altbn128" else 1
@@ -307,7 +313,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}

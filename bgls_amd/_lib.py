@@ -1,6 +1,7 @@
 """ctypes binding of the C ABI (include/bgls_hip.h).  Loads the in-tree HIP library and fails
 loudly if it is missing: there is no CPU fallback for the product path."""
 import ctypes
+import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +59,11 @@ def load():
             raise RuntimeError(
                 "bgls_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "The HIP library is the product; there is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7.  If this library pulled in
+        # /opt/rocm's copy first and torch initialised later, torch would report "No HIP GPUs are available".  Importing
+        # torch first lets the loader resolve our DT_NEEDED libamdhip64.so.7 to the copy already mapped (same SONAME).
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported

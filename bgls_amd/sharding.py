@@ -20,6 +20,10 @@ def all_gather_bytes(part, world):
     Returns a [world, len] uint8 tensor holding every rank's bytes in rank order."""
     if world == 1:
         return part.reshape(1, -1).clone()
+    if part.is_cuda and dist.get_backend() == "gloo":       # development runs that share one GPU: stage through the host
+        host = torch.empty(world * part.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, part.contiguous().reshape(-1).cpu())
+        return host.to(part.device).reshape(world, part.numel())
     out = torch.empty(world * part.numel(), dtype=torch.uint8, device=part.device)
     dist.all_gather_into_tensor(out, part.contiguous().reshape(-1))
     return out.reshape(world, part.numel())

@@ -397,3 +397,20 @@ def test_duplicate_scan_across_shards(gpu_lib):
     # stride > length: only the first `length` bytes of each slot count
     assert scan(b"".join(m[:32] + bytes(32) for m in msgs), n, 64, 32) & 1
     assert scan(b"".join(msgs[:2]), 2) == 0 and scan(msgs[0] + msgs[0], 2) & 1 and scan(msgs[0], 1) == 0
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The N > 1 path of bench.py end to end on real kernels: two ranks on cuda:0 exchanging over gloo
+    (BGLS_BENCH_SHARE_GPU=1) -- shard ranges, global duplicate scan, partial + status all-gather, final verification and
+    the tampered-message gate all run; only the numbers are meaningless."""
+    import json, os, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["BGLS_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--signers", "4096", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-800:], out.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["signers_per_gpu"] == 4096
