@@ -1231,6 +1231,9 @@ struct Ctx {
   hipStream_t stream = nullptr;
   std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
   void* gen_lines[2] = {nullptr, nullptr};   // k_gen_lines tables, one per curve, built on first use
+  uint32_t* h_res = nullptr;                 // pinned host words {verdict, final-stage flags, caller flags} of the verification in flight
+  bool res_pending = false;
+  hipStream_t res_stream = nullptr;
   // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
   bool prof = false;
   struct Pending { hipEvent_t a, b; int stage; };
@@ -1262,6 +1265,7 @@ struct Ctx {
     if (device >= cnt) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreate(&stream));
+    HIPCHK(hipHostMalloc((void**)&h_res, 64));
     ws.assign(40, {nullptr, 0});   // >= WS_NUM
     ready = true;
     return 0;
@@ -1280,8 +1284,19 @@ struct Ctx {
   }
 };
 
+// Contexts: each owns a stream, its workspaces and its stage timers.  A host thread works on the context it selected
+// (bgls_select_context, default 0); two contexts let one thread keep two verifications in flight, so the serial,
+// latency-bound stages of one (hashing rounds, reduction tail, final exponentiation) overlap the other's Miller launch.
+constexpr int NCTX = 4;
+thread_local int g_sel = 0;
+Ctx* ctx_all() {
+  static Ctx c[NCTX];
+  return c;
+}
 Ctx& ctx() {
-  static Ctx c;
+  Ctx* all = ctx_all();
+  Ctx& c = all[g_sel];
+  if (g_sel != 0 && !c.ready) c.device = all[0].device;
   return c;
 }
 
@@ -1595,11 +1610,12 @@ struct Engine {
     return 0;
   }
 
-  // returns 1/0 or <0; optionally copies the GT bytes out
-  static int finalize(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
-                      uint8_t* h_gt_out) {
+  // enqueue product-of-partials + final exponentiation + compare; the verdict lands in the context's pinned words
+  static int finalize_submit(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
+                             uint8_t* h_gt_out) {
     void *tmp, *fl;
     int rc;
+    if (c.res_pending) return fail(BGLS_ERR_ARG, "a verification is already in flight on this context (collect it first)");
     if ((rc = c.get(WS_TMP, GTB + 16, &tmp))) return rc;
     if ((rc = c.get(WS_OUT, 16, &fl))) return rc;
     uint8_t* d_gt = (uint8_t*)tmp;
@@ -1616,18 +1632,33 @@ struct Engine {
         k_final<C><<<1, 64, 0, st>>>(d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
     }
     HIPCHK(hipGetLastError());
-    uint32_t h[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(&h[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&h[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
-    if (d_flags_in) HIPCHK(hipMemcpyAsync(&h[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
+    c.h_res[0] = c.h_res[1] = c.h_res[2] = 0;
+    HIPCHK(hipMemcpyAsync(&c.h_res[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&c.h_res[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
+    if (d_flags_in) HIPCHK(hipMemcpyAsync(&c.h_res[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
     if (h_gt_out) HIPCHK(hipMemcpyAsync(h_gt_out, d_gt, GTB, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    c.res_pending = true;
+    c.res_stream = st;
+    return 0;
+  }
+  // wait for the verification in flight; returns 1/0 or <0
+  static int finalize_collect(Ctx& c) {
+    if (!c.res_pending) return fail(BGLS_ERR_ARG, "no verification in flight on this context");
+    c.res_pending = false;
+    HIPCHK(hipStreamSynchronize(c.res_stream));
     c.collect();
-    uint32_t f = h[1] | h[2];
+    uint32_t f = c.h_res[1] | c.h_res[2];
     if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
     if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
     if (f & FLAG_DUP) return 0;
-    return h[0] ? 1 : 0;
+    return c.h_res[0] ? 1 : 0;
+  }
+  // returns 1/0 or <0; optionally copies the GT bytes out
+  static int finalize(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
+                      uint8_t* h_gt_out) {
+    int rc;
+    if ((rc = finalize_submit(c, st, d_partials, count, do_final_exp, d_flags_in, h_gt_out))) return rc;
+    return finalize_collect(c);
   }
 
   template <class F, int PTB>
@@ -1981,6 +2012,17 @@ int final_verify_dev_t(const void* d_partials, size_t count, const void* d_flags
 }
 
 template <class C>
+int final_verify_submit_dev_t(const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return E::finalize_submit(c, st, (const uint8_t*)d_partials, count, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
 int aggregate_points_dev_t(int group, const void* d_pts, size_t n, void* d_out, void* stream) {
   typedef Engine<C> E;
   Ctx& c = ctx();
@@ -2248,11 +2290,14 @@ int bgls_abi_version(void) { return 1; }
 const char* bgls_last_error(void) { return g_err.c_str(); }
 
 int bgls_init(int device) {
+  Ctx* all = ctx_all();
+  for (int i = 0; i < NCTX; ++i) {
+    std::lock_guard<std::mutex> lk(all[i].mu);
+    if (all[i].ready && all[i].device != device) return fail(BGLS_ERR_ARG, "bgls_init: context already bound to another device");
+    if (!all[i].ready) all[i].device = device;
+  }
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
-  if (c.ready && c.device == device) return 0;
-  if (c.ready) return fail(BGLS_ERR_ARG, "bgls_init: context already bound to another device");
-  c.device = device;
   return c.ensure();
 }
 
@@ -2331,21 +2376,28 @@ int bgls_gt_identity(int curve, uint8_t* out) {
 }
 
 int bgls_profile_enable(int on) {
-  Ctx& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
-  c.prof = on != 0;
-  for (int i = 0; i < 8; ++i) { c.stage_ms[i] = 0; c.stage_cnt[i] = 0; }
+  Ctx* all = ctx_all();
+  for (int k = 0; k < NCTX; ++k) {
+    Ctx& c = all[k];
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.prof = on != 0;
+    for (int i = 0; i < 8; ++i) { c.stage_ms[i] = 0; c.stage_cnt[i] = 0; }
+  }
   return 0;
 }
 
 int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches) {
   if (!stage || !total_ms || !launches) return fail(BGLS_ERR_ARG, "NULL argument");
-  Ctx& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
   for (int i = 0; i < ST_NUM; ++i)
     if (!strcmp(stage, STAGE_NAMES[i])) {
-      *total_ms = c.stage_ms[i];
-      *launches = c.stage_cnt[i];
+      *total_ms = 0;
+      *launches = 0;
+      Ctx* all = ctx_all();
+      for (int k = 0; k < NCTX; ++k) {                      // summed over the contexts
+        std::lock_guard<std::mutex> lk(all[k].mu);
+        *total_ms += all[k].stage_ms[i];
+        *launches += all[k].stage_cnt[i];
+      }
       return 0;
     }
   return fail(BGLS_ERR_ARG, "unknown stage name");
@@ -2388,6 +2440,23 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
   if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
                                            d_flags, stream));
+}
+
+int bgls_select_context(int index) {
+  if (index < 0 || index >= NCTX) return fail(BGLS_ERR_ARG, "context index out of range");
+  g_sel = index;
+  return 0;
+}
+
+int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, final_verify_submit_dev_t<CV>(d_partials, count, d_flags, stream));
+}
+
+int bgls_final_verify_collect(int curve) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  DISPATCH(curve, Engine<CV>::finalize_collect(c));
 }
 
 int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {

@@ -163,6 +163,15 @@ int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_strid
 int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags,
                           void* stream);
 
+/* The same, split in two so that a second verification can be enqueued while this one's serial tail (reduction, final
+ * exponentiation) is still running: submit returns at once, collect waits and returns 1 / 0 / < 0.  One verification in
+ * flight per context. */
+int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream);
+int bgls_final_verify_collect(int curve);
+/* Contexts 0..3: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
+ * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */
+int bgls_select_context(int index);
+
 /* Device-resident key sum for the multisig path: d_out = projective partial sum of n G2 keys,
  * serialised as affine G2 bytes (bgls_g2_size).  Shards combine with bgls_aggregate_points. */
 int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream);

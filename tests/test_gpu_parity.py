@@ -414,3 +414,39 @@ def test_bench_two_ranks_share_one_gpu():
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-800:], out.stderr[-1500:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["signers_per_gpu"] == 4096
+
+
+def test_two_contexts_in_flight(gpu_lib, curve):
+    """bgls_select_context + bgls_final_verify_submit_dev / _collect: two verifications enqueued back to back on two
+    contexts (own streams, own workspaces) give their own verdicts -- a valid instance and one with a flipped message bit."""
+    import torch
+    cid, n_fp = curve["id"], curve["fp"]
+    n = 700
+    agg, keys, msgs = make_instance(gpu_lib, cid, n_fp, n, 4242)
+    dev = torch.device("cuda:0")
+    blob = b"".join(msgs)
+    bad = bytearray(blob); bad[64 * 301 + 7] ^= 4
+    t_keys = torch.frombuffer(bytearray(keys), dtype=torch.uint8).to(dev)
+    t_sig = torch.frombuffer(bytearray(agg), dtype=torch.uint8).to(dev)
+    t_msgs = [torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), torch.frombuffer(bad, dtype=torch.uint8).to(dev)]
+    gtb = 12 * n_fp
+    parts = [torch.zeros(gtb, dtype=torch.uint8, device=dev) for _ in range(2)]
+    flags = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    try:
+        for rep in range(2):
+            for k in (0, 1):
+                assert gpu_lib.bgls_select_context(k) == 0
+                assert gpu_lib.bgls_miller_product_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), t_msgs[k].data_ptr(), 64, 64, n, 1,
+                                                       parts[k].data_ptr(), flags[k].data_ptr(), None) == 0
+                assert gpu_lib.bgls_final_verify_submit_dev(cid, parts[k].data_ptr(), 1, flags[k].data_ptr(), None) == 0
+            assert gpu_lib.bgls_final_verify_submit_dev(cid, parts[1].data_ptr(), 1, flags[1].data_ptr(), None) < 0   # one in flight per context
+            got = []
+            for k in (0, 1):
+                assert gpu_lib.bgls_select_context(k) == 0
+                got.append(gpu_lib.bgls_final_verify_collect(cid))
+            assert got == [1, 0]
+            assert gpu_lib.bgls_final_verify_collect(cid) < 0          # nothing left to collect
+        assert gpu_lib.bgls_select_context(99) < 0
+    finally:
+        gpu_lib.bgls_select_context(0)
