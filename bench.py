@@ -225,12 +225,12 @@ def bench_multisig_hae(args, lib, cid, fp, n, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
     ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, help="single GPU: verifications kept in flight (1 = strictly sequential, max 4)")
+    ap.add_argument("--in-flight", type=int, default=4, help="single GPU: verifications kept in flight (1 = strictly sequential, max 4)")
     ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
@@ -271,23 +271,39 @@ def main():
     agg = (ctypes.c_uint8 * (2 * fp))()
     check(lib.bgls_aggregate_points(cid, 1, B(bytes(all_sigs.cpu().numpy().tobytes())), world, agg), "aggregate_points(global)")
     t_sig = torch.frombuffer(bytearray(bytes(agg)), dtype=torch.uint8).to(dev)
-    t_part = torch.zeros(gtb, dtype=torch.uint8, device=dev)
-    t_flags = torch.zeros(1, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # L verifications in flight on L library contexts / streams (default 4): every step is still one complete pass (duplicate
+    # scan, hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound
+    # stages of one step overlap the Miller launch of its neighbours.  --in-flight 1 runs them strictly one after the other.
+    L = max(1, min(4, args.in_flight))
+    lanes = [{"stream": torch.cuda.Stream(device=dev), "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
+              "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for _ in range(L)]
+    torch.cuda.synchronize()
 
-    def scan(buf, count):
-        return check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, t_flags.data_ptr(), stream), "duplicate_scan_dev")
+    def submit(k, msgs_t=t_msgs):
+        """Enqueue one complete verification on lane k (its own library context and stream); nothing here waits for the GPU."""
+        ln = lanes[k]
+        h = ln["stream"].cuda_stream
+        check(lib.bgls_select_context(k), "select_context")
+        with torch.cuda.stream(ln["stream"]):
+            ln["flags"].zero_()
+            if world > 1:                 # duplicates may straddle shards: exact scan over every rank's messages
+                global_duplicate_scan(lambda buf, count: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, ln["flags"].data_ptr(), h),
+                                                               "duplicate_scan_dev"), msgs_t, n, world)
+            check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
+                                              64, 64, n, 1 if world == 1 else 0, ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
+            if world == 1:
+                check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
+            else:
+                parts, merged = gather_partials_and_flags(ln["part"], ln["flags"], world)
+                check(lib.bgls_final_verify_submit_dev(cid, parts.data_ptr(), world, merged.data_ptr(), h), "final_verify_submit_dev")
+
+    def collect(k):
+        check(lib.bgls_select_context(k), "select_context")
+        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
 
     def step(msgs_t=t_msgs):
-        t_flags.zero_()
-        if world > 1:                     # duplicates may straddle shards: exact scan over every rank's messages
-            global_duplicate_scan(scan, msgs_t, n, world)
-        check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
-                                          64, 64, n, 1 if world == 1 else 0, t_part.data_ptr(), t_flags.data_ptr(), stream), "miller_product_dev")
-        if world == 1:
-            return check(lib.bgls_final_verify_dev(cid, t_part.data_ptr(), 1, t_flags.data_ptr(), stream), "final_verify_dev")
-        parts, merged = gather_partials_and_flags(t_part, t_flags, world)
-        return check(lib.bgls_final_verify_dev(cid, parts.data_ptr(), world, merged.data_ptr(), stream), "final_verify_dev")
+        submit(0, msgs_t)
+        return collect(0)
 
     def sync():
         if world > 1:
@@ -300,33 +316,11 @@ def main():
     bad = t_msgs.clone()
     if rank == world - 1:
         bad[64 * (n // 2) + 3] ^= 0x20
+    torch.cuda.synchronize()              # `bad` was written on torch's default stream, the lanes have their own
     if step(bad) != 0:
         raise RuntimeError("tampered instance accepted")
 
-    # Single GPU: L verifications in flight on L library contexts / streams (default 3) -- every step is still one complete
-    # pass (duplicate scan, hash, Miller, reduce, final exponentiation, verdict checked), but the serial latency-bound
-    # stages of one step overlap the Miller launch of its neighbours.  --in-flight 1 runs them strictly one after the other.
-    L = max(1, min(4, args.in_flight)) if world == 1 else 1
     pipelined = L > 1
-    lanes = []
-    if pipelined:
-        for k in range(L):
-            lanes.append({"stream": torch.cuda.Stream(device=dev), "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
-                          "flags": torch.zeros(1, dtype=torch.int32, device=dev)})
-
-    def submit(k):
-        ln = lanes[k]
-        check(lib.bgls_select_context(k), "select_context")
-        with torch.cuda.stream(ln["stream"]):
-            ln["flags"].zero_()
-        h = ln["stream"].cuda_stream
-        check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), t_msgs.data_ptr(), 64, 64, n, 1,
-                                          ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
-        check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
-
-    def collect(k):
-        check(lib.bgls_select_context(k), "select_context")
-        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
 
     def run(count, overlap):
         if not overlap:
