@@ -805,9 +805,13 @@ struct Coop64 {
 // time the two halves of the pipeline separately.
 template <class C, int DBG = 0>
 __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
-                                                        const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+                                                        const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, unsigned swap_mask) {
   typedef Coop64<C> K;
-  const int wave = threadIdx.x >> 6;
+  // The two waves of a block land on different SIMDs and every CU hosts four blocks: if wave 0 were the producer
+  // everywhere, two SIMDs of a CU would carry two producers and the other two would carry two consumers, and the kernel
+  // would run at the pace of the heavier role.  Blocks selected by swap_mask exchange the roles, so each SIMD carries
+  // one producer and one consumer.
+  const int wave = (int)(threadIdx.x >> 6) ^ ((blockIdx.x & swap_mask) ? 1 : 0);
   const int lane = threadIdx.x & 63;
   if (wave == 0) {
     // ---------------- producer: 64 pairings, one per lane
@@ -1300,6 +1304,15 @@ Ctx& ctx() {
   return c;
 }
 
+// role-swap mask of k_miller_ab64 (see the kernel); BGLS_AB64_SWAP overrides it for A/B runs
+unsigned ab64_swap() {
+  static const unsigned v = [] {
+    const char* e = getenv("BGLS_AB64_SWAP");
+    return e ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+  }();
+  return v;
+}
+
 // BGLS_KERNELS=v1 selects the round-1 thread-per-pairing kernels (kept for A/B measurements);
 // default is the wave-cooperative path (coop.hpp).
 // BGLS_MILLER=coop1 / ab forces the single-wave / producer-consumer cooperative kernel; default: by batch size.
@@ -1538,12 +1551,12 @@ struct Engine {
           Scope sc(c, st, ST_MILLER);
           const char* dbg = getenv("BGLS_AB64_DBG");
           if (C::CURVE_ID == 0 && dbg && dbg[0] == '1')
-            k_miller_ab64<BN254, 1><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags);
+            k_miller_ab64<BN254, 1><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags, ab64_swap());
           else if (C::CURVE_ID == 0 && dbg && dbg[0] == '2')
-            k_miller_ab64<BN254, 2><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags);
+            k_miller_ab64<BN254, 2><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags, ab64_swap());
           else
           k_miller_ab64<C><<<(unsigned)nb64, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1s, g2s, npairs, gen_at, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID],
-                                                                             (Fp2<C>*)pa, d_flags);
+                                                                             (Fp2<C>*)pa, d_flags, ab64_swap());
         }
         Scope sc(c, st, ST_REDUCE);
         Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;

@@ -6,7 +6,11 @@ O=gpurun_out/$R
 mkdir -p $O
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 python bench.py > $O/bench_altbn128.json 2> $O/bench_altbn128.err; tail -c 600 $O/bench_altbn128.json
-python bench.py --curve bls12 --steps 5 --warmup 2 > $O/bench_bls12.json 2> $O/bench_bls12.err
+python bench.py --curve bls12 --steps 10 --warmup 2 > $O/bench_bls12.json 2> $O/bench_bls12.err
+python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_altbn128_sequential.json 2>/dev/null
+python bench.py --curve bls12 --in-flight 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_bls12_sequential.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -o ${R}_seq -- python bench.py --in-flight 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_seq_run.log 2>&1
+python bench.py --workload multisig-hae --n 1048576 --steps 3 --warmup 1 > $O/bench_multisig_hae_altbn128_1M.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_run.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o $R -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o $R -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1

@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 src, dst = f"gpurun_out/{tag}", "profiles/r1"
-for d in ("stats", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+for d in ("stats", "stats_seq", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     shutil.rmtree(f"{dst}/{d}", ignore_errors=True)
     os.makedirs(f"{dst}/{d}")
     for f in glob.glob(f"{src}/{d}/*.csv"):
