@@ -222,6 +222,53 @@ def bench_multisig_hae(args, lib, cid, fp, n, rank, world):
     }), flush=True)
 
 
+def bench_decompress(args, lib, cid, fp, n, rank, world):
+    """UnmarshalG2 of n compressed alt-bn128 keys (curves/altbn128.go:329-376) -- the step in front of the
+    hot path when keys arrive over the wire.  Host buffers in and out (64 B -> 128 B per key)."""
+    if world != 1 or cid != 0:
+        raise SystemExit("decompress workload: alt-bn128, single GPU")
+    rnd = random.Random(0xB6150000 + 7)
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+    g2 = (ctypes.c_uint8 * 128)()
+    check(lib.bgls_generator(cid, 2, g2), "generator")
+    keys = (ctypes.c_uint8 * (n * 128))()
+    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(b"".join(s.to_bytes(32, "big") for s in sks)), None, n, keys), "scale_points(G2)")
+    comp = (ctypes.c_uint8 * (n * 64))()
+    check(lib.bgls_compress_points(cid, 2, keys, n, comp), "compress_points")
+    out = (ctypes.c_uint8 * (n * 128))()
+    ok = (ctypes.c_uint8 * n)()
+
+    def step():
+        check(lib.bgls_decompress_points(cid, 2, comp, n, out, ok), "decompress_points")
+
+    step()
+    if bytes(out) != bytes(keys) or bytes(ok) != b"\x01" * n:
+        raise RuntimeError("decompress round trip failed")
+    for _ in range(args.warmup):
+        step()
+    lib.bgls_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_cnt = stage(lib, "sum_points")
+    lib.bgls_profile_enable(0)
+    peak = ctypes.c_double()
+    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
+    avg_s = k_ms / max(k_cnt, 1) * 1e-3
+    fpmul_per_key = 3 * 320 + 40          # reference algorithm: two square roots and one residuosity test by exponentiation, plus x^3 etc.
+    macs = n * fpmul_per_key * MAC_PER_FPMUL[cid]
+    print(json.dumps({
+        "metric": "G2 key decompression keys/sec", "value": n * args.steps / elapsed, "unit": "keys/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "altbn128 UnmarshalG2 (compressed), %d keys, host buffers in and out" % n},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_decompress_bn<2>", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
+                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3,
+                     "hbm_algorithmic_GBps": n * 192 / avg_s / 1e9},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,7 +278,7 @@ def main():
     ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=4, help="single GPU: verifications kept in flight (1 = strictly sequential, max 4)")
-    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae"],
+    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae", "decompress"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
 
@@ -261,6 +308,8 @@ def main():
         return bench_multisig(args, lib, cid, fp, n, dev, rank, world)
     if args.workload == "multisig-hae":
         return bench_multisig_hae(args, lib, cid, fp, n, rank, world)
+    if args.workload == "decompress":
+        return bench_decompress(args, lib, cid, fp, n, rank, world)
 
     # ---- setup (untimed): resident shard + the global aggregate signature on rank 0
     keys, msgs, part_sig, sigs = make_shard(lib, cid, n, 0xB6150000 + 1 + 1000 * rank)

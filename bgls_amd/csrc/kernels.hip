@@ -19,6 +19,7 @@
 
 #include "pairing.hpp"
 #include "h2c.hpp"
+#include "wire.hpp"
 #include "coop.hpp"
 #include "finalexp.hpp"
 #include "../../include/bgls_hip.h"
@@ -452,6 +453,50 @@ __global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t*
   if (sg == 1) p = aff_neg<F>(p);
   Jac<F> r = jac_mul<F>(p, k, top + 1);
   aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(r));
+}
+
+// ---- compressed wire formats of alt-bn128 (wire.hpp; curves/altbn128.go:81-89,203-221,296-376) ----
+// GROUP 1: 64-byte points <-> 32-byte forms; GROUP 2: 128 <-> 64.  One point per thread: the decoders are one
+// (G1) or two (G2) square-root exponentiations plus a Legendre symbol and an inversion, i.e. about the cost of hashing
+// one message; ok[i] = 1 / 0 mirrors the reference's (Point, bool).
+template <int GROUP>
+__global__ void __launch_bounds__(64) k_decompress_bn(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CB = GROUP == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  bool good;
+  if constexpr (GROUP == BGLS_G1) {
+    Aff<F1<C>> p;
+    good = g1_decompress<C>(p, in + i * CB);
+    if (good) g1_to_bytes<C>(out + i * UB, p);
+  } else {
+    Aff<F2<C>> p;
+    good = g2_decompress<C>(p, in + i * CB);
+    if (good) g2_to_bytes<C>(out + i * UB, p);
+  }
+  if (!good)
+    for (int k = 0; k < UB; ++k) out[i * UB + k] = 0;
+  ok[i] = good ? 1 : 0;
+}
+
+template <int GROUP>
+__global__ void __launch_bounds__(64) k_compress_bn(const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CB = GROUP == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  if constexpr (GROUP == BGLS_G1) {
+    Aff<F1<C>> p;
+    bool good = g1_from_bytes<C>(p, in + i * UB) && aff_on_curve<F1<C>>(p);
+    if (!good) atomicOr(flags, FLAG_ENC);
+    g1_compress<C>(out + i * CB, p);
+  } else {
+    Aff<F2<C>> p;
+    bool good = g2_from_bytes<C>(p, in + i * UB) && aff_on_curve<F2<C>>(p);
+    if (!good) atomicOr(flags, FLAG_ENC);
+    g2_compress<C>(out + i * CB, p);
+  }
 }
 
 // ---- hashed aggregation exponents (bgls/blsHAE.go) and weighted key sums ----
@@ -2291,6 +2336,45 @@ int aggregate_signatures_hae_t(const uint8_t* sigs, const uint8_t* keys, size_t 
   return flags_to_rc(f);
 }
 
+// Marshal / Unmarshal* compressed branch over a batch (alt-bn128 only: BLS12-381's compressed layout belongs to the
+// un-vendored dis2/bls12 and is unpinned, curves/bls12_381.go:55,60,116,121)
+int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (curve != BGLS_CURVE_ALTBN128) return fail(BGLS_ERR_ARG, "compressed point formats are defined for alt-bn128 only");
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t CB = group == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  const size_t in_b = compress ? UB : CB, out_b = compress ? CB : UB;
+  void *d_in, *d_out, *d_ok, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * in_b, &d_in))) return rc;
+  if ((rc = c.get(WS_IN_A, n * out_b, &d_out))) return rc;
+  if ((rc = c.get(WS_IN_D, n, &d_ok))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, in, n * in_b, hipMemcpyHostToDevice, st));
+  {
+    Scope sc(c, st, ST_SUM);
+    if (compress) {
+      if (group == BGLS_G1) k_compress_bn<BGLS_G1><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+      else k_compress_bn<BGLS_G2><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+    } else {
+      if (group == BGLS_G1) k_decompress_bn<BGLS_G1><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
+      else k_decompress_bn<BGLS_G2><<<nblk(n, 64), 64, 0, st>>>((const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * out_b, hipMemcpyDeviceToHost, st));
+  if (!compress) HIPCHK(hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c.collect();
+  return flags_to_rc(f);
+}
+
 bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
 
 }  // namespace
@@ -2521,6 +2605,17 @@ int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t*
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (!multiplicity) DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
   DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, multiplicity, n, msg, msg_len));
+}
+
+/* ---- compressed wire formats (alt-bn128; curves/altbn128.go:81-89,203-221,296-376) ---- */
+int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (!group_ok(group) || (n && (!pts || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  return wire_points(curve, group, true, pts, n, out, nullptr);
+}
+
+int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (!group_ok(group) || (n && (!in || !out || !ok))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  return wire_points(curve, group, false, in, n, out, ok);
 }
 
 }  // extern "C"

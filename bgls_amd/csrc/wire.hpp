@@ -1,0 +1,139 @@
+// Compressed wire formats of alt-bn128 points.  Unlike every other format at the seam these are defined by the
+// reference's own code (not by an upstream library), so the decoders follow it statement by statement:
+//   Marshal      G1 curves/altbn128.go:81-89    x, top bit of byte 0 <- (2y > q)
+//                G2 curves/altbn128.go:203-221  x_im || x_re, top bits <- (2 y_im > q), (2 y_re > q)
+//   Unmarshal    G1 curves/altbn128.go:296-327, G2 :329-376 (compressed branches); square roots by calcQuadRes
+//                (curves/hash.go:178-190) and calcComplexQuadRes (curves/hash.go:196-223), then the component-wise sign
+//                rule, then MakeG1Point / MakeG2Point -> upstream Unmarshal = canonical coordinates + curve membership.
+// The sign bits of G2 are applied to the two components independently, exactly as the reference does; inconsistent
+// bits therefore yield a non-point and the final curve check rejects it.
+#pragma once
+#include "curve.hpp"
+
+namespace bgls {
+
+// plain (non-Montgomery) a: is 2a > q, i.e. a > (q - 1) / 2 ?
+template <class C>
+BGLS_HD bool fp_plain_gt_half(const Fp<C>& a) {
+  // (q - 1) / 2 = q >> 1 for odd q
+  bool gt = false, decided = false;
+#pragma unroll
+  for (int i = C::L - 1; i >= 0; --i) {
+    const u32 h = (C::P[i] >> 1) | (i + 1 < C::L ? (C::P[i + 1] << 31) : 0u);
+    if (!decided && a.v[i] != h) {
+      gt = a.v[i] > h;
+      decided = true;
+    }
+  }
+  return gt;
+}
+
+// y <- the representative selected by the sign bit (curves/altbn128.go:318-323): returns false when the rule would
+// produce q itself (flag set on a zero component), which the upstream Unmarshal rejects as non-canonical.
+template <class C>
+BGLS_HD bool fp_apply_sign(Fp<C>& y_mont, bool sgn) {
+  const Fp<C> yp = fp_from_mont<C>(y_mont);
+  const bool big = fp_plain_gt_half<C>(yp);               // 2y > q; 2y == q is impossible, so !big means 2y < q
+  if (sgn != big) {
+    if (fp_is_zero<C>(yp)) return false;                  // q - 0 = q: not a canonical coordinate
+    y_mont = fp_neg<C>(y_mont);
+  }
+  return true;
+}
+
+template <class C>
+BGLS_HD void fp_to_be_flag(uint8_t* out, const Fp<C>& plain, bool flag) {
+  fp_to_be<C>(out, plain);
+  if (flag) out[0] = (uint8_t)(out[0] + 128);
+}
+
+template <class C>
+BGLS_FN void g1_compress(uint8_t* out, const Aff<F1<C>>& p) {
+  if (p.inf) {
+    for (int i = 0; i < C::FP_BYTES; ++i) out[i] = 0;
+    return;
+  }
+  fp_to_be_flag<C>(out, fp_from_mont<C>(p.x), fp_plain_gt_half<C>(fp_from_mont<C>(p.y)));
+}
+
+template <class C>
+BGLS_FN void g2_compress(uint8_t* out, const Aff<F2<C>>& p) {
+  if (p.inf) {
+    for (int i = 0; i < 2 * C::FP_BYTES; ++i) out[i] = 0;
+    return;
+  }
+  fp_to_be_flag<C>(out, fp_from_mont<C>(p.x.c1), fp_plain_gt_half<C>(fp_from_mont<C>(p.y.c1)));
+  fp_to_be_flag<C>(out + C::FP_BYTES, fp_from_mont<C>(p.x.c0), fp_plain_gt_half<C>(fp_from_mont<C>(p.y.c0)));
+}
+
+template <class C>
+BGLS_HD Fp<C> fp_from_be_clear_top(const uint8_t* b, bool& flag) {
+  uint8_t tmp[C::FP_BYTES];
+  for (int i = 0; i < C::FP_BYTES; ++i) tmp[i] = b[i];
+  flag = tmp[0] >= 128;
+  if (flag) tmp[0] = (uint8_t)(tmp[0] - 128);
+  return fp_from_be<C>(tmp);
+}
+
+// UnmarshalG1, compressed branch.  Returns false for "nil, false".
+template <class C>
+BGLS_FN bool g1_decompress(Aff<F1<C>>& out, const uint8_t* b) {
+  bool ysgn;
+  const Fp<C> xp = fp_from_be_clear_top<C>(b, ysgn);
+  out.inf = false;
+  if (fp_is_zero<C>(xp)) {                                 // altbn128.go:311-313: infinity whatever the flag says
+    out.x = fp_zero<C>();
+    out.y = fp_zero<C>();
+    out.inf = true;
+    return true;
+  }
+  if (fp_geq_p<C>(xp)) return false;                       // upstream Unmarshal: coordinate exceeds modulus
+  out.x = fp_to_mont<C>(xp);
+  const Fp<C> y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(out.x), out.x), fp_load<C>(C::B));
+  out.y = fp_sqrt_candidate<C>(y2);                        // calcQuadRes: y2^((q+1)/4), no residuosity test here
+  if (!fp_apply_sign<C>(out.y, ysgn)) return false;
+  return fp_eq<C>(fp_sqr<C>(out.y), y2);                   // MakeG1Point -> upstream curve check
+}
+
+// calcComplexQuadRes (curves/hash.go:196-223); false where the reference would fail on ModInverse(0)
+template <class C>
+BGLS_FN bool f2_complex_quad_res(Fp2<C>& r, const Fp2<C>& a) {
+  if (fp_is_zero<C>(a.c1)) {
+    r.c0 = fp_sqrt_candidate<C>(a.c0);
+    r.c1 = fp_zero<C>();
+    return true;
+  }
+  const Fp<C> lam = fp_sqrt_candidate<C>(fp_add<C>(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1)));
+  const Fp<C> half = fp_load<C>(C::HALF);
+  Fp<C> delta = fp_mul<C>(fp_add<C>(a.c0, lam), half);
+  if (!(fp_is_zero<C>(delta) || fp_jacobi<C>(delta) > 0))  // isQuadRes (hash.go:254-265): 0 counts as a residue
+    delta = fp_mul<C>(fp_sub<C>(a.c0, lam), half);
+  r.c0 = fp_sqrt_candidate<C>(delta);
+  if (fp_is_zero<C>(r.c0)) return false;
+  r.c1 = fp_mul<C>(fp_mul<C>(fp_inv<C>(r.c0), half), a.c1);
+  return true;
+}
+
+// UnmarshalG2, compressed branch
+template <class C>
+BGLS_FN bool g2_decompress(Aff<F2<C>>& out, const uint8_t* b) {
+  bool yisgn, yrsgn;
+  const Fp<C> xi = fp_from_be_clear_top<C>(b, yisgn);
+  const Fp<C> xr = fp_from_be_clear_top<C>(b + C::FP_BYTES, yrsgn);
+  out.inf = false;
+  if (fp_is_zero<C>(xi) && fp_is_zero<C>(xr)) {            // altbn128.go:349-351
+    out.x = f2_zero<C>();
+    out.y = f2_zero<C>();
+    out.inf = true;
+    return true;
+  }
+  if (fp_geq_p<C>(xi) || fp_geq_p<C>(xr)) return false;
+  out.x = Fp2<C>{fp_to_mont<C>(xr), fp_to_mont<C>(xi)};
+  const Fp2<C> y2 = f2_add<C>(f2_mul<C>(f2_sqr<C>(out.x), out.x), F2<C>::curve_b());
+  if (!f2_complex_quad_res<C>(out.y, y2)) return false;
+  if (!fp_apply_sign<C>(out.y.c1, yisgn)) return false;    // the two components follow their own bits (altbn128.go:360-371)
+  if (!fp_apply_sign<C>(out.y.c0, yrsgn)) return false;
+  return f2_eq<C>(f2_sqr<C>(out.y), y2);                   // MakeG2Point -> upstream curve check
+}
+
+}  // namespace bgls

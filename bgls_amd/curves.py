@@ -40,6 +40,17 @@ class Point:
     def MarshalUncompressed(self):
         return self.raw
 
+    def Marshal(self):
+        """Point.Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221); BLS12-381's compressed
+        layout is upstream-defined and unpinned, so the uncompressed bytes are returned there."""
+        if self.curve.id != 0:
+            return self.raw
+        o = _lib.out(len(self.raw) // 2)
+        rc = _lib.load().bgls_compress_points(self.curve.id, self.group, _lib.buf(self.raw), 1, o)
+        if rc != 0:
+            raise RuntimeError("bgls_compress_points: %d %s" % (rc, _lib.last_error()))
+        return bytes(o)
+
     def Mul(self, scalar):
         """Point.Mul (altbn128.go:107-121,235-249; bls12_381.go:65-76,126-137): negative scalars
         negate then multiply, zero gives infinity.  The caller's scalar is NOT mutated."""
@@ -126,8 +137,16 @@ class CurveSystem:
         return self._make(G2, coords, check)
 
     def _unmarshal(self, group, data):
+        if data is not None and self.id == 0 and len(data) * 2 == self._pt_size(group):
+            # compressed branch of UnmarshalG1 / UnmarshalG2 (curves/altbn128.go:296-376); the caller's bytes are NOT
+            # mutated (the reference clears the sign bit in place, :306-309,344-349)
+            o, ok = _lib.out(self._pt_size(group)), _lib.out(1)
+            rc = _lib.load().bgls_decompress_points(self.id, group, _lib.buf(data), 1, o, ok)
+            if rc != 0 or ok[0] != 1:
+                return None, False
+            return Point(self, group, bytes(o)), True
         if data is None or len(data) != self._pt_size(group):
-            return None, False                      # compressed forms: next row
+            return None, False
         if _lib.load().bgls_point_check(self.id, group, _lib.buf(data)) != 1:
             return None, False
         return Point(self, group, data), True

@@ -74,7 +74,19 @@ func (pt *hipPoint) Equals(o Point) bool {
 	return ok && q.c == pt.c && q.group == pt.group && bytes.Equal(q.raw, pt.raw)
 }
 func (pt *hipPoint) MarshalUncompressed() []byte { return append([]byte(nil), pt.raw...) }
-func (pt *hipPoint) Marshal() []byte             { return pt.MarshalUncompressed() } // compressed forms: SURVEY 8f-2
+
+// Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221); BLS12-381's compressed layout is the
+// upstream library's and unpinned, so the uncompressed bytes are returned there.
+func (pt *hipPoint) Marshal() []byte {
+	if pt.c.id != C.BGLS_CURVE_ALTBN128 {
+		return pt.MarshalUncompressed()
+	}
+	out := make([]byte, len(pt.raw)/2)
+	if C.bgls_compress_points(pt.c.id, pt.group, p(pt.raw), 1, p(out)) != 0 {
+		return nil
+	}
+	return out
+}
 func (pt *hipPoint) Mul(k *big.Int) Point {
 	sign := []byte{0}
 	mag := new(big.Int).Set(k) // the caller's scalar is never mutated (unlike curves/bls12_381.go:70)
@@ -123,6 +135,14 @@ func (t hipPointT) Mul(k *big.Int) PointT { panic("GT exponentiation: not on the
 func (c *hipCurve) Name() string { return c.name }
 
 func (c *hipCurve) unmarshal(group C.int, data []byte) (Point, bool) {
+	if c.id == C.BGLS_CURVE_ALTBN128 && 2*len(data) == c.size(group) { // compressed branch, curves/altbn128.go:296-376
+		out := make([]byte, c.size(group))
+		ok := []byte{0}
+		if C.bgls_decompress_points(c.id, group, p(data), 1, p(out), p(ok)) != 0 || ok[0] != 1 {
+			return nil, false
+		}
+		return &hipPoint{c, group, out}, true
+	}
 	if len(data) != c.size(group) || C.bgls_point_check(c.id, group, p(data)) != 1 {
 		return nil, false
 	}
@@ -370,4 +390,37 @@ func HipVerifyMultiWithMultiplicity(curve CurveSystem, aggsig Point, keys []Poin
 		return false
 	}
 	return C.bgls_verify_multi_multiplicity(c.id, p(s.raw), p(kb), (*C.int64_t)(&multiplicity[0]), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
+}
+
+// HipUnmarshalG2Batch decodes n compressed or uncompressed alt-bn128 keys in one call (the batch form of UnmarshalG2 for
+// key sets arriving over the wire); ok[i] mirrors the per-point (Point, bool).
+func HipUnmarshalG2Batch(curve CurveSystem, data []byte, n int) ([]Point, []bool) {
+	c, isHip := curve.(*hipCurve)
+	if !isHip || n == 0 || len(data)%n != 0 {
+		return nil, nil
+	}
+	sz := c.size(C.BGLS_G2)
+	raw := data
+	oks := make([]byte, n)
+	if len(data)/n*2 == sz {
+		raw = make([]byte, n*sz)
+		if C.bgls_decompress_points(c.id, C.BGLS_G2, p(data), C.size_t(n), p(raw), p(oks)) != 0 {
+			return nil, nil
+		}
+	} else {
+		for i := range oks {
+			if C.bgls_point_check(c.id, C.BGLS_G2, p(raw[i*sz:(i+1)*sz])) == 1 {
+				oks[i] = 1
+			}
+		}
+	}
+	pts := make([]Point, n)
+	good := make([]bool, n)
+	for i := range pts {
+		if oks[i] == 1 {
+			pts[i] = &hipPoint{c, C.BGLS_G2, append([]byte(nil), raw[i*sz:(i+1)*sz]...)}
+			good[i] = true
+		}
+	}
+	return pts, good
 }

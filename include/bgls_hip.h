@@ -123,6 +123,17 @@ int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys
 int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity,
                                    size_t n, const uint8_t* msg, size_t msg_len);
 
+/* ---- compressed wire formats ------------------------------------------------------------- */
+/* Point.Marshal of alt-bn128 (curves/altbn128.go:81-89 G1, :203-221 G2): out = n compressed points -- G1: x (32-byte
+ * big-endian) with the top bit of byte 0 set iff 2y > q; G2: x_im || x_re with the top bits set iff 2 y_im > q / 2 y_re > q;
+ * infinity = zeros.  Inputs are validated like every other point (BGLS_ERR_ENCODING).  alt-bn128 only: the BLS12-381
+ * compressed layout is the un-vendored dis2/bls12's and unpinned (curves/bls12_381.go:55,60,116,121). */
+int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out);
+/* UnmarshalG1 / UnmarshalG2, compressed branches (curves/altbn128.go:296-327, :329-376): square roots by calcQuadRes /
+ * calcComplexQuadRes (curves/hash.go:178-223), the component-wise sign rule, then the MakeG*Point validation.
+ * out = n uncompressed points (zeros where rejected), ok[i] = 1 / 0 = the reference's (Point, bool). */
+int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);
+
 /* ---- per-point operations backing the Go Point / PointT methods --------------------------- */
 /* Point.Add (curves/altbn128.go:59-66,181-188; curves/bls12_381.go:33-41,94-102) */
 int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out);

@@ -7,6 +7,8 @@
                      curves/altbn128_test.go:26-38 (G2 generator coordinates).
  hae_<curve>.json    BLAKE2Xb outputs, hashed aggregation exponents and accept/reject cases of the HAE /
                      multiplicity flows (bgls/blsHAE.go, bgls/blsKosk.go:137-150) from the Python oracle.
+ wire_altbn128.json  compressed point encodings and Unmarshal decisions (curves/altbn128.go:81-89,203-221,296-376)
+                     from the Python oracle (oracle/pyref/wire.py).
  vectors_<curve>.json  outputs of the Python oracle (oracle/pyref) on seeded inputs: Miller / GT
                      values, pairing products, group sums, scalar multiples, extra hash-to-G1
                      messages, end-to-end accept/reject cases mirroring bgls/bgls_test.go:40-77 and
@@ -185,7 +187,52 @@ def hae(c, seed):
     json.dump(v, open(os.path.join(HERE, "hae_%s.json" % c.name), "w"), indent=0)
 
 
+def wire_vectors(seed):
+    """wire_altbn128.json: compressed forms (curves/altbn128.go:81-89,203-221) and Unmarshal decisions (:296-376) from the
+    Python oracle (oracle/pyref/wire.py): valid points with all sign-bit patterns, infinity, random x (about half have no
+    point), inconsistent G2 sign bits, non-canonical x."""
+    from oracle.pyref import wire
+    c = BN254
+    rnd = random.Random(seed)
+    G = Pairing(c).G
+    v = {"g1": [], "g2": [], "g1_decode": [], "g2_decode": []}
+    for i in range(8):
+        P = G.g1_mul(c.g1, rnd.randrange(1, c.r)); Q = G.g2_mul(c.g2, rnd.randrange(1, c.r))
+        v["g1"].append({"pt": G.g1_bytes(P).hex(), "compressed": wire.compress_g1(P).hex()})
+        v["g2"].append({"pt": G.g2_bytes(Q).hex(), "compressed": wire.compress_g2(Q).hex()})
+    v["g1"].append({"pt": G.g1_bytes(None).hex(), "compressed": wire.compress_g1(None).hex()})
+    v["g2"].append({"pt": G.g2_bytes(None).hex(), "compressed": wire.compress_g2(None).hex()})
+    def dec1(d):
+        pt, ok = wire.decompress_g1(d)
+        return {"in": d.hex(), "ok": ok, "pt": G.g1_bytes(pt).hex() if ok else None}
+    def dec2(d):
+        pt, ok = wire.decompress_g2(d)
+        return {"in": d.hex(), "ok": ok, "pt": G.g2_bytes(pt).hex() if ok else None}
+    for row in v["g1"]:
+        d = bytearray(bytes.fromhex(row["compressed"]))
+        v["g1_decode"].append(dec1(bytes(d)))
+        d[0] ^= 128
+        v["g1_decode"].append(dec1(bytes(d)))
+    for row in v["g2"]:
+        d = bytearray(bytes.fromhex(row["compressed"]))
+        for m0, m1 in ((0, 0), (128, 0), (0, 128), (128, 128)):
+            e = bytearray(d); e[0] ^= m0; e[32] ^= m1
+            v["g2_decode"].append(dec2(bytes(e)))
+    for i in range(24):
+        d = bytearray(rnd.randbytes(32)); d[0] &= rnd.choice((0x3f, 0xbf, 0xff))
+        v["g1_decode"].append(dec1(bytes(d)))
+    for i in range(12):
+        d = bytearray(rnd.randbytes(64)); d[0] &= rnd.choice((0x3f, 0xbf)); d[32] &= rnd.choice((0x3f, 0xbf))
+        v["g2_decode"].append(dec2(bytes(d)))
+    v["g1_decode"].append(dec1((c.p + 5).to_bytes(32, "big")))
+    v["g2_decode"].append(dec2((c.p + 5).to_bytes(32, "big") + (7).to_bytes(32, "big")))
+    assert any(r["ok"] for r in v["g1_decode"][18:]) and any(not r["ok"] for r in v["g1_decode"][18:])
+    json.dump(v, open(os.path.join(HERE, "wire_altbn128.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
+    if "--wire-only" in sys.argv:
+        wire_vectors(20261002); print("wire fixtures written"); sys.exit(0)
     if "--hae-only" in sys.argv:
         hae(BN254, 20260930); hae(BLS381, 20261001)
         print("hae fixtures written"); sys.exit(0)
@@ -194,4 +241,5 @@ if __name__ == "__main__":
     vectors(BLS381, 20260929)
     hae(BN254, 20260930)
     hae(BLS381, 20261001)
+    wire_vectors(20261002)
     print("golden fixtures written")

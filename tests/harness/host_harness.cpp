@@ -3,6 +3,7 @@
 #include <string.h>
 #include "../../bgls_amd/csrc/pairing.hpp"
 #include "../../bgls_amd/csrc/h2c.hpp"
+#include "../../bgls_amd/csrc/wire.hpp"
 
 using namespace bgls;
 
@@ -159,6 +160,44 @@ int ht_blake2b(const uint8_t* msg, size_t len, int k, uint8_t* out) {
   ByteSrc s; s.msg = msg; s.len = len; s.npre = 0; s.pre[0] = 0; s.suf[0]='G'; s.suf[1]='1'; s.suf[2]='_'; s.suf[3]='0'+k; s.nsuf = 4;
   u32 d[16]; blake2b512(s, d);
   for (int i = 0; i < 16; ++i) { out[4*i] = d[i] >> 24; out[4*i+1] = d[i] >> 16; out[4*i+2] = d[i] >> 8; out[4*i+3] = d[i]; }
+  return 0;
+}
+// compressed alt-bn128 forms (wire.hpp): op 0 = compress G1 (64 -> 32), 1 = compress G2 (128 -> 64),
+// 2 = decompress G1 (32 -> 64), 3 = decompress G2 (64 -> 128).  Returns 1 ok / 0 "nil,false" / -1 bad input.
+int ht_wire(int op, const uint8_t* in, uint8_t* out) {
+  typedef BN254 C;
+  if (op == 0) {
+    Aff<F1<C>> p;
+    if (!g1_from_bytes<C>(p, in) || !aff_on_curve<F1<C>>(p)) return -1;
+    g1_compress<C>(out, p);
+    return 1;
+  }
+  if (op == 1) {
+    Aff<F2<C>> p;
+    if (!g2_from_bytes<C>(p, in) || !aff_on_curve<F2<C>>(p)) return -1;
+    g2_compress<C>(out, p);
+    return 1;
+  }
+  if (op == 2) {
+    Aff<F1<C>> p;
+    if (!g1_decompress<C>(p, in)) return 0;
+    g1_to_bytes<C>(out, p);
+    return 1;
+  }
+  if (op == 3) {
+    Aff<F2<C>> p;
+    if (!g2_decompress<C>(p, in)) return 0;
+    g2_to_bytes<C>(out, p);
+    return 1;
+  }
+  return -1;
+}
+// one BLAKE2Xb expansion node (hashes.hpp blake2xb_node) from a 64-byte root
+int ht_blake2xb_node(const uint8_t* root, uint32_t i, uint32_t xof_len, uint32_t take, uint8_t* out) {
+  u64 r[8], o[8];
+  for (int k = 0; k < 8; ++k) { r[k] = 0; for (int b = 7; b >= 0; --b) r[k] = (r[k] << 8) | root[8 * k + b]; }
+  blake2xb_node(r, i, xof_len, take, o);
+  for (uint32_t b = 0; b < take; ++b) out[b] = (uint8_t)(o[b >> 3] >> (8 * (b & 7)));
   return 0;
 }
 }

@@ -119,3 +119,59 @@ def test_hashes_and_h2c(host_harness, curve, kat):
         o = out(2 * n)
         assert lib.ht_hash_to_g1(cid, B(m), ctypes.c_size_t(len(m)), o) == 0
         assert bytes(o).hex() == row["point"]
+
+
+def test_wire_formats_and_blake2x_node(host_harness):
+    """wire.hpp (alt-bn128 compressed forms, curves/altbn128.go:81-89,203-221,296-376) and hashes.hpp's BLAKE2Xb node,
+    compiled for the host, against the Python oracle: round trips, sign-bit rules, rejected encodings."""
+    import ctypes, random
+    from oracle.pyref import wire, hashes
+    from oracle.pyref.params import BN254 as C
+    from oracle.pyref.groups import Groups
+    G = Groups(C)
+    rnd = random.Random(41)
+    B = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b))
+
+    def run(op, data, outlen):
+        o = (ctypes.c_uint8 * outlen)()
+        return host_harness.ht_wire(op, B(data), o), bytes(o)
+
+    for _ in range(12):
+        P = G.g1_mul(C.g1, rnd.randrange(1, C.r)); Q = G.g2_mul(C.g2, rnd.randrange(1, C.r))
+        rc, c1 = run(0, G.g1_bytes(P), 32); assert rc == 1 and c1 == wire.compress_g1(P)
+        rc, c2 = run(1, G.g2_bytes(Q), 64); assert rc == 1 and c2 == wire.compress_g2(Q)
+        rc, u1 = run(2, c1, 64); assert rc == 1 and u1 == G.g1_bytes(P)
+        rc, u2 = run(3, c2, 128); assert rc == 1 and u2 == G.g2_bytes(Q)
+        f = bytearray(c1); f[0] ^= 128
+        rc, u = run(2, f, 64); assert rc == 1 and u == G.g1_bytes(G.g1_neg(P))
+        f = bytearray(c2); f[0] ^= 128
+        assert run(3, f, 128)[0] == 0 and wire.decompress_g2(bytes(f))[1] is False        # one bit only: not a point
+        f[32] ^= 128
+        rc, u = run(3, f, 128); assert rc == 1 and u == G.g2_bytes(G.g2_neg(Q))
+    # arbitrary x: same accept / reject decision and same bytes as the oracle
+    for _ in range(40):
+        d1 = bytearray(rnd.randbytes(32)); d1[0] &= rnd.choice((0x3f, 0xbf, 0xff))
+        pt, ok = wire.decompress_g1(bytes(d1))
+        rc, u = run(2, d1, 64)
+        assert rc == (1 if ok else 0) and (not ok or u == G.g1_bytes(pt))
+    for _ in range(16):
+        d2 = bytearray(rnd.randbytes(64)); d2[0] &= rnd.choice((0x3f, 0xbf)); d2[32] &= rnd.choice((0x3f, 0xbf))
+        pt, ok = wire.decompress_g2(bytes(d2))
+        rc, u = run(3, d2, 128)
+        assert rc == (1 if ok else 0) and (not ok or u == G.g2_bytes(pt))
+    assert run(2, bytes(32), 64) == (1, bytes(64)) and run(3, bytes(64), 128) == (1, bytes(128))
+    assert run(2, b"\x80" + bytes(31), 64) == (1, bytes(64))                              # x = 0 with the flag: still infinity
+    assert run(0, bytes(64), 32) == (1, bytes(32)) and run(1, bytes(128), 64) == (1, bytes(64))
+    assert run(2, (C.p + 1).to_bytes(32, "big"), 64)[0] == 0                               # x >= q
+    # BLAKE2Xb node
+    for ln, ol in ((0, 16), (100, 64), (300, 65), (10, 1000)):
+        d = rnd.randbytes(ln)
+        root = __import__("hashlib").blake2b(d, digest_size=64, node_offset=ol << 32).digest()
+        want = hashes.blake2xb(d, ol)
+        got = b""
+        for i in range((ol + 63) // 64):
+            take = min(64, ol - 64 * i)
+            o = (ctypes.c_uint8 * 64)()
+            host_harness.ht_blake2xb_node(B(root), i, ol, take, o)
+            got += bytes(o)[:take]
+        assert got == want
