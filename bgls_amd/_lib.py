@@ -49,6 +49,7 @@ SIGNATURES = {
     "bgls_final_verify_dev": (ci, [ci, vp, sz, vp, vp]),
     "bgls_aggregate_points_dev": (ci, [ci, ci, vp, sz, vp, vp]),
     "bgls_verify_multi_dev": (ci, [ci, vp, vp, sz, vp, sz, vp]),
+    "bgls_verify_multi_submit_dev": (ci, [ci, vp, vp, sz, vp, sz, vp]),
     "bgls_profile_enable": (ci, [ci]),
     "bgls_profile_get": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong)]),
     "bgls_probe_mad_peak": (ci, [ctypes.POINTER(ctypes.c_double)]),

@@ -1799,7 +1799,7 @@ int verify_aggregate_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* b
 
 template <class C>
 int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, size_t n, const uint8_t* d_msg,
-                       size_t msg_len) {
+                       size_t msg_len, bool submit_only = false) {
   typedef Engine<C> E;
   int rc;
   void *d_flags, *d_g2s, *d_g1s, *fa, *fb, *d_part;
@@ -1815,12 +1815,23 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   // h = -H(msg); pairs (h, apk), (sig, g2)
   MsgView mv = {d_msg, nullptr, msg_len, msg_len};
   Aff<F1<C>>* g1s = (Aff<F1<C>>*)d_g1s;
-  k_h2c<C><<<1, 64, 0, st>>>(mv, 1, g1s + 2, (uint32_t*)d_flags);
-  k_g1_to_bytes<C><<<1, 64, 0, st>>>(g1s + 2, 1, (uint8_t*)d_part);           // scratch: H(m) bytes
-  k_g1_parse<C><<<1, 64, 0, st>>>((const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);  // -H(m)
-  k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);               // sig
-  k_miller<C><<<1, 64, 0, st>>>(g1s, (const uint8_t*)d_g2s, 2, 1LL, (Fp12<C>*)fa, (uint32_t*)d_flags);
-  if ((rc = E::reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, 2, (uint8_t*)d_part))) return rc;
+  if (use_coop()) {
+    // one message through the batch hashing path, then the two-pairing product on the cooperative Miller kernel with
+    // the (sig, g2) pair on the pre-computed generator lines
+    if ((rc = E::hash_to_g1(c, st, mv, 1, g1s + 2, (uint32_t*)d_flags))) return rc;
+    k_g1_to_bytes<C><<<1, 64, 0, st>>>(g1s + 2, 1, (uint8_t*)d_part);           // scratch: H(m) bytes
+    k_g1_parse<C><<<1, 64, 0, st>>>((const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);  // -H(m)
+    k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);               // sig
+    if ((rc = E::miller_coop(c, st, g1s, (const uint8_t*)d_g2s, 2, 1LL, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
+  } else {
+    k_h2c<C><<<1, 64, 0, st>>>(mv, 1, g1s + 2, (uint32_t*)d_flags);
+    k_g1_to_bytes<C><<<1, 64, 0, st>>>(g1s + 2, 1, (uint8_t*)d_part);           // scratch: H(m) bytes
+    k_g1_parse<C><<<1, 64, 0, st>>>((const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);  // -H(m)
+    k_g1_parse<C><<<1, 64, 0, st>>>(d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);               // sig
+    k_miller<C><<<1, 64, 0, st>>>(g1s, (const uint8_t*)d_g2s, 2, 1LL, (Fp12<C>*)fa, (uint32_t*)d_flags);
+    if ((rc = E::reduce_to_bytes(st, (Fp12<C>*)fa, (Fp12<C>*)fb, 2, (uint8_t*)d_part))) return rc;
+  }
+  if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
   return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
 }
 
@@ -2103,13 +2114,14 @@ int aggregate_points_dev_t(int group, const void* d_pts, size_t n, void* d_out, 
 }
 
 template <class C>
-int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len, void* stream) {
+int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len, void* stream,
+                             bool submit_only = false) {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   int rc;
   if ((rc = c.ensure())) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c.stream;
-  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len);
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len, submit_only);
 }
 
 // ---- hashed aggregation exponents / weighted sums: host flows -------------------------------------------------
@@ -2576,6 +2588,12 @@ int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size
                           void* stream) {
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
+}
+
+int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
+                                 void* stream) {
+  if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream, true));
 }
 
 /* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */

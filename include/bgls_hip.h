@@ -190,6 +190,9 @@ int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n,
 /* verify_multi with keys already on the device. */
 int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg,
                           size_t msg_len, void* stream);
+/* The same without waiting: the verdict is collected with bgls_final_verify_collect on the same context. */
+int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg,
+                                 size_t msg_len, void* stream);
 
 /* ---- measurement hooks (bench.py; not part of the reference's interface) ------------------ */
 /* Per-stage device time, measured with HIP events on the stream the kernels are launched on.
