@@ -1725,17 +1725,28 @@ struct Engine {
       HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
       return 0;
     }
-    const int R = 16;
+    // Fan-in per pass.  A pass costs (fan-in - 1) dependent additions of latency, so once the partial sums no longer
+    // fill the chip (two resident waves per SIMD at these register counts = 131 072 threads) the tree narrows by 2
+    // per pass instead of 16: log2 passes of ONE addition each instead of a few passes of 15.  BGLS_SUM_R forces one
+    // fan-in everywhere (16 = the earlier shape) for A/B runs.
+    static const int forced = [] { const char* e = getenv("BGLS_SUM_R"); return e ? atoi(e) : 0; }();
+    auto fan = [&](size_t items) {
+      if (forced >= 2) return forced;
+      size_t r = (items + 131071) / 131072;
+      return (int)(r < 2 ? 2 : r > 16 ? 16 : r);
+    };
     void *ja, *jb;
     int rc;
     Scope sc(c, st, ST_SUM);
-    size_t n1 = (n + R - 1) / R;
+    const int R1 = fan(n);
+    size_t n1 = (n + R1 - 1) / R1;
     if ((rc = c.get(WS_JAC_A, (n1 + 1) * sizeof(Jac<F>), &ja))) return rc;
-    if ((rc = c.get(WS_JAC_B, (n1 / R + 2) * sizeof(Jac<F>), &jb))) return rc;
-    k_sum_first<F, PTB><<<nblk(n1, 64), 64, 0, st>>>(d_pts, n, R, (Jac<F>*)ja, d_flags);
+    if ((rc = c.get(WS_JAC_B, (n1 / 2 + 2) * sizeof(Jac<F>), &jb))) return rc;
+    k_sum_first<F, PTB><<<nblk(n1, 64), 64, 0, st>>>(d_pts, n, R1, (Jac<F>*)ja, d_flags);
     Jac<F>*a = (Jac<F>*)ja, *b = (Jac<F>*)jb;
     size_t cnt = n1;
     while (cnt > 1) {
+      const int R = fan(cnt);
       size_t nout = (cnt + R - 1) / R;
       k_sum_next<F><<<nblk(nout, 64), 64, 0, st>>>(a, cnt, R, b);
       Jac<F>* t = a;
@@ -2215,16 +2226,17 @@ int weighted_sum_dev(Ctx& c, hipStream_t st, const uint8_t* d_pts, const uint8_t
     HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
     return 0;
   }
-  const int R = 16;
   void *ja, *jb;
   int rc;
   Scope sc(c, st, ST_SUM);
   if ((rc = c.get(WS_JAC_A, (n + 1) * sizeof(Jac<F>), &ja))) return rc;
-  if ((rc = c.get(WS_JAC_B, (n / R + 2) * sizeof(Jac<F>), &jb))) return rc;
+  if ((rc = c.get(WS_JAC_B, (n / 2 + 2) * sizeof(Jac<F>), &jb))) return rc;
   k_wsum_first<F, PTB><<<nblk(n, 64), 64, 0, st>>>(d_pts, d_w16, d_signs, n, 1, (Jac<F>*)ja, d_flags);
   Jac<F>*a = (Jac<F>*)ja, *b = (Jac<F>*)jb;
   size_t cnt = n;
   while (cnt > 1) {
+    size_t r16 = (cnt + 131071) / 131072;                 // same fan-in rule as Engine::sum_points
+    const int R = (int)(r16 < 2 ? 2 : r16 > 16 ? 16 : r16);
     size_t nout = (cnt + R - 1) / R;
     k_sum_next<F><<<nblk(nout, 64), 64, 0, st>>>(a, cnt, R, b);
     Jac<F>* t = a;
