@@ -25,6 +25,8 @@ SIGNATURES = {
     "bgls_verify_aggregate": (ci, [ci, u8p, u8p, u8p, u64p, sz, ci]),
     "bgls_verify_multi": (ci, [ci, u8p, u8p, sz, u8p, sz]),
     "bgls_pairing_product": (ci, [ci, u8p, u8p, sz, u8p]),
+    "bgls_scale_generator": (ci, [ci, ci, u8p, sz, u8p]),
+    "bgls_sign_batch": (ci, [ci, u8p, u8p, u64p, sz, u8p]),
     "bgls_compress_points": (ci, [ci, ci, u8p, sz, u8p]),
     "bgls_decompress_points": (ci, [ci, ci, u8p, sz, u8p, u8p]),
     "bgls_hae_exponents": (ci, [ci, u8p, sz, u8p]),

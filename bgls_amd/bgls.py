@@ -164,3 +164,42 @@ def KoskVerifyMultiSignatureWithMultiplicity(curve, aggsig, keys, multiplicity, 
     rc = _lib.load().bgls_verify_multi_multiplicity(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in keys)), mult,
                                                     len(keys), _lib.buf(m2), len(m2))
     return rc == 1
+
+
+# ---- batch forms of KeyGen / Sign -------------------------------------------------------------
+def LoadPublicKeys(curve, sks):
+    """LoadPublicKey (bgls/bgls.go:40-43) for a list of secret keys in one call."""
+    n = len(sks)
+    if n == 0:
+        return []
+    size = len(curve.GetG2().raw)
+    o = _lib.out(n * size)
+    rc = _lib.load().bgls_scale_generator(curve.id, G2, _lib.buf(b"".join((sk % (1 << 256)).to_bytes(32, "big") for sk in sks)), n, o)
+    if rc != 0:
+        raise RuntimeError("bgls_scale_generator: %s" % _lib.last_error())
+    raw = bytes(o)
+    return [Point(curve, G2, raw[i * size:(i + 1) * size]) for i in range(n)]
+
+
+def SignBatch(curve, sks, msgs, kosk=False):
+    """Sign / KoskSign (bgls/bgls.go:46-56, bgls/blsKosk.go:73-77) for n (secret key, message) pairs in one call."""
+    n = len(sks)
+    if n != len(msgs):
+        return None
+    if n == 0:
+        return []
+    ms = [(b"\x01" + bytes(m)) if kosk else bytes(m) for m in msgs]
+    off = (ctypes.c_uint64 * (n + 1))()
+    acc = 0
+    for i, m in enumerate(ms):
+        off[i] = acc
+        acc += len(m)
+    off[n] = acc
+    size = len(curve.GetG1().raw)
+    o = _lib.out(n * size)
+    rc = _lib.load().bgls_sign_batch(curve.id, _lib.buf(b"".join((sk % (1 << 256)).to_bytes(32, "big") for sk in sks)),
+                                     _lib.buf(b"".join(ms)), off, n, o)
+    if rc != 0:
+        raise RuntimeError("bgls_sign_batch: %s" % _lib.last_error())
+    raw = bytes(o)
+    return [Point(curve, G1, raw[i * size:(i + 1) * size]) for i in range(n)]

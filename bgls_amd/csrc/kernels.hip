@@ -546,6 +546,32 @@ __global__ void __launch_bounds__(64) k_wsum_first(const uint8_t* pts, const uin
   out[t] = acc;
 }
 
+// ---- batch key generation / signing ----
+// out[i] = k_i * P_i with P_i taken from a device array of affine points (the hash-to-G1 output: Sign, bgls/bgls.go:46-56)
+// or, when pts == nullptr, the group generator (LoadPublicKey, bgls/bgls.go:40-43: GetG2().Mul(sk)).  Scalars are 32-byte
+// big-endian, as everywhere at the seam.
+template <class C, class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_scale_aff(const Aff<F>* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  if (pts) {
+    p = pts[i];
+  } else {
+    if constexpr (PT_BYTES == 2 * C::FP_BYTES) p = Aff<F>{fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+    else p = Aff<F>{f2_load<C>(C::G2), f2_load<C>(C::G2 + 2 * C::L), false};
+  }
+  u32 k[8];
+  int top = -1;
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = scalars + i * 32 + 4 * (7 - j);
+    k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  for (int j = 7; j >= 0 && top < 0; --j)
+    if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul<F>(p, k, top + 1)));
+}
+
 template <class F, int PT_BYTES>
 __global__ void k_check(const uint8_t* pts, size_t n, uint32_t* flags) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -2399,6 +2425,66 @@ int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n
   return flags_to_rc(f);
 }
 
+// LoadPublicKey over a batch (bgls/bgls.go:40-43): out[i] = sk_i * g2 (group = BGLS_G2) or sk_i * g1
+template <class C>
+int scale_generator_t(int group, const uint8_t* sks, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_sc, *d_out;
+  if ((rc = c.get(WS_IN_C, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_IN_A, n * PB, &d_out))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
+  if (group == BGLS_G1)
+    k_scale_aff<C, F1<C>, (int)E::G1B><<<nblk(n, 64), 64, 0, st>>>(nullptr, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  else
+    k_scale_aff<C, F2<C>, (int)E::G2B><<<nblk(n, 64), 64, 0, st>>>(nullptr, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// Sign over a batch (bgls/bgls.go:46-56): out[i] = sk_i * HashToG1(msg_i); the hash points never leave the device
+template <class C>
+int sign_batch_t(const uint8_t* sks, const uint8_t* blob, const uint64_t* off, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.ensure())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = off[n];
+  void *d_blob, *d_off, *d_g1s, *d_out, *d_flags, *d_sc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_G1S, n * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_IN_B, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::hash_to_g1(c, st, mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags))) return rc;
+  k_scale_aff<C, F1<C>, (int)E::G1B><<<nblk(n, 64), 64, 0, st>>>((const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
 bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
 
 }  // namespace
@@ -2646,6 +2732,17 @@ int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uin
 int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
   if (!group_ok(group) || (n && (!in || !out || !ok))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   return wire_points(curve, group, false, in, n, out, ok);
+}
+
+/* ---- batch key generation / signing (bgls/bgls.go:40-56) ---- */
+int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (!group_ok(group) || (n && (!scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, scale_generator_t<CV>(group, scalars, n, out));
+}
+
+int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* sigs_out) {
+  if (!msg_off || (n && (!sks || !sigs_out))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, sign_batch_t<CV>(sks, msg_blob, msg_off, n, sigs_out));
 }
 
 }  // extern "C"

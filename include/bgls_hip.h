@@ -123,6 +123,15 @@ int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys
 int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity,
                                    size_t n, const uint8_t* msg, size_t msg_len);
 
+/* ---- batch key generation and signing ---------------------------------------------------- */
+/* LoadPublicKey over a batch (bgls/bgls.go:40-43: curve.GetG2().Mul(sk)): out[i] = scalars[i] * generator of `group`
+ * (BGLS_G2 for public keys).  scalars: n x 32-byte big-endian. */
+int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out);
+/* Sign over a batch (bgls/bgls.go:46-56: HashToG1(msg).Mul(sk)); KoskSign is this call with 0x01 prepended to every
+ * message (bgls/blsKosk.go:73-77).  sigs_out: n G1 points. */
+int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
+                    uint8_t* sigs_out);
+
 /* ---- compressed wire formats ------------------------------------------------------------- */
 /* Point.Marshal of alt-bn128 (curves/altbn128.go:81-89 G1, :203-221 G2): out = n compressed points -- G1: x (32-byte
  * big-endian) with the top bit of byte 0 set iff 2y > q; G2: x_im || x_re with the top bits set iff 2 y_im > q / 2 y_re > q;

@@ -114,3 +114,30 @@ def test_curve_interface(curve):
     pt, ok = curve.UnmarshalG1(g1.MarshalUncompressed())
     assert ok and pt.Equals(g1)
     assert curve.UnmarshalG1(b"\x00" * 5) == (None, False)
+
+
+@pytest.mark.parametrize("curve", curves, ids=lambda c: c.Name())
+def test_batch_keygen_and_sign_match_per_point_calls_and_oracle(curve):
+    """bgls_scale_generator / bgls_sign_batch (LoadPublicKey, Sign, KoskSign of bgls/bgls.go:40-56 over a batch): same
+    bytes as the per-point mirror calls and as the C oracle; the signatures aggregate and verify."""
+    import random
+    from oracle import coracle
+    from bgls_amd.bgls import LoadPublicKeys, SignBatch, LoadPublicKey
+    rnd = random.Random(17 + curve.id)
+    n = 70
+    sks = [rnd.randrange(1, curve.GetG1Order()) for _ in range(n)]
+    sks[3] = 1
+    msgs = [rnd.randbytes(rnd.choice((8, 32, 64))) for _ in range(n)]
+    pks = LoadPublicKeys(curve, sks)
+    sigs = SignBatch(curve, sks, msgs)
+    ksigs = SignBatch(curve, sks, msgs, kosk=True)
+    for i in (0, 3, 11, n - 1):
+        assert pks[i].Equals(LoadPublicKey(curve, sks[i])) and sigs[i].Equals(Sign(curve, sks[i], msgs[i]))
+        assert ksigs[i].Equals(KoskSign(curve, sks[i], msgs[i]))
+        assert pks[i].raw == coracle.scale_point(curve.id, 2, curve.GetG2().raw, sks[i])
+        assert sigs[i].raw == coracle.scale_point(curve.id, 1, coracle.hash_to_g1(curve.id, msgs[i]), sks[i])
+    assert pks[3].Equals(curve.GetG2())
+    assert VerifyAggregateSignature(curve, AggregateSignatures(sigs), pks, msgs)
+    assert KoskVerifyAggregateSignature(curve, AggregateSignatures(ksigs), pks, msgs)
+    assert not VerifyAggregateSignature(curve, AggregateSignatures(ksigs), pks, msgs)
+    assert SignBatch(curve, sks, msgs[:-1]) is None and LoadPublicKeys(curve, []) == []
