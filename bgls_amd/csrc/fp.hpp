@@ -162,6 +162,21 @@ BGLS_HD Fp<C> fp_dbl(const Fp<C>& a) {
   return fp_add<C>(a, a);
 }
 
+// a / 2 mod p without a multiplication: (a + (a odd ? p : 0)) >> 1.  Valid on Montgomery residues as well (halving
+// commutes with the factor R).  a + p < 2^(32 L) for both moduli (254 and 381 bits), so the sum needs no extra limb.
+template <class C>
+BGLS_HD Fp<C> fp_half(const Fp<C>& a) {
+  const u32 mask = 0u - (a.v[0] & 1u);
+  Fp<C> t;
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) t.v[j] = addc(a.v[j], C::P[j] & mask, c);
+  Fp<C> r;
+#pragma unroll
+  for (int j = 0; j < C::L; ++j) r.v[j] = (t.v[j] >> 1) | (j + 1 < C::L ? (t.v[j + 1] << 31) : 0u);
+  return r;
+}
+
 template <class C>
 BGLS_HD Fp<C> fp_mul3(const Fp<C>& a) {
   return fp_add<C>(fp_dbl<C>(a), a);

@@ -40,6 +40,8 @@ template <class C, bool INL>
 BGLS_HD Fp2<C> f2s(const Fp2<C>& a) {
   if constexpr (INL) return f2_sqr_inl<C>(a); else return f2_sqr<C>(a);
 }
+template <class C>
+BGLS_HD Fp2<C> f2_half(const Fp2<C>& a) { return {fp_half<C>(a.c0), fp_half<C>(a.c1)}; }   // a / 2: shifts, no multiplication
 template <class C, bool INL>
 BGLS_HD Fp2<C> f2ms(const Fp2<C>& a, const Fp<C>& s) {      // by an Fp scalar
   if constexpr (INL) {
@@ -54,14 +56,13 @@ BGLS_HD Fp2<C> f2ms(const Fp2<C>& a, const Fp<C>& s) {      // by an Fp scalar
 
 template <class C, bool INL>
 BGLS_HD LineCoeffs<C> dbl_step_t(G2Proj<C>& R) {
-  Fp<C> half = fp_load<C>(C::HALF);
-  Fp2<C> A = f2ms<C, INL>(f2m<C, INL>(R.X, R.Y), half);
+  Fp2<C> A = f2_half<C>(f2m<C, INL>(R.X, R.Y));
   Fp2<C> B = f2s<C, INL>(R.Y);
   Fp2<C> Cc = f2s<C, INL>(R.Z);
   Fp2<C> b3 = {fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)};
   Fp2<C> E = f2m<C, INL>(b3, Cc);
   Fp2<C> Fv = f2_mul3<C>(E);
-  Fp2<C> G = f2ms<C, INL>(f2_add<C>(B, Fv), half);
+  Fp2<C> G = f2_half<C>(f2_add<C>(B, Fv));
   Fp2<C> H = f2_sub<C>(f2s<C, INL>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
   Fp2<C> I = f2_sub<C>(E, B);
   Fp2<C> J = f2s<C, INL>(R.X);
@@ -94,7 +95,6 @@ BGLS_HD LineCoeffs<C> add_step_t(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& y
 // so at most five Fp2 temporaries are live next to the running point.
 template <class C, class Emit>
 BGLS_HD void dbl_step_emit(G2Proj<C>& R, Emit&& emit) {
-  const Fp<C> half = fp_load<C>(C::HALF);
   Fp2<C> B = f2_sqr_inl<C>(R.Y);
   Fp2<C> Cc = f2_sqr_inl<C>(R.Z);
   Fp2<C> H = f2_sub<C>(f2_sqr_inl<C>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
@@ -102,11 +102,11 @@ BGLS_HD void dbl_step_emit(G2Proj<C>& R, Emit&& emit) {
   emit(2, f2_sub<C>(E, B));
   emit(0, f2_neg<C>(H));
   emit(1, f2_mul3<C>(f2_sqr_inl<C>(R.X)));
-  Fp2<C> A = f2ms<C, true>(f2_mul_inl<C>(R.X, R.Y), half);
+  Fp2<C> A = f2_half<C>(f2_mul_inl<C>(R.X, R.Y));
   R.Z = f2_mul_inl<C>(B, H);
   Fp2<C> Fv = f2_mul3<C>(E);
   R.X = f2_mul_inl<C>(A, f2_sub<C>(B, Fv));
-  Fp2<C> G = f2ms<C, true>(f2_add<C>(B, Fv), half);
+  Fp2<C> G = f2_half<C>(f2_add<C>(B, Fv));
   R.Y = f2_sub<C>(f2_sqr_inl<C>(G), f2_mul3<C>(f2_sqr_inl<C>(E)));
 }
 template <class C, class Emit>
