@@ -223,6 +223,7 @@ BGLS_HD void mul_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L], const u32 (&b)[C
   }
 }
 
+
 // t = a^2: off-diagonal products once, doubled, plus the diagonal.
 template <class C>
 BGLS_HD void sqr_wide(u32 (&t)[2 * C::L], const u32 (&a)[C::L]) {

@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       }
       ++step;
       wave_sync();
-      __syncthreads();
+      if constexpr (DBG != 3) __syncthreads();
       buf ^= 1;
     };
 #pragma unroll 1
@@ -1002,21 +1002,21 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      __syncthreads();
+      if constexpr (DBG != 3) __syncthreads();
       if constexpr (DBG != 1) {
         fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
         coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
       }
       fold();
       if (C::LOOP_NAF[i] != 0) {
-        __syncthreads();
+        if constexpr (DBG != 3) __syncthreads();
         fold();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
-      __syncthreads();
+      if constexpr (DBG != 3) __syncthreads();
       fold();
-      __syncthreads();
+      if constexpr (DBG != 3) __syncthreads();
       fold();
     } else {
       if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
@@ -1623,6 +1623,8 @@ struct Engine {
           const char* dbg = getenv("BGLS_AB64_DBG");
           if (C::CURVE_ID == 0 && dbg && dbg[0] == '1')
             k_miller_ab64<BN254, 1><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags, ab64_swap());
+          else if (C::CURVE_ID == 0 && dbg && dbg[0] == '3')
+            k_miller_ab64<BN254, 3><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags, ab64_swap());
           else if (C::CURVE_ID == 0 && dbg && dbg[0] == '2')
             k_miller_ab64<BN254, 2><<<(unsigned)nb64, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1s, g2s, npairs, gen_at, (const LineCoeffs<BN254>*)c.gen_lines[0], (Fp2<BN254>*)pa, d_flags, ab64_swap());
           else
