@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's own streams):
 # with the default, two of the four verification lanes land on one queue and serialise.  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -139,7 +139,7 @@ def bench_multisig(args, lib, cid, fp, n, dev, rank, world):
         raise RuntimeError("multisig correctness gate failed")
     # L verifications in flight (own context and stream each): the key sum of one overlaps the serial hash / pairing /
     # final-exponentiation tail of the others; every step is a complete verification whose verdict is checked
-    L = max(1, min(4, args.in_flight))
+    L = max(1, min(8, args.in_flight))
     lanes = [torch.cuda.Stream(device=dev) for _ in range(L)]
     torch.cuda.synchronize()
 
@@ -308,10 +308,13 @@ def main():
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
     ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 16, help="signers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4, help="single GPU: verifications kept in flight (1 = strictly sequential, max 4)")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="verifications kept in flight (1 = strictly sequential, max 8); default 4, multisig workload 8")
     ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae", "decompress"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
+    if args.in_flight is None:
+        args.in_flight = 8 if args.workload == "multisig" else 4
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -354,7 +357,7 @@ def main():
     # L verifications in flight on L library contexts / streams (default 4): every step is still one complete pass (duplicate
     # scan, hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound
     # stages of one step overlap the Miller launch of its neighbours.  --in-flight 1 runs them strictly one after the other.
-    L = max(1, min(4, args.in_flight))
+    L = max(1, min(8, args.in_flight))
     lanes = [{"stream": torch.cuda.Stream(device=dev), "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
               "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for _ in range(L)]
     torch.cuda.synchronize()

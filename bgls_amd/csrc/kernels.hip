@@ -1362,7 +1362,7 @@ struct Ctx {
 // Contexts: each owns a stream, its workspaces and its stage timers.  A host thread works on the context it selected
 // (bgls_select_context, default 0); two contexts let one thread keep two verifications in flight, so the serial,
 // latency-bound stages of one (hashing rounds, reduction tail, final exponentiation) overlap the other's Miller launch.
-constexpr int NCTX = 4;
+constexpr int NCTX = 8;
 thread_local int g_sel = 0;
 Ctx* ctx_all() {
   static Ctx c[NCTX];

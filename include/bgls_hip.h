@@ -188,7 +188,7 @@ int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const
  * flight per context. */
 int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream);
 int bgls_final_verify_collect(int curve);
-/* Contexts 0..3: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
+/* Contexts 0..7: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
  * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */
 int bgls_select_context(int index);
 
