@@ -463,8 +463,8 @@ def main():
                             "itself.  With %d in flight consecutive launches share the machine: launch_ms_events (HIP events around one "
                             "launch) stretches, launch_ms = timed region / launches is what a launch costs the machine." % (ex_cnt, L)}
         cname = "BN254" if cid == 0 else "BLS381"
-        # the library's dispatch rule (Engine::miller_coop): 64 pairings per block while one launch stays resident
-        miller_kernel = ("k_miller_ab64<%s>" % cname) if (n + 63) // 64 <= 1024 else ("k_miller_coop<%s>" % cname)
+        # the library's dispatch rule (Engine::miller_coop): 64 pairings per block, consecutive launches of 1024 blocks
+        miller_kernel = "k_miller_ab64<%s>%s" % (cname, "" if (n + 63) // 64 <= 1024 else " x%d launches" % (((n + 63) // 64 + 1023) // 1024))
         out = {
             "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

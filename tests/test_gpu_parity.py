@@ -450,3 +450,39 @@ def test_two_contexts_in_flight(gpu_lib, curve):
         assert gpu_lib.bgls_select_context(99) < 0
     finally:
         gpu_lib.bgls_select_context(0)
+
+
+def test_batch_beyond_one_launch(gpu_lib, curve):
+    """More than 2^16 signers: the Miller stage runs as consecutive 1024-block launches (the signature pair rides on the
+    first one, ragged tail on the last).  A valid instance verifies; corrupting a message in the first launch, in the
+    last launch or the signature rejects; the earlier single-wave kernel (BGLS_AB64_MAX_BLOCKS=1024 in a subprocess)
+    agrees on the verdicts."""
+    import subprocess, sys, os, tempfile
+    cid, n_fp = curve["id"], curve["fp"]
+    n = 65536 + 64 * 3 + 5
+    agg, keys, msgs = make_instance(gpu_lib, cid, n_fp, n, 31337)
+    blob = b"".join(msgs)
+    off = offsets(msgs)
+    assert gpu_lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(blob), off, n, 0) == 1
+    for pos in (64 * 10 + 3, 64 * (n - 2) + 1):
+        bad = bytearray(blob); bad[pos] ^= 0x40
+        assert gpu_lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(bytes(bad)), off, n, 0) == 0
+    g1 = out(2 * n_fp); gpu_lib.bgls_generator(cid, 1, g1)
+    assert gpu_lib.bgls_verify_aggregate(cid, g1, B(keys), B(blob), off, n, 0) == 0
+    with tempfile.TemporaryDirectory() as d:
+        for name, data in (("agg", agg), ("keys", keys), ("blob", blob)):
+            open(os.path.join(d, name), "wb").write(data)
+        code = r'''
+import ctypes, sys, os
+sys.path.insert(0, %r)
+from bgls_amd import _lib
+lib = _lib.load(); assert lib.bgls_init(0) == 0
+d = %r; n = %d
+rd = lambda f: open(os.path.join(d, f), "rb").read()
+B = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(b)
+off = (ctypes.c_uint64 * (n + 1))(*[64 * i for i in range(n + 1)])
+print("VERDICT", lib.bgls_verify_aggregate(%d, B(rd("agg")), B(rd("keys")), B(rd("blob")), off, n, 0))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), d, n, cid)
+        e = dict(os.environ); e["BGLS_AB64_MAX_BLOCKS"] = "1024"
+        o = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert "VERDICT 1" in o.stdout, (o.stdout[-300:], o.stderr[-500:])
