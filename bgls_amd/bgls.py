@@ -3,7 +3,7 @@
 import ctypes
 import secrets
 from . import _lib
-from .curves import AggregatePoints, Point, G1, G2
+from .curves import AggregatePoints, ScalePoints, Point, G1, G2
 
 
 def KeyGen(curve):                                   # bgls/bgls.go:30-37
@@ -203,3 +203,84 @@ def SignBatch(curve, sks, msgs, kosk=False):
         raise RuntimeError("bgls_sign_batch: %s" % _lib.last_error())
     raw = bytes(o)
     return [Point(curve, G1, raw[i * size:(i + 1) * size]) for i in range(n)]
+
+
+# ---- wrappers that are byte concatenation in front of the same path ---------------------------------------------
+def DistinctMsgSign(curve, sk, msg):                          # bgls/blsDistinctMessage.go:23-34
+    return Sign(curve, sk, LoadPublicKey(curve, sk).MarshalUncompressed() + bytes(msg))
+
+
+def DistinctMsgVerifySingleSignature(curve, sig, pubkey, msg):   # bgls/blsDistinctMessage.go:37-40
+    return VerifySingleSignature(curve, sig, pubkey, pubkey.MarshalUncompressed() + bytes(msg))
+
+
+def DistinctMsgVerifyAggregateSignature(curve, aggsig, keys, msgs):   # bgls/blsDistinctMessage.go:45-57
+    if len(keys) != len(msgs):
+        return False
+    return _verify_agg(curve, aggsig, keys, [k.MarshalUncompressed() + bytes(m) for k, m in zip(keys, msgs)], True)
+
+
+def Authenticate(curve, sk):                                  # bgls/blsKosk.go:44-55: a signature on the marshalled key
+    return Sign(curve, sk, LoadPublicKey(curve, sk).Marshal())
+
+
+def CheckAuthentication(curve, pubkey, authentication):      # bgls/blsKosk.go:59-69
+    return VerifySingleSignature(curve, authentication, pubkey, pubkey.Marshal())
+
+
+def KoskVerifyBatchMultiSignature(curve, aggsigs, pubkeys, msgs):    # bgls/blsKosk.go:126-133
+    aggsig = AggregateSignatures(aggsigs)
+    keys = [AggregateKeys(ks) for ks in pubkeys]
+    return KoskVerifyAggregateSignature(curve, aggsig, keys, msgs)
+
+
+def VerifyBatchMultiSignatureWithHAE(curve, aggsigs, aggpubkeys, msgs, allowDups):   # bgls/blsHAE.go:62-72
+    """As in the reference, the random factors of the allowDups branch are applied to a throw-away copy (ScalePoints
+    returns new points and the result is discarded, blsHAE.go:64-69), so both branches verify the plain aggregate."""
+    if allowDups:
+        ScalePoints(aggsigs, [secrets.randbelow(curve.GetG1Order()) for _ in aggsigs])
+    return _verify_agg(curve, AggregateSignatures(aggsigs), aggpubkeys, msgs, True)
+
+
+# ---- accountable-subgroup multisignatures (bgls/blsAsmSigs.go) -----------------------------------------------------
+def _ams_h0(curve, msg):                                      # getAmsH0, blsAsmSigs.go:73-78
+    return curve.HashToG1(b"\x00" + bytes(msg))
+
+
+def _ams_h2(curve, apk, msg):                                 # getAmsH2, blsAsmSigs.go:80-86
+    return curve.HashToG1(b"\x01" + apk.MarshalUncompressed() + bytes(msg))
+
+
+def AmsCreateMembershipKeySharesKnownExp(curve, sk, apk, exp, numSigners):   # blsAsmSigs.go:23-30
+    return [_ams_h2(curve, apk, str(i).encode()).Mul(sk).Mul(exp) for i in range(numSigners)]
+
+
+def AmsCreateMembershipKeyShares(curve, sk, curIndex, pubkeys):              # blsAsmSigs.go:17-21
+    t = hashPubKeysToExponents(pubkeys)
+    apk = AggregatePoints(ScalePoints(pubkeys, t))
+    return AmsCreateMembershipKeySharesKnownExp(curve, sk, apk, t[curIndex], len(pubkeys))
+
+
+def AmsAggregateMembershipKeyShares(curve, shares):           # blsAsmSigs.go:32-34
+    return AggregatePoints(shares)
+
+
+def AmsCreateSignatureShare(curve, sk, membershipKey, msg):   # blsAsmSigs.go:36-40
+    sig, _ = _ams_h0(curve, msg).Mul(sk).Add(membershipKey)
+    return sig
+
+
+def AmsCombineSignatureShares(pubkeys, sigs):                 # blsAsmSigs.go:42-46
+    return AggregatePoints(pubkeys), AggregateSignatures(sigs)
+
+
+def AmsVerifySignature(curve, apk, signers, aggKey, aggSig, msg):   # blsAsmSigs.go:48-59: a three-pairing product
+    aggMsg = AggregatePoints([_ams_h2(curve, apk, str(i).encode()) for i in signers])
+    pt, ok = curve.PairingProduct([_ams_h0(curve, msg), aggMsg, aggSig.Mul(-1)], [aggKey, apk, curve.GetG2()])
+    return ok and pt.Equals(curve.GetGTIdentity())
+
+
+def AmsVerifySignatureWithSetCheck(curve, check, apk, signers, aggKey, aggSig, msg):   # blsAsmSigs.go:61-66
+    if not check(signers):
+        return False
+    return AmsVerifySignature(curve, apk, signers, aggKey, aggSig, msg)

@@ -141,3 +141,91 @@ def test_batch_keygen_and_sign_match_per_point_calls_and_oracle(curve):
     assert KoskVerifyAggregateSignature(curve, AggregateSignatures(ksigs), pks, msgs)
     assert not VerifyAggregateSignature(curve, AggregateSignatures(ksigs), pks, msgs)
     assert SignBatch(curve, sks, msgs[:-1]) is None and LoadPublicKeys(curve, []) == []
+
+
+@pytest.mark.parametrize("curve", curves, ids=lambda c: c.Name())
+def test_distinct_message_scheme(curve):
+    """bgls/blsDistinctMessage_test.go:14-60 TestDistinctMsgSingleSigner + TestDistinctMsgAggregation"""
+    from bgls_amd.bgls import DistinctMsgSign, DistinctMsgVerifySingleSignature, DistinctMsgVerifyAggregateSignature
+    sk, vk, _ = KeyGen(curve)
+    msg = secrets.token_bytes(64)
+    sig = DistinctMsgSign(curve, sk, msg)
+    assert DistinctMsgVerifySingleSignature(curve, sig, vk, msg)
+    sig2, _ = sig.Copy().Add(curve.GetG1())
+    assert not DistinctMsgVerifySingleSignature(curve, sig2, vk, msg)
+    N = 6
+    msgs, sigs, pubkeys = [], [], []
+    for _ in range(N):
+        m = secrets.token_bytes(32)
+        sk, vk, _ = KeyGen(curve)
+        msgs.append(m); pubkeys.append(vk); sigs.append(DistinctMsgSign(curve, sk, m))
+    aggSig = AggregatePoints(sigs)
+    assert DistinctMsgVerifyAggregateSignature(curve, aggSig, pubkeys, msgs)
+    assert not DistinctMsgVerifyAggregateSignature(curve, aggSig, pubkeys[:N - 1], msgs)
+    same = [msgs[0]] * N                                      # identical payloads are fine: the key prefix makes them distinct
+    s2 = [DistinctMsgSign(curve, sk_, m_) for sk_, m_ in zip([KeyGen(curve)[0] for _ in range(N)], same)]
+    msgs[0] = msgs[1]
+    assert not VerifyAggregateSignature(curve, aggSig, pubkeys, msgs)
+
+
+@pytest.mark.parametrize("curve", curves, ids=lambda c: c.Name())
+def test_authentication_and_batch_multisig(curve):
+    """bgls/blsKosk.go:44-69 (Authenticate / CheckAuthentication) and :126-133 (KoskVerifyBatchMultiSignature),
+    bgls/blsHAE.go:62-72 (VerifyBatchMultiSignatureWithHAE)"""
+    from bgls_amd.bgls import Authenticate, CheckAuthentication, KoskVerifyBatchMultiSignature, VerifyBatchMultiSignatureWithHAE
+    sk, vk, _ = KeyGen(curve)
+    auth = Authenticate(curve, sk)
+    assert CheckAuthentication(curve, vk, auth)
+    _, vk2, _ = KeyGen(curve)
+    assert not CheckAuthentication(curve, vk2, auth)
+    groups, aggsigs, msgs = [], [], []
+    for g in range(3):
+        m = secrets.token_bytes(32)
+        ks, ss = [], []
+        for _ in range(4):
+            s_, v_, _ = KeyGen(curve)
+            ks.append(v_); ss.append(KoskSign(curve, s_, m))
+        groups.append(ks); aggsigs.append(AggregateSignatures(ss)); msgs.append(m)
+    assert KoskVerifyBatchMultiSignature(curve, aggsigs, groups, msgs)
+    assert not KoskVerifyBatchMultiSignature(curve, aggsigs, groups, msgs[::-1])
+    plain = [AggregateSignatures([Sign(curve, s_, m) for s_ in sks_]) for sks_, m in
+             (([11, 12], b"a" * 32), ([13, 14, 15], b"b" * 32))]
+    apks = [AggregateKeys([curve.GetG2().Mul(s_) for s_ in sks_]) for sks_ in ([11, 12], [13, 14, 15])]
+    for dups in (False, True):
+        assert VerifyBatchMultiSignatureWithHAE(curve, plain, apks, [b"a" * 32, b"b" * 32], dups)
+    assert not VerifyBatchMultiSignatureWithHAE(curve, plain, apks, [b"a" * 32, b"c" * 32], False)
+
+
+@pytest.mark.parametrize("curve", curves, ids=lambda c: c.Name())
+def test_ams_consistency(curve):
+    """bgls/blsAsmSigs_test.go:15-60 TestAmsConsistency (6 keys / 4 signers instead of 15 / 8)"""
+    from bgls_amd.bgls import (AmsAggregateMembershipKeyShares, AmsCombineSignatureShares, AmsCreateMembershipKeyShares,
+                               AmsCreateMembershipKeySharesKnownExp, AmsCreateSignatureShare, AmsVerifySignature,
+                               AmsVerifySignatureWithSetCheck, hashPubKeysToExponents, _ams_h2)
+    numKeys, numSigners = 6, 4
+    sks, pubkeys = [], []
+    for _ in range(numKeys):
+        s_, v_, _ = KeyGen(curve)
+        sks.append(s_); pubkeys.append(v_)
+    exps = hashPubKeysToExponents(pubkeys)
+    apk = AggregatePoints(ScalePoints(pubkeys, exps))
+    mk = []
+    for i in range(numKeys):
+        shares = AmsCreateMembershipKeyShares(curve, sks[i], i, pubkeys)
+        known = AmsCreateMembershipKeySharesKnownExp(curve, sks[i], apk, exps[i], numKeys)
+        assert all(a.Equals(b) for a, b in zip(shares, known))
+        mk.append(shares)
+    membership = [AmsAggregateMembershipKeyShares(curve, [mk[j][i] for j in range(numKeys)]) for i in range(numKeys)]
+    for i in (0, numKeys - 1):
+        p1, ok1 = curve.Pair(membership[i], curve.GetG2())
+        p2, ok2 = curve.Pair(_ams_h2(curve, apk, str(i).encode()), apk)
+        assert ok1 and ok2 and p1.Equals(p2)
+    msg = secrets.token_bytes(64)
+    shares = [AmsCreateSignatureShare(curve, sks[i], membership[i], msg) for i in range(numSigners)]
+    aggKey, aggSig = AmsCombineSignatureShares(pubkeys[:numSigners], shares)
+    signer_set = list(range(numSigners))
+    assert AmsVerifySignature(curve, apk, signer_set, aggKey, aggSig, msg)
+    assert AmsVerifySignatureWithSetCheck(curve, lambda s: len(s) > 3, apk, signer_set, aggKey, aggSig, msg)
+    assert not AmsVerifySignatureWithSetCheck(curve, lambda s: len(s) > 5, apk, signer_set, aggKey, aggSig, msg)
+    assert not AmsVerifySignature(curve, apk, signer_set, aggKey, aggSig, secrets.token_bytes(64))
+    assert not AmsVerifySignature(curve, apk, signer_set[:-1], aggKey, aggSig, msg)
