@@ -497,7 +497,9 @@ def main():
                                      "note": "bgls_verify_aggregate with host buffers (pageable memory), never the headline value"}
             pmc = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
             if os.path.exists(pmc) and args.curve == "altbn128" and n == 1 << 16:
-                out["roofline"]["traffic"] = json.load(open(pmc))
+                det = json.load(open(pmc))          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the evidence run (profiles/r1)
+                out["roofline"]["traffic"] = det.get("bytes_per_launch_fetch_x2")     # bytes per launch, gfx950 FETCH_SIZE correction applied
+                out["roofline"]["traffic_detail"] = det
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cid, keys, msgs, sigs, n, fp, lib)
         print(json.dumps(out), flush=True)
