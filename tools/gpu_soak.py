@@ -1,0 +1,58 @@
+"""Development soak test (GPU): random batch sizes / message lengths / corruptions on both curves; every verdict is
+checked against the expectation (valid -> 1, any single corruption -> 0) and, for small n, against the C oracle.
+  python tools/gpu_soak.py [seconds]"""
+import ctypes, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bgls_amd import _lib
+from oracle import coracle
+L = _lib.load(); assert L.bgls_init(0) == 0
+B = lambda b: (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rnd = random.Random(int(time.time()))
+t0 = time.time(); runs = 0; oracle_checks = 0
+
+
+def offsets(msgs):
+    off = (ctypes.c_uint64 * (len(msgs) + 1))(); acc = 0
+    for i, m in enumerate(msgs):
+        off[i] = acc; acc += len(m)
+    off[len(msgs)] = acc
+    return off
+
+
+while time.time() - t0 < budget:
+    cid = rnd.randrange(2); fp = 32 if cid == 0 else 48
+    n = rnd.choice([1, 2, 3, 5, 6, 7, 59, 60, 61, 63, 64, 65, 127, 128, 129, 255, 256, 257, rnd.randrange(1, 700), rnd.randrange(1, 4000)])
+    mlen = rnd.choice([8, 9, 31, 32, 33, 64, 100, 200])
+    msgs = [rnd.randbytes(mlen) for _ in range(n)]
+    if len(set(msgs)) != n:
+        continue
+    sks = [rnd.randrange(1, 1 << 250) for _ in range(n)]
+    kb = b"".join(s.to_bytes(32, "big") for s in sks)
+    keys = (ctypes.c_uint8 * (n * 4 * fp))(); assert L.bgls_scale_generator(cid, 2, B(kb), n, keys) == 0
+    sigs = (ctypes.c_uint8 * (n * 2 * fp))(); assert L.bgls_sign_batch(cid, B(kb), B(b"".join(msgs)), offsets(msgs), n, sigs) == 0
+    agg = (ctypes.c_uint8 * (2 * fp))(); assert L.bgls_aggregate_points(cid, 1, sigs, n, agg) == 0
+    blob = b"".join(msgs); off = offsets(msgs)
+    ok = L.bgls_verify_aggregate(cid, agg, keys, B(blob), off, n, 0)
+    assert ok == 1, ("valid rejected", cid, n, mlen)
+    kind = rnd.randrange(4)
+    if kind == 0:
+        bad = bytearray(blob); bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        r = L.bgls_verify_aggregate(cid, agg, keys, B(bytes(bad)), off, n, 1)
+    elif kind == 1 and n > 1:
+        i, k = rnd.sample(range(n), 2); kk = bytearray(bytes(keys)); s = 4 * fp
+        kk[i * s:(i + 1) * s], kk[k * s:(k + 1) * s] = bytes(keys)[k * s:(k + 1) * s], bytes(keys)[i * s:(i + 1) * s]
+        r = L.bgls_verify_aggregate(cid, agg, B(bytes(kk)), B(blob), off, n, 0)
+    elif kind == 2:
+        i = rnd.randrange(n)
+        r = L.bgls_verify_aggregate(cid, B(bytes(sigs)[i * 2 * fp:(i + 1) * 2 * fp]), keys, B(blob), off, n, 0) if n > 1 else 0
+    else:
+        dup = list(msgs); dup[-1] = dup[0]
+        r = L.bgls_verify_aggregate(cid, agg, keys, B(b"".join(dup)), offsets(dup), n, 0) if n > 1 else 0
+    assert r == 0, ("corruption accepted", cid, n, mlen, kind)
+    if n <= 40:
+        assert coracle.verify_aggregate(cid, bytes(agg), bytes(keys), msgs, threads=8) == 1
+        oracle_checks += 1
+    runs += 1
+print("soak ok: %d instances (%d also checked by the oracle) in %.0f s" % (runs, oracle_checks, time.time() - t0))
