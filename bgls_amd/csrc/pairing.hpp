@@ -40,6 +40,20 @@ template <class C, bool INL>
 BGLS_HD Fp2<C> f2s(const Fp2<C>& a) {
   if constexpr (INL) return f2_sqr_inl<C>(a); else return f2_sqr<C>(a);
 }
+// 3 b' Z^2 of the doubling step.  BLS12-381: b' = 4 xi with xi = 1 + i, so 3 b' = 12 (1 + i) and the product is two
+// additions for xi and a short doubling chain for 12 = 8 + 4 -- no multiplication.  alt-bn128: b' = 3 / (9 + i) has no
+// such structure and stays a full Fp2 multiplication by the constant.
+template <class C, bool INL>
+BGLS_HD Fp2<C> f2_mul_3b(const Fp2<C>& z2) {
+  if constexpr (!C::TWIST_D && C::XI_RE == 1) {
+    const Fp2<C> t4 = f2_dbl<C>(f2_dbl<C>(f2_mulxi<C>(z2)));
+    return f2_add<C>(f2_dbl<C>(t4), t4);
+  } else {
+    const Fp2<C> b3 = {fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)};
+    if constexpr (INL) return f2_mul_inl<C>(b3, z2); else return f2_mul<C>(b3, z2);
+  }
+}
+
 template <class C>
 BGLS_HD Fp2<C> f2_half(const Fp2<C>& a) { return {fp_half<C>(a.c0), fp_half<C>(a.c1)}; }   // a / 2: shifts, no multiplication
 template <class C, bool INL>
@@ -59,8 +73,7 @@ BGLS_HD LineCoeffs<C> dbl_step_t(G2Proj<C>& R) {
   Fp2<C> A = f2_half<C>(f2m<C, INL>(R.X, R.Y));
   Fp2<C> B = f2s<C, INL>(R.Y);
   Fp2<C> Cc = f2s<C, INL>(R.Z);
-  Fp2<C> b3 = {fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)};
-  Fp2<C> E = f2m<C, INL>(b3, Cc);
+  Fp2<C> E = f2_mul_3b<C, INL>(Cc);
   Fp2<C> Fv = f2_mul3<C>(E);
   Fp2<C> G = f2_half<C>(f2_add<C>(B, Fv));
   Fp2<C> H = f2_sub<C>(f2s<C, INL>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
@@ -98,7 +111,7 @@ BGLS_HD void dbl_step_emit(G2Proj<C>& R, Emit&& emit) {
   Fp2<C> B = f2_sqr_inl<C>(R.Y);
   Fp2<C> Cc = f2_sqr_inl<C>(R.Z);
   Fp2<C> H = f2_sub<C>(f2_sqr_inl<C>(f2_add<C>(R.Y, R.Z)), f2_add<C>(B, Cc));
-  Fp2<C> E = f2_mul_inl<C>(Fp2<C>{fp_load<C>(C::B2X3_RE), fp_load<C>(C::B2X3_IM)}, Cc);
+  Fp2<C> E = f2_mul_3b<C, true>(Cc);
   emit(2, f2_sub<C>(E, B));
   emit(0, f2_neg<C>(H));
   emit(1, f2_mul3<C>(f2_sqr_inl<C>(R.X)));
