@@ -259,7 +259,10 @@ __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<
 
 // Emitter for dbl_step_emit / add_step_emit: scales LineCoeffs slot `which` by yP / xP and stores it as the
 // matching entry of RL[j] (D-type: c0 yP, c1 xP, c2;  M-type: c2, c1 xP, c0 yP).
-template <class C>
+template <class C, bool R28>
+__device__ __forceinline__ void st_entry(LReg r, int e, const Fp2<C>& x);   // coop_r28.hpp: plain store or converted to 28-bit limbs
+
+template <class C, bool R28 = false>
 struct LineEmitter {
   LReg r;
   int j;
@@ -280,7 +283,7 @@ struct LineEmitter {
       entry = C::TWIST_D ? 2 : 0;
     }
     if (!valid) e = (entry == 0) ? f2_one<C>() : f2_zero<C>();
-    if (live) lds_st<C>(r, 3 * j + entry, e);
+    if (live) st_entry<C, R28>(r, 3 * j + entry, e);
   }
 };
 
@@ -311,7 +314,7 @@ __device__ __forceinline__ Fp2<C> f2_shfl_xor1(const Fp2<C>& a) {
 }
 // lanes (2m, 2m+1) hold lines A (even lane) and B (odd lane); writes the five coefficients of A*B into entries
 // 5m .. 5m+4 of region rl.  Uniform instruction stream: operand selects by lane parity.
-template <class C>
+template <class C, bool R28 = false>
 __device__ __forceinline__ void coop_write_line_pair(LReg rl, int j, const Fp2<C> (&own)[3]) {
   // a = even lane's line, b = odd lane's line (index 2 = the w^3 coefficient)
   //   even lane: P00 = a0 b0, P11 = a1 b1, K01 = (a0+a1)(b0+b1);   odd lane: P22 = a2 b2, K02 = (a0+a2)(b0+b2), K12 = (a1+a2)(b1+b2)
@@ -328,12 +331,12 @@ __device__ __forceinline__ void coop_write_line_pair(LReg rl, int j, const Fp2<C
   Fp2<C> q1 = f2_shfl_xor1<C>(p1), q2 = f2_shfl_xor1<C>(p2);
   const int m = j >> 1;
   if (!odd) {       // c0 = P00 + xi P22, c1 = K01 - P00 - P11, c2 = P11
-    lds_st<C>(rl, 5 * m + 0, f2_add<C>(p1, f2_mulxi<C>(q1)));
-    lds_st<C>(rl, 5 * m + 1, f2_sub<C>(f2_sub<C>(p3, p1), p2));
-    lds_st<C>(rl, 5 * m + 2, p2);
+    st_entry<C, R28>(rl, 5 * m + 0, f2_add<C>(p1, f2_mulxi<C>(q1)));
+    st_entry<C, R28>(rl, 5 * m + 1, f2_sub<C>(f2_sub<C>(p3, p1), p2));
+    st_entry<C, R28>(rl, 5 * m + 2, p2);
   } else {          // c3 = K02 - P00 - P22, c4 = K12 - P11 - P22   (q1 = P00, q2 = P11 from the even lane)
-    lds_st<C>(rl, 5 * m + 3, f2_sub<C>(f2_sub<C>(p2, q1), p1));
-    lds_st<C>(rl, 5 * m + 4, f2_sub<C>(f2_sub<C>(p3, q2), p1));
+    st_entry<C, R28>(rl, 5 * m + 3, f2_sub<C>(f2_sub<C>(p2, q1), p1));
+    st_entry<C, R28>(rl, 5 * m + 4, f2_sub<C>(f2_sub<C>(p3, q2), p1));
   }
 }
 

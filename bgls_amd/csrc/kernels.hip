@@ -21,6 +21,7 @@
 #include "h2c.hpp"
 #include "wire.hpp"
 #include "coop.hpp"
+#include "coop_r28.hpp"
 #include "finalexp.hpp"
 #include "../../include/bgls_hip.h"
 
@@ -855,9 +856,9 @@ __global__ void k_gen_lines(LineCoeffs<C>* table, int* nsteps) {
 // slot l/10 of group l%10, so groups 0..3 fold seven lines and the others six plus a constant 1), the
 // (-sigma, g2) pair needs no point steps (k_gen_lines table, scaled by lane 0 of block 0), and nothing
 // spills: the point-step temporaries fit the 256-register budget.
-template <class C>
+template <class C, bool R28 = false>
 struct Coop64 {
-  static constexpr int S2 = 2 * C::L;
+  static constexpr int S2 = R28 ? R28_S2 : 2 * C::L;        // R28: ten 28-bit limbs per field element (coop_r28.hpp), 38.4 KB per block
   static constexpr int NENT = 18;            // per group and buffer: 3 line pairs x 5 coefficients + 1 single line x 3
   // BLS12-381: xi = 1+i costs two additions, so the accumulator region keeps the plain coefficients only and
   // the wrap-around factor is applied after the load; that is what lets four blocks share a CU's 160 KB.
@@ -874,10 +875,11 @@ struct Coop64 {
 // the constant 1 there.  The consumer folds 3 five-term elements + 1 three-term line per step.
 // DBG (development only, BGLS_AB64_DBG): 1 = producer work only, 2 = consumer work only -- wrong results, used to
 // time the two halves of the pipeline separately.
-template <class C, int DBG = 0>
+// R28 (alt-bn128): the consumer works on 28-bit limbs (coop_r28.hpp); the producer converts what it stores.
+template <class C, int DBG = 0, bool R28 = false>
 __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
                                                         const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, unsigned swap_mask) {
-  typedef Coop64<C> K;
+  typedef Coop64<C, R28> K;
   // The two waves of a block land on different SIMDs and every CU hosts four blocks: if wave 0 were the producer
   // everywhere, two SIMDs of a CU would carry two producers and the other two would carry two consumers, and the kernel
   // would run at the pace of the heavier role.  Blocks selected by swap_mask exchange the roles, so each SIMD carries
@@ -918,9 +920,9 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     if (lane >= 4 && lane < 10) {
       for (int b = 0; b < 2; ++b) {
         const LReg r = {lane * K::GROUP_DW + (b ? K::RL2 : K::RL), K::NENT};
-        lds_st<C>(r, 15, f2_one<C>());
-        lds_st<C>(r, 16, f2_zero<C>());
-        lds_st<C>(r, 17, f2_zero<C>());
+        st_entry<C, R28>(r, 15, f2_one<C>());
+        st_entry<C, R28>(r, 16, f2_zero<C>());
+        st_entry<C, R28>(r, 17, f2_zero<C>());
       }
     }
     G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
@@ -930,15 +932,15 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       if (!valid) { cap.e[0] = f2_one<C>(); cap.e[1] = f2_zero<C>(); cap.e[2] = f2_zero<C>(); }
       const LReg r = {tgb + (buf ? K::RL2 : K::RL), K::NENT};
       if (paired) {
-        coop_write_line_pair<C>(r, j, cap.e);
+        coop_write_line_pair<C, R28>(r, j, cap.e);
       } else {
-        lds_st<C>(r, 15, cap.e[0]);
-        lds_st<C>(r, 16, cap.e[1]);
-        lds_st<C>(r, 17, cap.e[2]);
+        st_entry<C, R28>(r, 15, cap.e[0]);
+        st_entry<C, R28>(r, 16, cap.e[1]);
+        st_entry<C, R28>(r, 17, cap.e[2]);
       }
       if (sig_lane && sig_valid) {
         const LineCoeffs<C> l = gen_lines[step];
-        LineEmitter<C> em{LReg{4 * K::GROUP_DW + (buf ? K::RL2 : K::RL), K::NENT}, 5, S.x, S.y, true, true};   // entries 15..17
+        LineEmitter<C, R28> em{LReg{4 * K::GROUP_DW + (buf ? K::RL2 : K::RL), K::NENT}, 5, S.x, S.y, true, true};   // entries 15..17
         em(0, l.c0);
         em(1, l.c1);
         em(2, l.c2);
@@ -984,6 +986,50 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     const int g = live ? lane / 6 : 9;
     const int j = live ? lane % 6 : lane - 60;
     const int gb = g * K::GROUP_DW;
+    if constexpr (R28) {
+      // ---- 28-bit-limb consumer: same schedule, every dot product a pile of carry-free column accumulations
+      static_assert(C::CURVE_ID == 0 && C::TWIST_D, "alt-bn128 only");
+      const int rbo = gb + K::RB;
+      F28x2 fj;
+      {
+        const F28 one = r28_load<C>(C::R28_ONE);
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
+      }
+      coop_publish28<C>(rbo, j, fj, live);
+      int buf = 0;
+      auto fold = [&]() {
+        if constexpr (DBG == 1) { buf ^= 1; return; }
+        const int rlo = gb + (buf ? K::RL2 : K::RL);
+#pragma unroll 1
+        for (int m = 0; m < 3; ++m) {
+          fj = coop_dot28<C, 5>(rlo, 5 * m, rbo, j, COOP_SH_D5);
+          coop_publish28<C>(rbo, j, fj, live);
+        }
+        fj = coop_dot28<C, 3>(rlo, 15, rbo, j, COOP_SH_D);
+        coop_publish28<C>(rbo, j, fj, live);
+        buf ^= 1;
+      };
+#pragma unroll 1
+      for (int i = 1; i < C::LOOP_LEN; ++i) {
+        if constexpr (DBG != 3) __syncthreads();
+        if constexpr (DBG != 1) {
+          fj = coop_sqr_sym28<C>(rbo, j);
+          coop_publish28<C>(rbo, j, fj, live);
+        }
+        fold();
+        if (C::LOOP_NAF[i] != 0) {
+          if constexpr (DBG != 3) __syncthreads();
+          fold();
+        }
+      }
+      if constexpr (DBG != 3) __syncthreads();
+      fold();
+      if constexpr (DBG != 3) __syncthreads();
+      fold();
+      if (live) out[((size_t)blockIdx.x * 10 + g) * 6 + j] = from_r28<C>(fj);
+      return;
+    }
     const LReg rb = {gb + K::RB, 12};
     Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
     coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
@@ -1375,6 +1421,12 @@ Ctx& ctx() {
   return c;
 }
 
+// BGLS_R28=1: alt-bn128 Miller kernel with the 28-bit-limb consumer (coop_r28.hpp)
+bool r28_mode() {
+  static const bool v = [] { const char* e = getenv("BGLS_R28"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // role-swap mask of k_miller_ab64 (see the kernel); BGLS_AB64_SWAP overrides it for A/B runs
 unsigned ab64_swap() {
   static const unsigned v = [] {
@@ -1635,12 +1687,18 @@ struct Engine {
             const long long sig_at = (blk0 == 0 && gen_at >= 0) ? gen_at : -1LL;   // block 0 of the first launch scales the generator lines
             Fp2<C>* outc = (Fp2<C>*)pa + blk0 * 10 * 6;
             const LineCoeffs<C>* gl = (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID];
-            if (dbgm == 1)
+            if (dbgm == 1 && !r28_mode())
               k_miller_ab64<BN254, 1><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
-            else if (dbgm == 2)
+            else if (dbgm == 2 && !r28_mode())
               k_miller_ab64<BN254, 2><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
             else if (dbgm == 3)
               k_miller_ab64<BN254, 3><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
+            else if (C::CURVE_ID == 0 && r28_mode() && dbgm == 1)
+              k_miller_ab64<BN254, 1, true><<<(unsigned)nblocks, 128, Coop64<BN254, true>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
+            else if (C::CURVE_ID == 0 && r28_mode() && dbgm == 2)
+              k_miller_ab64<BN254, 2, true><<<(unsigned)nblocks, 128, Coop64<BN254, true>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
+            else if (C::CURVE_ID == 0 && r28_mode())
+              k_miller_ab64<BN254, 0, true><<<(unsigned)nblocks, 128, Coop64<BN254, true>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
             else
               k_miller_ab64<C><<<(unsigned)nblocks, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1c, g2c, np, sig_at, gl, outc, d_flags, ab64_swap());
           }

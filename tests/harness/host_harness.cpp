@@ -4,6 +4,7 @@
 #include "../../bgls_amd/csrc/pairing.hpp"
 #include "../../bgls_amd/csrc/h2c.hpp"
 #include "../../bgls_amd/csrc/wire.hpp"
+#include "../../bgls_amd/csrc/r28.hpp"
 
 using namespace bgls;
 
@@ -199,5 +200,41 @@ int ht_blake2xb_node(const uint8_t* root, uint32_t i, uint32_t xof_len, uint32_t
   blake2xb_node(r, i, xof_len, take, o);
   for (uint32_t b = 0; b < take; ++b) out[b] = (uint8_t)(o[b >> 3] >> (8 * (b & 7)));
   return 0;
+}
+// r28.hpp (28-bit-limb consumer arithmetic, alt-bn128): inputs / outputs are Fp2 as 64-byte big-endian (re || im).
+// op 0: from_r28(to_r28(a))   op 1: from_r28(r28_f2_mul(to_r28(a), to_r28(b)))   op 2: xi * a (through a product by one)
+// op 3: a five-term dot product sum_t a_t * b_t with a_t = a^(t+1)-ish derived values, both ways; returns 1 when equal
+int ht_r28(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  typedef BN254 C;
+  auto ld = [](const uint8_t* p) { return Fp2<C>{fp_to_mont<C>(fp_from_be<C>(p)), fp_to_mont<C>(fp_from_be<C>(p + 32))}; };
+  auto st = [](uint8_t* p, const Fp2<C>& v) { fp_to_be<C>(p, fp_from_mont<C>(v.c0)); fp_to_be<C>(p + 32, fp_from_mont<C>(v.c1)); };
+  Fp2<C> x = ld(a), y = ld(b);
+  if (op == 0) { st(out, from_r28<C>(to_r28<C>(x))); return 0; }
+  if (op == 1) { st(out, from_r28<C>(r28_f2_mul<C>(to_r28<C>(x), to_r28<C>(y)))); return 0; }
+  if (op == 2) {   // the xi multiple is a lazy value (up to ~73 p): bring it down with a product by one before converting back
+    F28x2 one = {r28_load<C>(C::R28_ONE), F28{}};
+    for (int i = 0; i < 10; ++i) one.c1.v[i] = 0;
+    st(out, from_r28<C>(r28_f2_mul<C>(r28_mulxi<C>(to_r28<C>(x)), one)));
+    return 0;
+  }
+  if (op == 3) {
+    Fp2<C> as[5], bs[5];
+    as[0] = x; bs[0] = y;
+    for (int t = 1; t < 5; ++t) { as[t] = f2_add<C>(f2_sqr<C>(as[t - 1]), y); bs[t] = f2_mulxi<C>(f2_add<C>(bs[t - 1], x)); }
+    Fp2<C> want = f2_zero<C>();
+    for (int t = 0; t < 5; ++t) want = f2_add<C>(want, f2_mul<C>(as[t], bs[t]));
+    u64 cr[20], ci[20];
+    for (int k = 0; k < 20; ++k) cr[k] = ci[k] = 0;
+    for (int t = 0; t < 5; ++t) {
+      F28x2 ea = to_r28<C>(as[t]), eb = to_r28<C>(bs[t]);
+      r28_acc(cr, ea.c0, eb.c0); r28_acc(cr, ea.c1, r28_fatneg<C>(eb.c1));
+      r28_acc(ci, ea.c0, eb.c1); r28_acc(ci, ea.c1, eb.c0);
+    }
+    F28x2 got = {r28_redc<C>(cr), r28_redc<C>(ci)};
+    st(out, from_r28<C>(got));
+    uint8_t w[64]; st(w, want);
+    return memcmp(w, out, 64) == 0 ? 1 : 0;
+  }
+  return -1;
 }
 }

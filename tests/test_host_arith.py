@@ -175,3 +175,24 @@ def test_wire_formats_and_blake2x_node(host_harness):
             host_harness.ht_blake2xb_node(B(root), i, ol, take, o)
             got += bytes(o)[:take]
         assert got == want
+
+
+def test_r28_consumer_arithmetic(host_harness):
+    """r28.hpp (28-bit limbs, Montgomery radix 2^280) against the library's 32-bit arithmetic on the host: conversion
+    round trip (shift + one Barrett step), Fp2 product, xi multiple, and a five-term dot product with one reduction."""
+    import ctypes, random
+    p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    rnd = random.Random(28)
+    B = lambda b: (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b))
+    enc = lambda re, im: re.to_bytes(32, "big") + im.to_bytes(32, "big")
+    dec = lambda b: (int.from_bytes(b[:32], "big"), int.from_bytes(b[32:], "big"))
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << 253, (1 << 222) - 1, 1 << 222]
+    vals = [(rnd.choice(edge), rnd.choice(edge)) for _ in range(30)] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(200)]
+    for (a0, a1), (b0, b1) in zip(vals, vals[::-1]):
+        o = (ctypes.c_uint8 * 64)()
+        assert host_harness.ht_r28(0, B(enc(a0, a1)), B(enc(b0, b1)), o) == 0 and dec(bytes(o)) == (a0, a1)
+        assert host_harness.ht_r28(1, B(enc(a0, a1)), B(enc(b0, b1)), o) == 0
+        assert dec(bytes(o)) == ((a0 * b0 - a1 * b1) % p, (a0 * b1 + a1 * b0) % p)
+        assert host_harness.ht_r28(2, B(enc(a0, a1)), B(enc(b0, b1)), o) == 0
+        assert dec(bytes(o)) == ((9 * a0 - a1) % p, (9 * a1 + a0) % p)
+        assert host_harness.ht_r28(3, B(enc(a0, a1)), B(enc(b0, b1)), o) == 1

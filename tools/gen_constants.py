@@ -95,6 +95,29 @@ def main():
     r_bls = x**4 - x**2 + 1
     assert p_bls == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
+    def r28_consts(p, L):
+        """Constants of the 28-bit-limb consumer representation (r28.hpp): R' = 2^280, 10 limbs."""
+        W, N = 28, 10
+        Mk = (1 << W) - 1
+        lim = lambda x: [(x >> (W * i)) & Mk for i in range(N)]
+        R = 1 << (32 * L)
+        Rp = 1 << (W * N)
+        o = ""
+        o += arr("R28_P", lim(p))
+        o += "  static constexpr uint32_t R28_NP = 0x%xu;\n" % ((-pow(p, -1, 1 << W)) % (1 << W))
+        # "fat" multiple of p for limb-wise negation of a tight operand: limbs 0..8 in [2^28, 2^29), top limb = what is left
+        k = 64
+        base = sum((1 << 28) << (W * i) for i in range(N - 1))
+        d = k * p - base
+        assert d >= 0
+        fat = [(1 << 28) + ((d >> (W * i)) & Mk) for i in range(N - 1)] + [d >> (W * (N - 1))]
+        assert sum(v << (W * i) for i, v in enumerate(fat)) == k * p and all(v < (1 << 29) for v in fat[:-1])
+        o += arr("R28_FAT", fat)
+        o += arr("R28_ONE", lim(Rp % p))                              # 1 in R' form
+        o += "  static constexpr uint32_t R28_MU = 0x%xu;\n" % ((1 << 278) // p)   # Barrett: q = (top32(y) * MU) >> 32 ~ y 2^24 / p
+        o += arr("R28_BACK", limbs((R * R // Rp) % p * 1 % p if (R * R) % Rp == 0 else (R * R * pow(Rp, -1, p)) % p, L))   # 32-bit Montgomery multiplier: x R' -> x R
+        return o
+
     def bn_extra(M, limbs, L):
         g2 = [10857046999023057135944570762232829481370756359578518086990519993285655852781,
               11559732032986387107991004021392285783925812861821192530917403151452391805634,
@@ -157,7 +180,7 @@ def main():
         return o
 
     txt = "// GENERATED by tools/gen_constants.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\nnamespace bgls {\n\n"
-    txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, bn_extra)
+    txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, lambda M, limbs, L: bn_extra(M, limbs, L) + r28_consts(p_bn, L))
     txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, bls_extra)
     txt += "}  // namespace bgls\n"
     with open(OUT, "w") as f:

@@ -213,6 +213,94 @@ __global__ void __launch_bounds__(64) mb_b(F28x2* io, int iters, size_t n) {
   io[t] = s;
 }
 
+// ---- D: the consumer's unit of work -- a five-term Fp2 dot product with ONE reduction per output half ----
+// A-form: per term three double-width products (Karatsuba over i) added into three double-width accumulators, then
+// real = sum v0 - sum v1 + 6 p^2, imag = sum s - sum v0 - sum v1, two Montgomery reductions (as coop_dot_inl).
+__device__ __forceinline__ Fp2<BN254> dot5_a(const Fp2<BN254> (&a)[5], const Fp2<BN254> (&b)[5]) {
+  typedef BN254 C;
+  constexpr int W = 2 * C::L;
+  u32 v0[W], v1[W], s[W], tmp[W];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    Fp<C> sa = fp_add_nr<C>(a[t].c0, a[t].c1), sb = fp_add_nr<C>(b[t].c0, b[t].c1);
+    if (t == 0) {
+      mul_wide<C>(v0, a[t].c0.v, b[t].c0.v);
+      mul_wide<C>(v1, a[t].c1.v, b[t].c1.v);
+      mul_wide<C>(s, sa.v, sb.v);
+    } else {
+      mul_wide<C>(tmp, a[t].c0.v, b[t].c0.v); w_add<W>(v0, v0, tmp);
+      mul_wide<C>(tmp, a[t].c1.v, b[t].c1.v); w_add<W>(v1, v1, tmp);
+      mul_wide<C>(tmp, sa.v, sb.v); w_add<W>(s, s, tmp);
+    }
+  }
+  w_sub<W>(s, s, v0);
+  w_sub<W>(s, s, v1);
+  w_add<W>(v0, v0, C::P2W6);
+  w_sub<W>(v0, v0, v1);
+  Fp2<C> r;
+  r.c0 = redc_k<C, 3>(v0);
+  r.c1 = redc_k<C, 3>(s);
+  return r;
+}
+// B-form: all twenty limb-level products of the five terms go straight into one set of 64-bit column accumulators per
+// output half (schoolbook over i, the subtraction as a "fat" negation): no carries, no wide additions, no fix-ups.
+__device__ __forceinline__ F28x2 dot5_b(const F28x2 (&a)[5], const F28x2 (&b)[5]) {
+  F28x2 r;
+  {
+    uint64_t c[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) c[k] = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      F28 nb1;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) nb1.v[i] = FAT28[i] - b[t].c1.v[i];
+      acc_prod(c, a[t].c0, b[t].c0);
+      acc_prod(c, a[t].c1, nb1);
+    }
+    r.c0 = redc28(c);
+  }
+  {
+    uint64_t c[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) c[k] = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      acc_prod(c, a[t].c0, b[t].c1);
+      acc_prod(c, a[t].c1, b[t].c0);
+    }
+    r.c1 = redc28(c);
+  }
+  return r;
+}
+__global__ void __launch_bounds__(64) mb_dot_a(Fp2<BN254>* io, int iters, size_t n) {
+  const size_t t = blockIdx.x * 64 + threadIdx.x;
+  Fp2<BN254> a[5], b[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { a[k] = io[(t + 3 * k) % n]; b[k] = io[n + (t + 5 * k) % n]; }
+  for (int i = 0; i < iters; ++i) {
+    Fp2<BN254> r = dot5_a(a, b);
+    a[i % 5] = r;                       // keep a dependency so nothing is hoisted
+  }
+  io[t] = f2_add<BN254>(a[0], f2_add<BN254>(a[1], f2_add<BN254>(a[2], f2_add<BN254>(a[3], a[4]))));
+}
+__global__ void __launch_bounds__(64) mb_dot_b(F28x2* io, int iters, size_t n) {
+  const size_t t = blockIdx.x * 64 + threadIdx.x;
+  F28x2 a[5], b[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { a[k] = io[(t + 3 * k) % n]; b[k] = io[n + (t + 5 * k) % n]; }
+  for (int i = 0; i < iters; ++i) {
+    F28x2 r = dot5_b(a, b);
+    a[i % 5] = r;
+  }
+  F28x2 s = a[0];
+#pragma unroll
+  for (int c = 1; c < 5; ++c)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { s.c0.v[k] += a[c].c0.v[k]; s.c1.v[k] += a[c].c1.v[k]; }
+  io[t] = s;
+}
+
 template <class F> float run(F launch, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   launch(); hipDeviceSynchronize();
@@ -280,6 +368,18 @@ int main() {
              (double)blocks * 64 * iters / t1 / 1e6, t2, (double)blocks * 64 * iters * 2 / t2 / 1e6);
     }
     hipFree(d);
+  }
+  {
+    const int iters = 100;            // multiple of 5: the a[i % 5] rotation is resolved at compile time after unrolling by 5
+    Fp2<BN254>* da; hipMalloc(&da, 2 * n * sizeof(Fp2<BN254>)); hipMemset(da, 1, 2 * n * sizeof(Fp2<BN254>));
+    F28x2* db; hipMalloc(&db, 2 * n * sizeof(F28x2)); hipMemset(db, 1, 2 * n * sizeof(F28x2));
+    for (int blocks : {2048, 8192, 16384}) {
+      float ta = run([&] { mb_dot_a<<<blocks, 64>>>(da, iters, n); }, 3);
+      float tb = run([&] { mb_dot_b<<<blocks, 64>>>(db, iters, n); }, 3);
+      printf("D five-term dot  blocks=%5d  A (32-bit limbs, lazy): %8.3f ms = %6.2f G dot/s | B (28-bit limbs, columns): %8.3f ms = %6.2f G dot/s  (B/A = %.2f)\n",
+             blocks, ta, (double)blocks * 64 * iters / ta / 1e6, tb, (double)blocks * 64 * iters / tb / 1e6, ta / tb);
+    }
+    hipFree(da); hipFree(db);
   }
   return 0;
 }
