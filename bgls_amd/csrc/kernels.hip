@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <vector>
+#include <atomic>
 #include <string>
 
 #include "pairing.hpp"
@@ -1071,6 +1072,114 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
   }
 }
 
+// ---- throughput shape of the alt-bn128 Miller kernel: 60 pairings per block, single lines, 28-bit-limb consumer ------
+// With the consumer on 28-bit limbs (coop_r28.hpp) the producer wave is the slower half of k_miller_ab64, and a fifth of
+// its step is the product of neighbouring lines.  Here the producer only steps its points and stores its own line
+// (converted to 28-bit limbs); the consumer, which has the slack, folds the six three-term lines of its group itself --
+// the same number of products as three five-term elements plus a single line, two more reductions.  Six lines per group
+// and buffer is exactly the LDS footprint of k_miller_ab64 (38.4 KB), so four blocks still share a CU; lanes 60..63 of the
+// producer idle and the signature pair moves to the epilogue kernel (as on BLS12-381).  A 2^16 batch is 1093 blocks: one
+// more than fit at once, which is irrelevant while launches overlap and a second, nearly empty round when they do not --
+// hence only in throughput mode (bgls_set_throughput_mode).
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags) {
+  static_assert(C::CURVE_ID == 0 && C::TWIST_D, "alt-bn128 only");
+  typedef Coop64<C, true> K;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave == 0) {
+    // ---------------- producer: 60 pairings, one per lane; lane 6g + j feeds line j of group g
+    const bool owner = lane < 60;
+    const size_t idx = (size_t)blockIdx.x * 60 + lane;
+    const int tg = owner ? lane / 6 : 0;
+    const int j = owner ? lane % 6 : 0;
+    const int tgb = tg * K::GROUP_DW;
+    Aff<F2<C>> Q;
+    Aff<F1<C>> P;
+    bool valid = owner && idx < n;
+    if (valid) {
+      bool ok = g2_from_bytes<C>(Q, g2s + idx * 4 * C::FP_BYTES);
+      ok = ok && aff_on_curve<F2<C>>(Q);
+      if (!ok) atomicOr(flags, FLAG_ENC);
+      P = g1s[idx];
+      valid = !P.inf && !Q.inf;
+    }
+    if (!valid) {
+      Q.x = f2_load<C>(C::G2);
+      Q.y = f2_load<C>(C::G2 + 2 * C::L);
+      P.x = fp_load<C>(C::G1X);
+      P.y = fp_load<C>(C::G1Y);
+    }
+    G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+    int buf = 0;
+    auto done = [&]() {
+      wave_sync();
+      __syncthreads();
+      buf ^= 1;
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      done();
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+        done();
+      }
+    }
+    {
+      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+      add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      done();
+      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+      add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      done();
+    }
+  } else {
+    // ---------------- consumer: 10 groups x 6 lanes, six three-term lines per step
+    const bool live = lane < 60;
+    const int g = live ? lane / 6 : 9;
+    const int j = live ? lane % 6 : lane - 60;
+    const int gb = g * K::GROUP_DW;
+    const int rbo = gb + K::RB;
+    F28x2 fj;
+    {
+      const F28 one = r28_load<C>(C::R28_ONE);
+#pragma unroll
+      for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
+    }
+    coop_publish28<C>(rbo, j, fj, live);
+    int buf = 0;
+    auto fold = [&]() {
+      const int rlo = gb + (buf ? K::RL2 : K::RL);
+#pragma unroll 1
+      for (int m = 0; m < 6; ++m) {
+        fj = coop_dot28<C, 3>(rlo, 3 * m, rbo, j, COOP_SH_D);
+        coop_publish28<C>(rbo, j, fj, live);
+      }
+      buf ^= 1;
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      __syncthreads();
+      fj = coop_sqr_sym28<C>(rbo, j);
+      coop_publish28<C>(rbo, j, fj, live);
+      fold();
+      if (C::LOOP_NAF[i] != 0) {
+        __syncthreads();
+        fold();
+      }
+    }
+    __syncthreads();
+    fold();
+    __syncthreads();
+    fold();
+    if (live) out[((size_t)blockIdx.x * 10 + g) * 6 + j] = from_r28<C>(fj);
+  }
+}
+
 // out[G] = prod in[G*R .. min(count, (G+1)*R))   (w-basis Fp12 arrays)
 template <class C>
 __global__ void __launch_bounds__(64) k_reduce_coop(const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
@@ -1270,9 +1379,11 @@ __global__ void __launch_bounds__(128) k_cofactor_epilogue(const Fp2<C>* rest, c
       fe_put<C>(S_ACC, lane, v);
     }
     wave_sync();
-    for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
-      fe_mul<C>(S_ACC, S_ACC, S_ACC);
-      if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) fe_mul<C>(S_ACC, S_ACC, S_BASE);
+    if constexpr (C::CURVE_ID == 1) {                       // alt-bn128 has cofactor 1: the epilogue only folds the signature pair in
+      for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
+        fe_mul<C>(S_ACC, S_ACC, S_ACC);
+        if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) fe_mul<C>(S_ACC, S_ACC, S_BASE);
+      }
     }
   } else {
     if (lane < 6) {
@@ -1419,6 +1530,19 @@ Ctx& ctx() {
   Ctx& c = all[g_sel];
   if (g_sel != 0 && !c.ready) c.device = all[0].device;
   return c;
+}
+
+// Throughput mode (bgls_set_throughput_mode / BGLS_THROUGHPUT=1): alt-bn128 batches use k_miller_s60, whose launches are
+// meant to overlap with their neighbours (several verifications in flight).
+std::atomic<int> g_throughput{-1};
+bool throughput_mode() {
+  int v = g_throughput.load();
+  if (v < 0) {
+    const char* e = getenv("BGLS_THROUGHPUT");
+    v = (e && e[0] == '1') ? 1 : 0;
+    g_throughput.store(v);
+  }
+  return v == 1;
 }
 
 // BGLS_R28=1: alt-bn128 Miller kernel with the 28-bit-limb consumer (coop_r28.hpp)
@@ -1644,13 +1768,9 @@ struct Engine {
     if (!cofactor) {
       k_w_to_bytes<C><<<1, 64, 0, st>>>(w, d_partial);
     } else {
-      if constexpr (C::CURVE_ID == 1) {
-        int rc;
-        if ((rc = ensure_gen_lines(c, st))) return rc;
-        k_cofactor_epilogue<C><<<1, 128, FE<C>::LDS_BYTES2, st>>>(w, sig, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID], d_partial);
-      } else {
-        return fail(BGLS_ERR_ARG, "cofactor epilogue on a cofactor-1 curve");
-      }
+      int rc;
+      if ((rc = ensure_gen_lines(c, st))) return rc;
+      k_cofactor_epilogue<C><<<1, 128, FE<C>::LDS_BYTES2, st>>>(w, sig, (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID], d_partial);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1666,6 +1786,37 @@ struct Engine {
       // Larger batches run as consecutive launches of 1024 blocks (2^16 pairings each): measured per 2^16 pairings,
       // alt-bn128 6.2 ms either way, BLS12-381 11.0 ms against 15.3 ms for the single-wave kernel (one wave per SIMD there).
       // BGLS_AB64_MAX_BLOCKS=1024 restores the earlier rule (single-wave kernel above 2^16) for A/B runs.
+      if constexpr (C::CURVE_ID == 0) {
+        if (throughput_mode() && miller_mode() == 0 && npairs >= 1 && (gen_at < 0 || gen_at == (long long)npairs)) {
+          int rc;
+          void *pa, *pb;
+          const size_t nb60 = (npairs + 59) / 60;
+          const size_t groups60 = nb60 * 10;
+          if ((rc = c.get(WS_F_A, (groups60 + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+          if ((rc = c.get(WS_F_B, (groups60 / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+          {
+            Scope sc(c, st, ST_MILLER);
+            for (size_t blk0 = 0; blk0 < nb60; blk0 += 8192) {            // grid size stays comfortably inside 32 bits
+              const size_t nblocks = nb60 - blk0 < 8192 ? nb60 - blk0 : 8192;
+              const size_t p0 = blk0 * 60;
+              k_miller_s60<C><<<(unsigned)nblocks, 128, Coop64<C, true>::BLOCK_BYTES, st>>>(g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags);
+            }
+          }
+          Scope sc(c, st, ST_REDUCE);
+          Fp2<C>*a = (Fp2<C>*)pa, *b = (Fp2<C>*)pb;
+          size_t cnt = groups60;
+          while (cnt > 1) {
+            size_t nout = (cnt + 3) / 4;
+            k_reduce_coop<C><<<nblk(nout, K::GROUPS), 64, K::WAVE_BYTES, st>>>(a, cnt, 4, b);
+            Fp2<C>* t = a;
+            a = b;
+            b = t;
+            cnt = nout;
+          }
+          // the (-sigma, g2) pair is folded in by the epilogue kernel (generator lines, 36-lane arithmetic)
+          return emit_partial(c, st, a, gen_at >= 0, gen_at >= 0 ? g1s + gen_at : nullptr, d_partial);
+        }
+      }
       static const size_t max_blocks = [] { const char* e = getenv("BGLS_AB64_MAX_BLOCKS"); return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)1 << 40; }();
       if (miller_mode() == 0 && !getenv("BGLS_NO_AB64") && nb64 >= 1 && nb64 <= max_blocks && (gen_at < 0 || gen_at == (long long)npairs)) {
         int rc;
@@ -2721,6 +2872,11 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
   if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
                                            d_flags, stream));
+}
+
+int bgls_set_throughput_mode(int on) {
+  g_throughput.store(on ? 1 : 0);
+  return 0;
 }
 
 int bgls_select_context(int index) {

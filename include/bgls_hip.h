@@ -188,6 +188,10 @@ int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const
  * flight per context. */
 int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream);
 int bgls_final_verify_collect(int curve);
+/* Throughput mode: alt-bn128 Miller launches take the shape that is fastest when several verifications are in flight
+ * (60 pairings per block: a 2^16 batch is 1093 blocks, one more round than fit at once when it runs alone).  Results are
+ * identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the environment. */
+int bgls_set_throughput_mode(int on);
 /* Contexts 0..7: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
  * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */
 int bgls_select_context(int index);

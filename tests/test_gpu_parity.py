@@ -333,7 +333,7 @@ ok = ok and rc == 0 and all(raw[(300 + i) * 2 * fp:(301 + i) * 2 * fp].hex() == 
 print("OK" if ok else "MISMATCH")
 ''' % (root, os.path.join(root, "tests", "golden", "vectors_%s.json" % curve["name"]), curve["fp"], curve["id"], curve["id"], curve["id"])
     for env in ({"BGLS_KERNELS": "v1"}, {"BGLS_MILLER": "coop1", "BGLS_FINAL": "6"}, {"BGLS_MILLER": "ab", "BGLS_STEP_CALLS": "1"},
-                {"BGLS_H2C": "rounds"}, {"BGLS_G1_COFACTOR": "1"}, {"BGLS_R28": "1"}):
+                {"BGLS_H2C": "rounds"}, {"BGLS_G1_COFACTOR": "1"}, {"BGLS_R28": "1"}, {"BGLS_THROUGHPUT": "1"}):
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
         assert out.stdout.strip().endswith("OK"), (env, out.stdout[-500:], out.stderr[-500:])
