@@ -506,7 +506,8 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
             if os.path.exists(pmc) and args.curve == "altbn128" and n == 1 << 16:
                 det = json.load(open(pmc))          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the evidence run (profiles/r1)
-                out["roofline"]["traffic"] = det.get("bytes_per_launch_fetch_x2")     # bytes per launch, gfx950 FETCH_SIZE correction applied
+                shape = det.get("throughput_shape") if (pipelined and cid == 0 and not args.no_throughput_mode) else None
+                out["roofline"]["traffic"] = (shape or det).get("bytes_per_launch_fetch_x2")     # bytes per launch, gfx950 FETCH_SIZE correction applied
                 out["roofline"]["traffic_detail"] = det
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cid, keys, msgs, sigs, n, fp, lib)
