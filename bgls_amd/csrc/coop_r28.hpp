@@ -76,6 +76,28 @@ __device__ __forceinline__ F28x2 coop_dot28(int ra_off, int a_e0, int rb_off, in
   return r;
 }
 
+// The same three-term dot product with Karatsuba over i: three limb-product piles per term instead of four
+// (sum a0 b0, sum a1 b1, sum (a0+a1)(b0+b1)), combined column by column at the end.  A column of a difference can be
+// negative although the difference is not, hence the bias (a multiple of p that dominates every column, R28_BIAS3).
+// Only for NT = 3 and undoubled operands: with more terms the sums would leave the 64-bit column budget.
+template <class C>
+__device__ __forceinline__ F28x2 coop_dot28_k3(int ra_off, int a_e0, int rb_off, int j, const int* sh) {
+  u64 v0[20], v1[20], ss[20];
+#pragma unroll
+  for (int k = 0; k < 20; ++k) v0[k] = v1[k] = ss[k] = 0;
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    const int sht = sh[t];
+    int k = j - sht;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    const F28x2 a = lds_ld28(ra_off + (a_e0 + t) * R28_S2);
+    const F28x2 b = lds_ld28(rb_off + (2 * k + wrap) * R28_S2);
+    r28_kara_term(v0, v1, ss, a, b);
+  }
+  return r28_kara_finish<C>(v0, v1, ss);
+}
+
 // f^2 with the symmetric terms merged (COOP_SQ_TAB, see coop_sqr_sym_inl): a doubled term doubles the limbs of its
 // left operand (below 2^29, still inside the column budget: at most three doubled terms and one plain one per lane)
 template <class C>

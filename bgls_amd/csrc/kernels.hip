@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
 // producer idle and the signature pair moves to the epilogue kernel (as on BLS12-381).  A 2^16 batch is 1093 blocks: one
 // more than fit at once, which is irrelevant while launches overlap and a second, nearly empty round when they do not --
 // hence only in throughput mode (bgls_set_throughput_mode).
-template <class C>
+template <class C, int DBG = 0>    // DBG 1 / 2: producer / consumer work only (timing, wrong results)
 __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags) {
   static_assert(C::CURVE_ID == 0 && C::TWIST_D, "alt-bn128 only");
   typedef Coop64<C, true> K;
@@ -1119,22 +1119,22 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      if constexpr (DBG != 2) dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
       done();
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+        if constexpr (DBG != 2) add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
         done();
       }
     }
     {
       Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
       Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-      add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
       done();
       Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
       Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-      add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
       done();
     }
   } else {
@@ -1153,10 +1153,11 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
     coop_publish28<C>(rbo, j, fj, live);
     int buf = 0;
     auto fold = [&]() {
+      if constexpr (DBG == 1) { buf ^= 1; return; }
       const int rlo = gb + (buf ? K::RL2 : K::RL);
 #pragma unroll 1
       for (int m = 0; m < 6; ++m) {
-        fj = coop_dot28<C, 3>(rlo, 3 * m, rbo, j, COOP_SH_D);
+        fj = coop_dot28_k3<C>(rlo, 3 * m, rbo, j, COOP_SH_D);
         coop_publish28<C>(rbo, j, fj, live);
       }
       buf ^= 1;
@@ -1164,8 +1165,10 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();
-      fj = coop_sqr_sym28<C>(rbo, j);
-      coop_publish28<C>(rbo, j, fj, live);
+      if constexpr (DBG != 1) {
+        fj = coop_sqr_sym28<C>(rbo, j);
+        coop_publish28<C>(rbo, j, fj, live);
+      }
       fold();
       if (C::LOOP_NAF[i] != 0) {
         __syncthreads();
@@ -1799,7 +1802,13 @@ struct Engine {
             for (size_t blk0 = 0; blk0 < nb60; blk0 += 8192) {            // grid size stays comfortably inside 32 bits
               const size_t nblocks = nb60 - blk0 < 8192 ? nb60 - blk0 : 8192;
               const size_t p0 = blk0 * 60;
-              k_miller_s60<C><<<(unsigned)nblocks, 128, Coop64<C, true>::BLOCK_BYTES, st>>>(g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags);
+              const char* dbg = getenv("BGLS_AB64_DBG");
+              if (dbg && dbg[0] == '1')
+                k_miller_s60<C, 1><<<(unsigned)nblocks, 128, Coop64<C, true>::BLOCK_BYTES, st>>>(g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags);
+              else if (dbg && dbg[0] == '2')
+                k_miller_s60<C, 2><<<(unsigned)nblocks, 128, Coop64<C, true>::BLOCK_BYTES, st>>>(g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags);
+              else
+                k_miller_s60<C><<<(unsigned)nblocks, 128, Coop64<C, true>::BLOCK_BYTES, st>>>(g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags);
             }
           }
           Scope sc(c, st, ST_REDUCE);

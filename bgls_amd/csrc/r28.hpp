@@ -196,4 +196,29 @@ BGLS_HD F28x2 r28_f2_mul(const F28x2& a, const F28x2& b) {
   return r;
 }
 
+// ---- Karatsuba form of a three-term dot product: three piles per term, one combination per output ----
+BGLS_HD void r28_kara_term(u64 (&v0)[20], u64 (&v1)[20], u64 (&ss)[20], const F28x2& a, const F28x2& b) {
+  F28 sa, sb;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { sa.v[q] = a.c0.v[q] + a.c1.v[q]; sb.v[q] = b.c0.v[q] + b.c1.v[q]; }
+  r28_acc(v0, a.c0, b.c0);
+  r28_acc(v1, a.c1, b.c1);
+  r28_acc(ss, sa, sb);
+}
+// at most three terms of tight operands (limbs < 2^28, top limb < 2^12): see R28_BIAS3 in tools/gen_constants.py
+template <class C>
+BGLS_HD F28x2 r28_kara_finish(u64 (&v0)[20], u64 (&v1)[20], u64 (&ss)[20]) {
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    const u64 bias = C::R28_BIAS3[k];
+    const u64 both = v0[k] + v1[k];
+    ss[k] = ss[k] + bias - both;            // imaginary part: sum (a0 b1 + a1 b0)
+    v0[k] = v0[k] + bias - v1[k];           // real part: sum (a0 b0 - a1 b1)
+  }
+  F28x2 r;
+  r.c0 = r28_redc<C>(v0);
+  r.c1 = r28_redc<C>(ss);
+  return r;
+}
+
 }  // namespace bgls

@@ -196,3 +196,4 @@ def test_r28_consumer_arithmetic(host_harness):
         assert host_harness.ht_r28(2, B(enc(a0, a1)), B(enc(b0, b1)), o) == 0
         assert dec(bytes(o)) == ((9 * a0 - a1) % p, (9 * a1 + a0) % p)
         assert host_harness.ht_r28(3, B(enc(a0, a1)), B(enc(b0, b1)), o) == 1
+        assert host_harness.ht_r28(4, B(enc(a0, a1)), B(enc(b0, b1)), o) == 1

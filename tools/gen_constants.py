@@ -115,6 +115,33 @@ def main():
         o += arr("R28_FAT", fat)
         o += arr("R28_ONE", lim(Rp % p))                              # 1 in R' form
         o += "  static constexpr uint32_t R28_MU = 0x%xu;\n" % ((1 << 278) // p)   # Barrett: q = (top32(y) * MU) >> 32 ~ y 2^24 / p
+        # Column biases for the Karatsuba form of a three-term Fp2 dot product (coop_r28.hpp): column k of
+        # sum (a0+a1)(b0+b1) - sum a0 b0 - sum a1 b1 and of sum a0 b0 - sum a1 b1 can be negative even though the totals are
+        # not; BIAS3[k] >= the largest possible sum (a0 b0 + a1 b1)[k] over three terms of tight operands (limbs < 2^28, top
+        # limb < 2^12), and the whole array is a multiple of p, so adding it changes nothing mod p.
+        la = [1 << 28] * 9 + [1 << 12]
+        col = [0] * 20
+        for i in range(10):
+            for j in range(10):
+                col[i + j] += (la[i] - 1) * (la[j] - 1)
+        bias = []
+        for k in range(20):
+            need = 2 * 3 * col[k]
+            b = 1
+            while b < need + 1:
+                b <<= 1
+            bias.append(b if need else 0)
+        Vb = sum(b << (W * k) for k, b in enumerate(bias))
+        fix = (-Vb) % p
+        for k in range(10):
+            bias[k] += (fix >> (W * k)) & Mk
+        assert fix >> (W * 10) == 0 and sum(b << (W * k) for k, b in enumerate(bias)) % p == 0
+        scol = [0] * 20
+        for i in range(10):
+            for j in range(10):
+                scol[i + j] += (2 * la[i] - 1) * (2 * la[j] - 1)
+        assert all(3 * scol[k] + bias[k] < (1 << 64) for k in range(20))
+        o += "  static constexpr uint64_t R28_BIAS3[20] = {%s};\n" % ", ".join("0x%xull" % b for b in bias)
         o += arr("R28_BACK", limbs((R * R // Rp) % p * 1 % p if (R * R) % Rp == 0 else (R * R * pow(Rp, -1, p)) % p, L))   # 32-bit Montgomery multiplier: x R' -> x R
         return o
 
