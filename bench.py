@@ -465,9 +465,10 @@ def main():
         if ex_cnt:
             ex_s = ex_ms / ex_cnt * 1e-3
             excl = {"launch_ms": ex_s * 1e3, "achieved": macs_per_launch / ex_s / 1e12, "frac": macs_per_launch / ex_s / peak.value if peak.value else None,
-                    "note": "the same kernel with one verification in flight (the %d warm-up steps): its duration when it has the machine to "
-                            "itself.  With %d in flight consecutive launches share the machine: launch_ms_events (HIP events around one "
-                            "launch) stretches, launch_ms = timed region / launches is what a launch costs the machine." % (ex_cnt, L)}
+                    "note": "the Miller launch with one verification in flight (the %d warm-up steps; k_miller_ab64, the shape the library "
+                            "uses when launches do not overlap): its duration with the machine to itself.  With %d in flight consecutive "
+                            "launches share the machine: launch_ms_events (HIP events around one launch) stretches, launch_ms = timed "
+                            "region / launches is what a launch costs the machine." % (ex_cnt, L)}
         cname = "BN254" if cid == 0 else "BLS381"
         # the library's dispatch rule (Engine::miller_coop): 64 pairings per block, consecutive launches of 1024 blocks
         miller_kernel = "k_miller_ab64<%s>%s" % (cname, "" if (n + 63) // 64 <= 1024 else " x%d launches" % (((n + 63) // 64 + 1023) // 1024))
