@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o /tmp/microbench && /tmp/microbench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include "../bgls_amd/csrc/coop.hpp"
+#include "../bgls_amd/csrc/coop_r28.hpp"
 using namespace bgls;
 
 template <class C>
