@@ -1837,7 +1837,7 @@ struct Engine {
         {
           Scope sc(c, st, ST_MILLER);
           const char* dbg = getenv("BGLS_AB64_DBG");
-          const int dbgm = (C::CURVE_ID == 0 && dbg) ? dbg[0] - '0' : 0;
+          const int dbgm = dbg ? dbg[0] - '0' : 0;
           for (size_t blk0 = 0; blk0 < nb64; blk0 += 1024) {
             const size_t nblocks = nb64 - blk0 < 1024 ? nb64 - blk0 : 1024;
             const size_t p0 = blk0 * 64;                                   // first pairing of this launch
@@ -1847,11 +1847,11 @@ struct Engine {
             const long long sig_at = (blk0 == 0 && gen_at >= 0) ? gen_at : -1LL;   // block 0 of the first launch scales the generator lines
             Fp2<C>* outc = (Fp2<C>*)pa + blk0 * 10 * 6;
             const LineCoeffs<C>* gl = (const LineCoeffs<C>*)c.gen_lines[C::CURVE_ID];
-            if (dbgm == 1 && !r28_mode())
-              k_miller_ab64<BN254, 1><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
-            else if (dbgm == 2 && !r28_mode())
-              k_miller_ab64<BN254, 2><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
-            else if (dbgm == 3)
+            if (dbgm == 1 && !(C::CURVE_ID == 0 && r28_mode()))
+              k_miller_ab64<C, 1><<<(unsigned)nblocks, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1c, g2c, np, sig_at, gl, outc, d_flags, ab64_swap());
+            else if (dbgm == 2 && !(C::CURVE_ID == 0 && r28_mode()))
+              k_miller_ab64<C, 2><<<(unsigned)nblocks, 128, Coop64<C>::BLOCK_BYTES, st>>>(g1c, g2c, np, sig_at, gl, outc, d_flags, ab64_swap());
+            else if (dbgm == 3 && C::CURVE_ID == 0)
               k_miller_ab64<BN254, 3><<<(unsigned)nblocks, 128, Coop64<BN254>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
             else if (C::CURVE_ID == 0 && r28_mode() && dbgm == 1)
               k_miller_ab64<BN254, 1, true><<<(unsigned)nblocks, 128, Coop64<BN254, true>::BLOCK_BYTES, st>>>((const Aff<F1<BN254>>*)g1c, g2c, np, sig_at, (const LineCoeffs<BN254>*)gl, (Fp2<BN254>*)outc, d_flags, ab64_swap());
