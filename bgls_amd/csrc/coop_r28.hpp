@@ -79,7 +79,9 @@ __device__ __forceinline__ F28x2 coop_dot28(int ra_off, int a_e0, int rb_off, in
 // The same three-term dot product with Karatsuba over i: three limb-product piles per term instead of four
 // (sum a0 b0, sum a1 b1, sum (a0+a1)(b0+b1)), combined column by column at the end.  A column of a difference can be
 // negative although the difference is not, hence the bias (a multiple of p that dominates every column, R28_BIAS3).
-// Only for NT = 3 and undoubled operands: with more terms the sums would leave the 64-bit column budget.
+// Only for NT = 3 and undoubled operands: with more terms the sums would leave the 64-bit column budget.  Worst case for
+// operands with limbs < 2^28 (top limb < 2^12): a column reaches 2^63.43 before the reduction and 2^63.51 with the
+// reduction's own products and carries, a factor 1.4 below 2^64 (asserted when the constants are generated).
 template <class C>
 __device__ __forceinline__ F28x2 coop_dot28_k3(int ra_off, int a_e0, int rb_off, int j, const int* sh) {
   u64 v0[20], v1[20], ss[20];
