@@ -1,0 +1,1376 @@
+// Host side of the aggregate-verify engine: contexts, workspaces, the stage pipeline and the C ABI declared in
+// include/bgls_hip.h.  Pipeline of bgls.VerifyAggregateSignature (bgls/bgls.go:94-119) on the device:
+//   dup_check     exact duplicate-message scan          (containsDuplicateMessage, bgls.go:139-150)
+//   hash_to_g1    H(m_i) for every message              (concurrentHash, bgls.go:107-111,134-137)
+//   g1_parse      -sigma                                (aggsig.Mul(-1), bgls.go:112)
+//   miller        Miller values of every (H(m_i), pk_i) and of (-sigma, g2), multiplied into per-group partial products
+//                                                       (concurrentPair + GT Add tree, curves/curve.go:132-169,217-223)
+//   reduce        product of the partial products
+//   final36       ONE final exponentiation, compare with 1 (Equals(GetGTIdentity), bgls.go:115-118)
+// Kernels live in the k_*.hip units and are reached through launch.hpp.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+#include <atomic>
+#include <string>
+
+#include "dev_common.hpp"
+#include "coop.hpp"
+#include "coop_r28.hpp"
+#include "finalexp.hpp"
+#include "miller_kernels.hpp"
+#include "launch.hpp"
+#include "../../include/bgls_hip.h"
+
+using namespace bgls;
+
+// ======================================================================= host side
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[256];
+  if (e != hipSuccess)
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(buf, sizeof buf, "%s", what);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                         \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return fail(BGLS_ERR_HIP, #expr, e_); \
+  } while (0)
+
+// Largest batch one call accepts: the duplicate table (2n rounded up to a power of two, u32 slots), the hashing work
+// lists (u32 indices) and the grid computations all assume n < 2^30.
+constexpr size_t MAX_BATCH = (size_t)1 << 30;
+
+// workspace slots
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_NUM };
+
+struct Ctx {
+  std::mutex mu;
+  int device = 0;
+  bool ready = false;
+  hipStream_t stream = nullptr;
+  std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
+  uint32_t* h_res = nullptr;                 // pinned host words {verdict, final-stage flags, caller flags} of the verification in flight
+  bool res_pending = false;
+  hipStream_t res_stream = nullptr;
+  // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
+  bool prof = false;
+  struct Pending { hipEvent_t a, b; int stage; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+  double stage_ms[8] = {0};
+  unsigned long long stage_cnt[8] = {0};
+  hipEvent_t ev() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void collect() {
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { stage_ms[p.stage] += ms; stage_cnt[p.stage] += 1; }
+      ev_pool.push_back(p.a);
+      ev_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+
+  // makes this context's device current for the calling thread and creates the stream on first use
+  int enter() {
+    if (!ready) {
+      int cnt = 0;
+      hipError_t e = hipGetDeviceCount(&cnt);
+      if (e != hipSuccess || cnt <= 0) return fail(BGLS_ERR_NO_DEVICE, "no HIP device available", e);
+      if (device < 0 || device >= cnt) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
+    }
+    HIPCHK(hipSetDevice(device));
+    if (ready) return 0;
+    HIPCHK(hipStreamCreate(&stream));
+    HIPCHK(hipHostMalloc((void**)&h_res, 64));
+    ws.assign(WS_NUM + 8, {nullptr, 0});
+    ready = true;
+    return 0;
+  }
+  int get(int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ws[slot].second < bytes) {
+      if (ws[slot].first) HIPCHK(hipFree(ws[slot].first));
+      ws[slot] = {nullptr, 0};
+      size_t cap = bytes + bytes / 4;
+      HIPCHK(hipMalloc(&ws[slot].first, cap));
+      ws[slot].second = cap;
+    }
+    *out = ws[slot].first;
+    return 0;
+  }
+};
+
+// Contexts: each owns a stream, its workspaces and its stage timers.  A host thread works on context (device, index) =
+// (bgls_init's device or bgls_select_device's, bgls_select_context's index, default 0): several contexts of one device
+// let one thread keep several verifications in flight, so the serial, latency-bound stages of one (hashing rounds,
+// reduction tail, final exponentiation) overlap the Miller launch of another; contexts of different devices are what
+// the multi-GPU entry points drive from their worker threads.
+constexpr int NCTX = 8;
+constexpr int MAX_DEVICES = 16;
+std::atomic<int> g_default_device{0};
+thread_local int g_sel = 0;
+thread_local int g_dev = -1;           // -1: the process default
+Ctx* ctx_pool() {
+  static Ctx c[MAX_DEVICES][NCTX];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (int d = 0; d < MAX_DEVICES; ++d)
+      for (int k = 0; k < NCTX; ++k) c[d][k].device = d;
+  });
+  return &c[0][0];
+}
+int cur_device() { return g_dev >= 0 ? g_dev : g_default_device.load(); }
+Ctx& ctx_of(int device, int index) { return ctx_pool()[(size_t)device * NCTX + index]; }
+Ctx& ctx() { return ctx_of(cur_device(), g_sel); }
+
+// Per-device tables built once: the fixed-argument line coefficients of the generator g2 (k_gen_lines), one per curve.
+// Built under the device's lock on a private stream and published only after the build has completed, so every stream
+// of every context of that device may read them without further ordering.
+struct DeviceTables {
+  std::mutex mu;
+  void* gen_lines[2] = {nullptr, nullptr};
+};
+DeviceTables& tables_of(int device) {
+  static DeviceTables t[MAX_DEVICES];
+  return t[device];
+}
+
+// Throughput mode (bgls_set_throughput_mode / BGLS_THROUGHPUT=1): alt-bn128 batches use k_miller_s60, whose launches are
+// meant to overlap with their neighbours (several verifications in flight).
+std::atomic<int> g_throughput{-1};
+bool throughput_mode() {
+  int v = g_throughput.load();
+  if (v < 0) {
+    const char* e = getenv("BGLS_THROUGHPUT");
+    v = (e && e[0] == '1') ? 1 : 0;
+    g_throughput.store(v);
+  }
+  return v == 1;
+}
+
+#ifdef BGLS_DEV
+// development builds only: BGLS_MILLER_DBG=1/2 times the producer / consumer half of the fused Miller kernels (WRONG results)
+int miller_dbg() {
+  static const int v = [] { const char* e = getenv("BGLS_MILLER_DBG"); return e ? atoi(e) : 0; }();
+  return v;
+}
+#else
+constexpr int miller_dbg() { return 0; }
+#endif
+
+enum { ST_DUP = 0, ST_H2C, ST_MILLER, ST_REDUCE, ST_FINAL, ST_SUM, ST_NUM };
+const char* const STAGE_NAMES[ST_NUM] = {"dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points"};
+
+struct Scope {  // brackets the launches of one stage with events when profiling is on
+  Ctx& c; hipStream_t st; int stage; hipEvent_t a = nullptr;
+  Scope(Ctx& c_, hipStream_t st_, int stage_) : c(c_), st(st_), stage(stage_) {
+    if (c.prof) { a = c.ev(); (void)hipEventRecord(a, st); }
+  }
+  ~Scope() {
+    if (c.prof && a) { hipEvent_t b = c.ev(); (void)hipEventRecord(b, st); c.pending.push_back({a, b, stage}); }
+  }
+};
+
+template <class C>
+struct Engine {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  static constexpr size_t FB = C::FP_BYTES, G1B = 2 * FB, G2B = 4 * FB, GTB = 12 * FB;
+
+  static int dup_scan(Ctx& c, hipStream_t st, MsgView mv, size_t n, uint32_t* d_flags) {
+    if (n < 2) return 0;
+    if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+    size_t cap = 1;
+    while (cap < 2 * n) cap <<= 1;
+    void* tab;
+    int rc;
+    if ((rc = c.get(WS_TABLE, cap * 4, &tab))) return rc;
+    Scope sc(c, st, ST_DUP);
+    HIPCHK(hipMemsetAsync(tab, 0, cap * 4, st));
+    kl::dup_check(st, mv, n, (uint32_t*)tab, (uint32_t)(cap - 1), d_flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
+  // d_flags: device u32 (already zeroed by caller).  Writes the product of the n (+1) Miller values to d_partial (GT
+  // bytes, no final exponentiation).
+  static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
+                            int check_dups, uint8_t* d_partial, uint32_t* d_flags) {
+    if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+    const bool raw = C::CURVE_ID == 1 && n > 0;     // BLS12-381: uncleared hash points, cofactor applied once in GT
+    void* g1s;
+    int rc;
+    if ((rc = c.get(WS_G1S, (n + 2) * sizeof(Aff<G1F>), &g1s))) return rc;
+    if (check_dups && (rc = dup_scan(c, st, mv, n, d_flags))) return rc;
+    if (n) {
+      Scope sc(c, st, ST_H2C);
+      if ((rc = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags, raw))) return rc;
+    }
+    if (d_sig) kl::g1_parse<C>(st, d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
+    return miller(c, st, (const Aff<G1F>*)g1s, d_keys, n, d_sig ? (const Aff<G1F>*)g1s + n : nullptr, d_partial, d_flags, raw);
+  }
+
+  // H(m_i) as affine Montgomery points.  raw (BLS12-381 only): points before cofactor clearing, for the cofactor-in-GT
+  // verification path.
+  static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags, bool raw = false) {
+    if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+    int rc;
+    void *lists = nullptr, *cnts = nullptr;
+    if constexpr (C::CURVE_ID == 0) {
+      if (n >= 256) {
+        if ((rc = c.get(WS_H2C_LIST, 2 * n * 4, &lists))) return rc;
+        if ((rc = c.get(WS_H2C_CNT, 64, &cnts))) return rc;
+        HIPCHK(hipMemsetAsync(cnts, 0, 64, st));
+      }
+      kl::h2c_bn(st, mv, n, (uint32_t*)lists, (uint32_t*)cnts, out, d_flags);
+    } else {
+      void *pts, *kinds;
+      if ((rc = c.get(WS_H2C_PTS, 2 * n * sizeof(Aff<G1F>), &pts))) return rc;
+      if ((rc = c.get(WS_H2C_KIND, 2 * n * 4, &kinds))) return rc;
+      kl::h2c_bls(st, mv, n, (Aff<G1F>*)pts, (uint32_t*)kinds, out, raw);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
+  // fixed-argument lines of g2 for this device (DeviceTables)
+  static int gen_lines(Ctx& c, const LineCoeffs<C>** out) {
+    DeviceTables& t = tables_of(c.device);
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (!t.gen_lines[C::CURVE_ID]) {
+      void *tab = nullptr, *cnt = nullptr;
+      hipStream_t bs = nullptr;
+      HIPCHK(hipMalloc(&tab, 160 * sizeof(LineCoeffs<C>)));
+      hipError_t e = hipMalloc(&cnt, 16);
+      if (e == hipSuccess) e = hipStreamCreate(&bs);
+      if (e == hipSuccess) {
+        kl::gen_lines<C>(bs, (LineCoeffs<C>*)tab, (int*)cnt);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
+      }
+      if (bs) (void)hipStreamDestroy(bs);
+      if (cnt) (void)hipFree(cnt);
+      if (e != hipSuccess) {
+        (void)hipFree(tab);
+        return fail(BGLS_ERR_HIP, "building the generator line table", e);
+      }
+      t.gen_lines[C::CURVE_ID] = tab;
+    }
+    *out = (const LineCoeffs<C>*)t.gen_lines[C::CURVE_ID];
+    return 0;
+  }
+
+  // product of the per-group partial products (w-basis Fp12 arrays, 6 Fp2 each) down to one
+  static int reduce(Ctx& c, hipStream_t st, Fp2<C>* a, Fp2<C>* b, size_t cnt, Fp2<C>** out) {
+    Scope sc(c, st, ST_REDUCE);
+    const int R = 4;                       // each pass costs R-1 dependent products of latency: keep the tree shallow per pass
+    while (cnt > 1) {
+      const size_t nout = (cnt + R - 1) / R;
+      kl::reduce_coop<C>(st, a, cnt, R, b);
+      Fp2<C>* t = a;
+      a = b;
+      b = t;
+      cnt = nout;
+    }
+    HIPCHK(hipGetLastError());
+    *out = a;
+    return 0;
+  }
+
+  // Miller product of npairs (g1s[i], g2s[i]) pairs and, when sig != nullptr, of (*sig, g2) on the generator's
+  // pre-computed lines; GT bytes (no final exponentiation) to d_partial.  sig must be an element of the g1s array
+  // (verification stores -sigma behind the hash points).  cofactor: the g1s are uncleared BLS12-381 hash points, the
+  // product of their Miller values is raised to the G1 cofactor before the signature pair is folded in.
+  static int miller(Ctx& c, hipStream_t st, const Aff<G1F>* g1s, const uint8_t* g2s, size_t npairs, const Aff<G1F>* sig,
+                    uint8_t* d_partial, uint32_t* d_flags, bool cofactor = false) {
+    if (npairs == 0 && !sig) {
+      HIPCHK(hipMemsetAsync(d_partial, 0, GTB, st));
+      HIPCHK(hipMemsetAsync(d_partial + GTB - 1, 1, 1, st));
+      return 0;
+    }
+    int rc;
+    const LineCoeffs<C>* gl = nullptr;
+    if (sig && (rc = gen_lines(c, &gl))) return rc;
+    void *pa, *pb;
+    Fp2<C>* red = nullptr;
+    bool epilogue = cofactor;
+    if constexpr (C::CURVE_ID == 0) {
+      if (throughput_mode() && npairs >= 1) {
+        // 60 pairings per block, 28-bit-limb consumer; the signature pair goes to the epilogue kernel
+        const size_t nb60 = (npairs + 59) / 60, groups = nb60 * 10;
+        if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+        if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+        {
+          Scope sc(c, st, ST_MILLER);
+          for (size_t blk0 = 0; blk0 < nb60; blk0 += 8192) {
+            const size_t nblocks = nb60 - blk0 < 8192 ? nb60 - blk0 : 8192;
+            const size_t p0 = blk0 * 60;
+            kl::miller_s60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, miller_dbg());
+          }
+          HIPCHK(hipGetLastError());
+        }
+        if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, groups, &red))) return rc;
+        epilogue = sig != nullptr;
+        return emit_partial(c, st, red, epilogue, sig, gl, d_partial);
+      }
+    }
+    // 64 pairings per block at 256 registers: one 2^16 batch is exactly 1024 resident blocks; larger batches run as
+    // consecutive launches of 1024 blocks.  Block 0 of the first launch also scales the generator lines for the
+    // signature pair (unless the epilogue kernel does: cofactor path).
+    const size_t nb64 = npairs ? (npairs + 63) / 64 : 1, groups = nb64 * 10;
+    if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    {
+      Scope sc(c, st, ST_MILLER);
+      for (size_t blk0 = 0; blk0 < nb64; blk0 += 1024) {
+        const size_t nblocks = nb64 - blk0 < 1024 ? nb64 - blk0 : 1024;
+        const size_t p0 = blk0 * 64;
+        const size_t np = npairs - p0 < nblocks * 64 ? npairs - p0 : nblocks * 64;
+        const long long sig_at = (blk0 == 0 && sig && !cofactor) ? (long long)(sig - (g1s + p0)) : -1LL;
+        kl::miller_ab64<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, np, sig_at, gl, (Fp2<C>*)pa + blk0 * 10 * 6, d_flags, miller_dbg());
+      }
+      HIPCHK(hipGetLastError());
+    }
+    if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, groups, &red))) return rc;
+    return emit_partial(c, st, red, cofactor, cofactor ? sig : nullptr, gl, d_partial);
+  }
+
+  // serialise the reduced product; with `epilogue`: raise it to the G1 cofactor (BLS12-381 raw hash points; a no-op
+  // exponent on alt-bn128) and fold the signature pair in on the 36-lane arithmetic
+  static int emit_partial(Ctx& c, hipStream_t st, const Fp2<C>* w, bool epilogue, const Aff<G1F>* sig, const LineCoeffs<C>* gl,
+                          uint8_t* d_partial) {
+    (void)c;
+    if (!epilogue) kl::w_to_bytes<C>(st, w, d_partial);
+    else kl::cofactor_epilogue<C>(st, w, sig, gl, d_partial);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
+  // enqueue product-of-partials + final exponentiation + compare; the verdict lands in the context's pinned words
+  static int finalize_submit(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
+                             uint8_t* h_gt_out) {
+    void *tmp, *fl;
+    int rc;
+    if (c.res_pending) return fail(BGLS_ERR_ARG, "a verification is already in flight on this context (collect it first)");
+    if ((rc = c.get(WS_TMP, GTB + 16, &tmp))) return rc;
+    if ((rc = c.get(WS_OUT, 16, &fl))) return rc;
+    uint8_t* d_gt = (uint8_t*)tmp;
+    uint32_t* d_verdict = (uint32_t*)(d_gt + GTB);
+    uint32_t* d_fl2 = (uint32_t*)fl;
+    HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
+    {
+      Scope sc(c, st, ST_FINAL);
+      kl::final36<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+    }
+    HIPCHK(hipGetLastError());
+    c.h_res[0] = c.h_res[1] = c.h_res[2] = 0;
+    HIPCHK(hipMemcpyAsync(&c.h_res[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&c.h_res[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
+    if (d_flags_in) HIPCHK(hipMemcpyAsync(&c.h_res[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
+    if (h_gt_out) HIPCHK(hipMemcpyAsync(h_gt_out, d_gt, GTB, hipMemcpyDeviceToHost, st));
+    c.res_pending = true;
+    c.res_stream = st;
+    return 0;
+  }
+  // wait for the verification in flight; returns 1/0 or <0
+  static int finalize_collect(Ctx& c) {
+    if (!c.res_pending) return fail(BGLS_ERR_ARG, "no verification in flight on this context");
+    c.res_pending = false;
+    HIPCHK(hipStreamSynchronize(c.res_stream));
+    c.collect();
+    uint32_t f = c.h_res[1] | c.h_res[2];
+    if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+    if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "G2 point outside the order-r subgroup");
+    if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
+    if (f & FLAG_DUP) return 0;
+    return c.h_res[0] ? 1 : 0;
+  }
+  // returns 1/0 or <0; optionally copies the GT bytes out
+  static int finalize(Ctx& c, hipStream_t st, const uint8_t* d_partials, size_t count, int do_final_exp, const uint32_t* d_flags_in,
+                      uint8_t* h_gt_out) {
+    int rc;
+    if ((rc = finalize_submit(c, st, d_partials, count, do_final_exp, d_flags_in, h_gt_out))) return rc;
+    return finalize_collect(c);
+  }
+
+  // AggregatePoints (curves/curve.go:73-121): affine bytes of the sum of n points to d_out
+  static int sum_points(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, uint8_t* d_out, uint32_t* d_flags) {
+    const size_t PTB = group == BGLS_G1 ? G1B : G2B;
+    if (n == 0) {
+      HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
+      return 0;
+    }
+    // Fan-in per pass.  A pass costs (fan-in - 1) dependent additions of latency, so once the partial sums no longer
+    // fill the chip (two resident waves per SIMD at these register counts = 131 072 threads) the tree narrows by 2
+    // per pass instead of 16: log2 passes of ONE addition each instead of a few passes of 15.
+    auto fan = [&](size_t items) {
+      size_t r = (items + 131071) / 131072;
+      return (int)(r < 2 ? 2 : r > 16 ? 16 : r);
+    };
+    void *ja, *jb;
+    int rc;
+    Scope sc(c, st, ST_SUM);
+    const size_t JB = kl::jac_bytes<C>(group);
+    const int R1 = fan(n);
+    size_t n1 = (n + R1 - 1) / R1;
+    if ((rc = c.get(WS_JAC_A, (n1 + 1) * JB, &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (n1 / 2 + 2) * JB, &jb))) return rc;
+    kl::sum_first<C>(st, group, d_pts, n, R1, ja, d_flags);
+    void *a = ja, *b = jb;
+    size_t cnt = n1;
+    while (cnt > 1) {
+      const int R = fan(cnt);
+      size_t nout = (cnt + R - 1) / R;
+      kl::sum_next<C>(st, group, a, cnt, R, b);
+      void* t = a;
+      a = b;
+      b = t;
+      cnt = nout;
+    }
+    kl::jac_to_bytes<C>(st, group, a, 1, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+};
+
+int flags_to_rc(uint32_t f) {
+  if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+  if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
+  return 0;
+}
+
+#define DISPATCH(curve, CALL)                                    \
+  do {                                                           \
+    if ((curve) == BGLS_CURVE_ALTBN128) {                        \
+      typedef BN254 CV;                                          \
+      return CALL;                                               \
+    } else if ((curve) == BGLS_CURVE_BLS12_381) {                \
+      typedef BLS381 CV;                                         \
+      return CALL;                                               \
+    }                                                            \
+    return fail(BGLS_ERR_ARG, "unknown curve id");               \
+  } while (0)
+
+template <class C>
+int verify_aggregate_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* blob, const uint64_t* off, size_t n, int allow_dups) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = n ? off[n] : 0;
+  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, mv, n, !allow_dups, (uint8_t*)d_part,
+                              (uint32_t*)d_flags)))
+    return rc;
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, size_t n, const uint8_t* d_msg,
+                       size_t msg_len, bool submit_only = false) {
+  typedef Engine<C> E;
+  int rc;
+  void *d_flags, *d_g2s, *d_g1s, *d_part;
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_TMP2, 2 * E::G2B, &d_g2s))) return rc;
+  if ((rc = c.get(WS_G1S, 4 * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  // apk = sum(keys)  (AggregatePoints)
+  if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags))) return rc;
+  // pairs (-H(msg), apk) and (sig, g2): one message through the batch hashing path, then the two-pairing product on the
+  // cooperative Miller kernel with the (sig, g2) pair on the pre-computed generator lines
+  MsgView mv = {d_msg, nullptr, msg_len, msg_len};
+  Aff<F1<C>>* g1s = (Aff<F1<C>>*)d_g1s;
+  if ((rc = E::hash_to_g1(c, st, mv, 1, g1s + 2, (uint32_t*)d_flags))) return rc;
+  kl::g1_to_bytes<C>(st, g1s + 2, 1, (uint8_t*)d_part);                                    // scratch: H(m) bytes
+  kl::g1_parse<C>(st, (const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);               // -H(m)
+  kl::g1_parse<C>(st, d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);                            // sig
+  if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
+  if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int verify_multi_t(const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sig, *d_keys, *d_msg;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, msg_len, &d_msg))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (msg_len) HIPCHK(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len);
+}
+
+template <class C>
+int pairing_product_t(const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  void *d_g1b, *d_g2b, *d_g1s, *d_flags, *d_part;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_g1b))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_g2b))) return rc;
+  if ((rc = c.get(WS_G1S, (n + 1) * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n == 0) {
+    memset(gt_out, 0, E::GTB);
+    gt_out[E::GTB - 1] = 1;
+    return 0;
+  }
+  HIPCHK(hipMemcpyAsync(d_g1b, g1s, n * E::G1B, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_g2b, g2s, n * E::G2B, hipMemcpyHostToDevice, st));
+  kl::g1_parse<C>(st, (const uint8_t*)d_g1b, n, 0, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags);
+  if ((rc = E::miller(c, st, (const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_g2b, n, nullptr, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
+  rc = E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, gt_out);
+  return rc < 0 ? rc : 0;
+}
+
+template <class C>
+int hash_to_g1_t(const uint8_t* blob, const uint64_t* off, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = off[n];
+  void *d_blob, *d_off, *d_g1s, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_G1S, n * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::hash_to_g1(c, st, mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags))) return rc;
+  kl::g1_to_bytes<C>(st, (const Aff<F1<C>>*)d_g1s, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int aggregate_points_t(int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * PB, &d_in))) return rc;
+  if ((rc = c.get(WS_OUT, PB, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_in, pts, n * PB, hipMemcpyHostToDevice, st));
+  rc = E::sum_points(c, st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  if (rc) return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int scale_points_t(int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_sc, *d_sg, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * PB, &d_in))) return rc;
+  if ((rc = c.get(WS_IN_C, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_IN_D, n, &d_sg))) return rc;
+  if ((rc = c.get(WS_IN_A, n * PB, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, pts, n * PB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, st));
+  if (signs) HIPCHK(hipMemcpyAsync(d_sg, signs, n, hipMemcpyHostToDevice, st));
+  const uint8_t* sg = signs ? (const uint8_t*)d_sg : nullptr;
+  kl::scale<C>(st, group, (const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out, (uint32_t*)d_flags, 32);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int point_check_t(int group, const uint8_t* a) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_flags;
+  if ((rc = c.get(WS_IN_B, PB, &d_in))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, a, PB, hipMemcpyHostToDevice, st));
+  kl::check<C>(st, group, (const uint8_t*)d_in, 1, (uint32_t*)d_flags);
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return f ? 0 : 1;
+}
+
+template <class C>
+int generator_t(int group, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void* d_out;
+  if ((rc = c.get(WS_OUT, PB, &d_out))) return rc;
+  kl::generator<C>(st, group, (uint8_t*)d_out);
+  HIPCHK(hipMemcpyAsync(out, d_out, PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+template <class C>
+int gt_mul_t(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void* d_in;
+  if ((rc = c.get(WS_IN_A, 2 * E::GTB, &d_in))) return rc;
+  HIPCHK(hipMemcpyAsync(d_in, a, E::GTB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync((uint8_t*)d_in + E::GTB, b, E::GTB, hipMemcpyHostToDevice, st));
+  rc = E::finalize(c, st, (const uint8_t*)d_in, 2, 0, nullptr, out);
+  return rc < 0 ? rc : 0;
+}
+
+template <class C>
+int miller_product_dev_t(const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
+                         int check_dups, void* d_partial, void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  return E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, mv, n, check_dups, (uint8_t*)d_partial,
+                           (uint32_t*)d_flags);
+}
+
+// containsDuplicateMessage (bgls/bgls.go:139-150) over device-resident fixed-stride messages: exact byte comparison
+int duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  return Engine<BN254>::dup_scan(c, st, mv, n, (uint32_t*)d_flags);      // curve-independent
+}
+
+template <class C>
+int final_verify_dev_t(const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return E::finalize(c, st, (const uint8_t*)d_partials, count, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int final_verify_submit_dev_t(const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return E::finalize_submit(c, st, (const uint8_t*)d_partials, count, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int aggregate_points_dev_t(int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  void* d_flags;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  rc = E::sum_points(c, st, group, (const uint8_t*)d_pts, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+  if (rc) return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
+int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len, void* stream,
+                             bool submit_only = false) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len, submit_only);
+}
+
+// ---- hashed aggregation exponents / weighted sums: host flows -------------------------------------------------
+// Root digest of BLAKE2Xb (hashes.hpp has the device-side tables; these are the host's own copies).  One sequential
+// compression chain over all key bytes -- by construction not parallel -- computed while the keys travel to the device.
+namespace host_blake2 {
+const uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                        0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+const uint8_t SIGMA[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+inline uint64_t ror(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+inline void compress(uint64_t h[8], const uint8_t* block, uint64_t t, bool last) {
+  uint64_t m[16], v[16];
+  memcpy(m, block, 128);                                     // little-endian host
+  for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+  v[12] ^= t;
+  if (last) v[14] = ~v[14];
+#define BGLS_G(a, b, c, d, x, y)                                                    \
+  v[a] += v[b] + (x); v[d] = ror(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 24); \
+  v[a] += v[b] + (y); v[d] = ror(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 63);
+  for (int r = 0; r < 12; ++r) {
+    const uint8_t* s = SIGMA[r];
+    BGLS_G(0, 4, 8, 12, m[s[0]], m[s[1]]) BGLS_G(1, 5, 9, 13, m[s[2]], m[s[3]])
+    BGLS_G(2, 6, 10, 14, m[s[4]], m[s[5]]) BGLS_G(3, 7, 11, 15, m[s[6]], m[s[7]])
+    BGLS_G(0, 5, 10, 15, m[s[8]], m[s[9]]) BGLS_G(1, 6, 11, 12, m[s[10]], m[s[11]])
+    BGLS_G(2, 7, 8, 13, m[s[12]], m[s[13]]) BGLS_G(3, 4, 9, 14, m[s[14]], m[s[15]])
+  }
+#undef BGLS_G
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+// h <- BLAKE2Xb root of data[0..len) for an XOF of xof_len bytes (x/crypto/blake2b/blake2x.go Reset + Write + finalize)
+void xb_root(const uint8_t* data, size_t len, uint32_t xof_len, uint64_t h[8]) {
+  for (int i = 0; i < 8; ++i) h[i] = IV[i];
+  h[0] ^= 0x01010040ull;
+  h[1] ^= (uint64_t)xof_len << 32;
+  size_t off = 0;
+  while (len - off > 128) {
+    compress(h, data + off, (uint64_t)off + 128, false);
+    off += 128;
+  }
+  uint8_t lastb[128];
+  memset(lastb, 0, 128);
+  if (len > off) memcpy(lastb, data + off, len - off);
+  compress(h, lastb, (uint64_t)len, true);
+}
+}  // namespace host_blake2
+
+// d_t (WS_HAE_T) <- the n 16-byte exponents of hashPubKeysToExponents (blsHAE.go:80-93) for the keys' wire bytes
+template <class C>
+int hae_exponents_dev(Ctx& c, hipStream_t st, const uint8_t* h_keys, size_t n, void** d_t) {
+  typedef Engine<C> E;
+  if (n >= (1ull << 28)) return fail(BGLS_ERR_ARG, "XOF length 16 n must fit a uint32 (blsHAE.go:81)");
+  int rc;
+  void* d_root;
+  if ((rc = c.get(WS_HAE_ROOT, 64, &d_root))) return rc;
+  if ((rc = c.get(WS_HAE_T, n * 16, d_t))) return rc;
+  if (n == 0) return 0;
+  uint64_t root[8];
+  const uint32_t xof_len = (uint32_t)(16 * n);
+  host_blake2::xb_root(h_keys, n * E::G2B, xof_len, root);
+  HIPCHK(hipMemcpyAsync(d_root, root, 64, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));                          // root[] is a stack buffer
+  kl::blake2x_expand(st, (const uint64_t*)d_root, xof_len, (uint8_t*)*d_t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <class C>
+int hae_exponents_t(const uint8_t* keys, size_t n, uint8_t* t_out) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  void* d_t;
+  if ((rc = hae_exponents_dev<C>(c, c.stream, keys, n, &d_t))) return rc;
+  if (n) HIPCHK(hipMemcpyAsync(t_out, d_t, n * 16, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// d_out (affine bytes) <- sum_i w_i P_i over device-resident points and 16-byte weights
+template <class C>
+int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint8_t* d_w16, const uint8_t* d_signs, size_t n,
+                     uint8_t* d_out, uint32_t* d_flags) {
+  const size_t PTB = group == BGLS_G1 ? Engine<C>::G1B : Engine<C>::G2B;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
+    return 0;
+  }
+  void *ja, *jb;
+  int rc;
+  Scope sc(c, st, ST_SUM);
+  const size_t JB = kl::jac_bytes<C>(group);
+  if ((rc = c.get(WS_JAC_A, (n + 1) * JB, &ja))) return rc;
+  if ((rc = c.get(WS_JAC_B, (n / 2 + 2) * JB, &jb))) return rc;
+  kl::wsum_first<C>(st, group, d_pts, d_w16, d_signs, n, ja, d_flags);
+  void *a = ja, *b = jb;
+  size_t cnt = n;
+  while (cnt > 1) {
+    size_t r16 = (cnt + 131071) / 131072;                 // same fan-in rule as Engine::sum_points
+    const int R = (int)(r16 < 2 ? 2 : r16 > 16 ? 16 : r16);
+    size_t nout = (cnt + R - 1) / R;
+    kl::sum_next<C>(st, group, a, cnt, R, b);
+    void* t = a;
+    a = b;
+    b = t;
+    cnt = nout;
+  }
+  kl::jac_to_bytes<C>(st, group, a, 1, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// verify_multi with apk = sum w_i pk_i: VerifyMultiSignatureWithHAE (blsHAE.go:56-58; weights hashed from the keys) when
+// mult == nullptr, the core of KoskVerifyMultiSignatureWithMultiplicity (blsKosk.go:137-150) otherwise.
+template <class C>
+int verify_multi_weighted_t(const uint8_t* sig, const uint8_t* keys, const int64_t* mult, size_t n, const uint8_t* msg, size_t msg_len) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sig, *d_keys, *d_msg, *d_apk, *d_fl2, *d_t = nullptr, *d_sg = nullptr;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, msg_len, &d_msg))) return rc;
+  if ((rc = c.get(WS_HAE_APK, E::G2B, &d_apk))) return rc;
+  if ((rc = c.get(WS_FLAGS2, 16, &d_fl2))) return rc;
+  HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (msg_len) HIPCHK(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+  if (!mult) {
+    if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  } else {
+    std::vector<uint8_t> w(n * 16, 0), sg(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      const int64_t m = mult[i];
+      uint64_t mag = m < 0 ? (uint64_t)0 - (uint64_t)m : (uint64_t)m;
+      sg[i] = m < 0 ? 1 : 0;
+      for (int b = 0; b < 8; ++b) w[i * 16 + 15 - b] = (uint8_t)(mag >> (8 * b));
+    }
+    if ((rc = c.get(WS_HAE_T, n * 16, &d_t))) return rc;
+    if ((rc = c.get(WS_HAE_SIGN, n, &d_sg))) return rc;
+    if (n) {
+      HIPCHK(hipMemcpyAsync(d_t, w.data(), n * 16, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(d_sg, sg.data(), n, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));                      // w, sg are locals
+    }
+  }
+  if ((rc = weighted_sum_dev<C>(c, st, BGLS_G2, (const uint8_t*)d_keys, (const uint8_t*)d_t, (const uint8_t*)d_sg, n,
+                                                   (uint8_t*)d_apk, (uint32_t*)d_fl2)))
+    return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_fl2, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if ((rc = flags_to_rc(f))) return rc;
+  return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_apk, 1, (const uint8_t*)d_msg, msg_len);
+}
+
+// VerifyAggregateSignatureWithHAE (blsHAE.go:49-53): keys scaled by their exponents, then verifyAggSig with duplicates allowed
+template <class C>
+int verify_aggregate_hae_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* blob, const uint64_t* off, size_t n) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = n ? off[n] : 0;
+  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part, *d_scaled, *d_t;
+  if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
+  if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  if ((rc = c.get(WS_HAE_KEYS, n * E::G2B, &d_scaled))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  if (n) {
+    kl::scale<C>(st, BGLS_G2, (const uint8_t*)d_keys, (const uint8_t*)d_t, nullptr, n, (uint8_t*)d_scaled, (uint32_t*)d_flags, 16);
+    HIPCHK(hipGetLastError());
+  }
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_scaled, mv, n, 0, (uint8_t*)d_part, (uint32_t*)d_flags)))
+    return rc;
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+// AggregateSignaturesWithHAE (blsHAE.go:39-46): sum_i t_i sigma_i
+template <class C>
+int aggregate_signatures_hae_t(const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void *d_sigs, *d_out, *d_flags, *d_t;
+  if ((rc = c.get(WS_IN_B, n * E::G1B, &d_sigs))) return rc;
+  if ((rc = c.get(WS_OUT, E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_sigs, sigs, n * E::G1B, hipMemcpyHostToDevice, st));
+  if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
+  if ((rc = weighted_sum_dev<C>(c, st, BGLS_G1, (const uint8_t*)d_sigs, (const uint8_t*)d_t, nullptr, n, (uint8_t*)d_out,
+                                                   (uint32_t*)d_flags)))
+    return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+// Marshal / Unmarshal* compressed branch over a batch (alt-bn128 only: BLS12-381's compressed layout belongs to the
+// un-vendored dis2/bls12 and is unpinned, curves/bls12_381.go:55,60,116,121)
+int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (curve != BGLS_CURVE_ALTBN128) return fail(BGLS_ERR_ARG, "compressed point formats are defined for alt-bn128 only");
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t CB = group == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  const size_t in_b = compress ? UB : CB, out_b = compress ? CB : UB;
+  void *d_in, *d_out, *d_ok, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * in_b, &d_in))) return rc;
+  if ((rc = c.get(WS_IN_A, n * out_b, &d_out))) return rc;
+  if ((rc = c.get(WS_IN_D, n, &d_ok))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, in, n * in_b, hipMemcpyHostToDevice, st));
+  {
+    Scope sc(c, st, ST_SUM);
+    if (compress) {
+      kl::compress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+    } else {
+      kl::decompress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * out_b, hipMemcpyDeviceToHost, st));
+  if (!compress) HIPCHK(hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c.collect();
+  return flags_to_rc(f);
+}
+
+// LoadPublicKey over a batch (bgls/bgls.go:40-43): out[i] = sk_i * g2 (group = BGLS_G2) or sk_i * g1
+template <class C>
+int scale_generator_t(int group, const uint8_t* sks, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_sc, *d_out;
+  if ((rc = c.get(WS_IN_C, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_IN_A, n * PB, &d_out))) return rc;
+  HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
+  kl::scale_aff<C>(st, group, nullptr, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// Sign over a batch (bgls/bgls.go:46-56): out[i] = sk_i * HashToG1(msg_i); the hash points never leave the device
+template <class C>
+int sign_batch_t(const uint8_t* sks, const uint8_t* blob, const uint64_t* off, size_t n, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  const size_t blob_len = off[n];
+  void *d_blob, *d_off, *d_g1s, *d_out, *d_flags, *d_sc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_G1S, n * sizeof(Aff<F1<C>>), &d_g1s))) return rc;
+  if ((rc = c.get(WS_IN_A, n * E::G1B, &d_out))) return rc;
+  if ((rc = c.get(WS_IN_B, n * 32, &d_sc))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  if ((rc = E::hash_to_g1(c, st, mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags))) return rc;
+  kl::scale_aff<C>(st, BGLS_G1, (const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, n * E::G1B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+int bgls_abi_version(void) { return 1; }
+
+const char* bgls_last_error(void) { return g_err.c_str(); }
+
+int bgls_init(int device) {
+  if (device < 0 || device >= MAX_DEVICES) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
+  g_default_device.store(device);
+  g_dev = -1;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  return c.enter();
+}
+
+size_t bgls_fp_size(int curve) { return curve == BGLS_CURVE_ALTBN128 ? 32 : curve == BGLS_CURVE_BLS12_381 ? 48 : 0; }
+size_t bgls_g1_size(int curve) { return 2 * bgls_fp_size(curve); }
+size_t bgls_g2_size(int curve) { return 4 * bgls_fp_size(curve); }
+size_t bgls_gt_size(int curve) { return 12 * bgls_fp_size(curve); }
+
+int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                          size_t n, int allow_duplicates) {
+  if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_aggregate_t<CV>(sig, keys, msg_blob, msg_off, n, allow_duplicates));
+}
+
+int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
+}
+
+int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+  if (!gt_out || (n && (!g1s || !g2s))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, pairing_product_t<CV>(g1s, g2s, n, gt_out));
+}
+
+int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out) {
+  if (n && (!msg_off || !g1_out)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, hash_to_g1_t<CV>(msg_blob, msg_off, n, g1_out));
+}
+
+int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (!group_ok(group) || !out || (n && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, aggregate_points_t<CV>(group, pts, n, out));
+}
+
+int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
+                      uint8_t* out) {
+  if (!group_ok(group) || (n && (!pts || !scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, scale_points_t<CV>(group, pts, scalars, signs, n, out));
+}
+
+int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (!group_ok(group) || !a || !b || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  size_t pb = group == BGLS_G1 ? bgls_g1_size(curve) : bgls_g2_size(curve);
+  if (!pb) return fail(BGLS_ERR_ARG, "unknown curve id");
+  std::vector<uint8_t> two(2 * pb);
+  memcpy(two.data(), a, pb);
+  memcpy(two.data() + pb, b, pb);
+  return bgls_aggregate_points(curve, group, two.data(), 2, out);
+}
+
+int bgls_point_check(int curve, int group, const uint8_t* a) {
+  if (!group_ok(group) || !a) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, point_check_t<CV>(group, a));
+}
+
+int bgls_generator(int curve, int group, uint8_t* out) {
+  if (!group_ok(group) || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, generator_t<CV>(group, out));
+}
+
+int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out) {
+  return bgls_pairing_product(curve, g1, g2, 1, gt_out);
+}
+
+int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (!a || !b || !out) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, gt_mul_t<CV>(a, b, out));
+}
+
+int bgls_gt_identity(int curve, uint8_t* out) {
+  size_t n = bgls_gt_size(curve);
+  if (!n || !out) return fail(BGLS_ERR_ARG, "unknown curve id or NULL argument");
+  memset(out, 0, n);
+  out[n - 1] = 1;
+  return 0;
+}
+
+int bgls_profile_enable(int on) {
+  Ctx* all = ctx_pool();
+  for (int k = 0; k < MAX_DEVICES * NCTX; ++k) {
+    Ctx& c = all[k];
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.prof = on != 0;
+    for (int i = 0; i < 8; ++i) { c.stage_ms[i] = 0; c.stage_cnt[i] = 0; }
+  }
+  return 0;
+}
+
+int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches) {
+  if (!stage || !total_ms || !launches) return fail(BGLS_ERR_ARG, "NULL argument");
+  for (int i = 0; i < ST_NUM; ++i)
+    if (!strcmp(stage, STAGE_NAMES[i])) {
+      *total_ms = 0;
+      *launches = 0;
+      Ctx* all = ctx_pool();
+      for (int k = 0; k < MAX_DEVICES * NCTX; ++k) {        // summed over the contexts of every device
+        std::lock_guard<std::mutex> lk(all[k].mu);
+        *total_ms += all[k].stage_ms[i];
+        *launches += all[k].stage_cnt[i];
+      }
+      return 0;
+    }
+  return fail(BGLS_ERR_ARG, "unknown stage name");
+}
+
+int bgls_probe_mad_peak(double* mac_per_s) {
+  if (!mac_per_s) return fail(BGLS_ERR_ARG, "NULL argument");
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void* sink;
+  if ((rc = c.get(WS_OUT, 16, &sink))) return rc;
+  const int iters = 4096, blocks = 256 * 8, threads = 256;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHK(hipEventRecord(a, st));
+    kl::mad_probe(st, blocks, threads, 12345u + rep, iters, (uint64_t*)sink);
+    HIPCHK(hipEventRecord(b, st));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    double macs = (double)blocks * threads * iters * 16.0;
+    double rate = macs / (ms * 1e-3);
+    if (rep > 0 && rate > best) best = rate;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *mac_per_s = best;
+  return 0;
+}
+
+int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len,
+                            size_t msg_stride, size_t n, int check_duplicates, void* d_partial_out, void* d_flags,
+                            void* stream) {
+  if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
+                                           d_flags, stream));
+}
+
+int bgls_set_throughput_mode(int on) {
+  g_throughput.store(on ? 1 : 0);
+  return 0;
+}
+
+int bgls_select_context(int index) {
+  if (index < 0 || index >= NCTX) return fail(BGLS_ERR_ARG, "context index out of range");
+  g_sel = index;
+  return 0;
+}
+
+int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, final_verify_submit_dev_t<CV>(d_partials, count, d_flags, stream));
+}
+
+int bgls_final_verify_collect(int curve) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  DISPATCH(curve, Engine<CV>::finalize_collect(c));
+}
+
+int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+  if (!d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (n >= (1ull << 30)) return fail(BGLS_ERR_ARG, "too many messages for one scan");
+  return duplicate_scan_dev(d_msgs, msg_len, msg_stride, n, d_flags, stream);
+}
+
+int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+  if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, final_verify_dev_t<CV>(d_partials, count, d_flags, stream));
+}
+
+int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+  if (!group_ok(group) || !d_out || (n && !d_pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, aggregate_points_dev_t<CV>(group, d_pts, n, d_out, stream));
+}
+
+int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
+                          void* stream) {
+  if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
+}
+
+int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
+                                 void* stream) {
+  if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream, true));
+}
+
+/* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */
+int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out) {
+  if (n && (!keys || !t_out)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, hae_exponents_t<CV>(keys, n, t_out));
+}
+
+int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+  if (!out || (n && (!sigs || !keys))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, aggregate_signatures_hae_t<CV>(sigs, keys, n, out));
+}
+
+int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, nullptr, n, msg, msg_len));
+}
+
+int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                              size_t n) {
+  if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_aggregate_hae_t<CV>(sig, keys, msg_blob, msg_off, n));
+}
+
+int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity, size_t n,
+                                   const uint8_t* msg, size_t msg_len) {
+  if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (!multiplicity) DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
+  DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, multiplicity, n, msg, msg_len));
+}
+
+/* ---- compressed wire formats (alt-bn128; curves/altbn128.go:81-89,203-221,296-376) ---- */
+int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (!group_ok(group) || (n && (!pts || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  return wire_points(curve, group, true, pts, n, out, nullptr);
+}
+
+int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (!group_ok(group) || (n && (!in || !out || !ok))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  return wire_points(curve, group, false, in, n, out, ok);
+}
+
+/* ---- batch key generation / signing (bgls/bgls.go:40-56) ---- */
+int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (!group_ok(group) || (n && (!scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, scale_generator_t<CV>(group, scalars, n, out));
+}
+
+int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* sigs_out) {
+  if (!msg_off || (n && (!sks || !sigs_out))) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, sign_batch_t<CV>(sks, msg_blob, msg_off, n, sigs_out));
+}
+
+}  // extern "C"
+
+

@@ -1,0 +1,269 @@
+// Hashing kernels: duplicate-message scan and hash-to-G1 for both curves (see h2c.hpp for the algorithms and
+// their reference citations), plus the BLAKE2Xb expansion of the hashed-aggregation exponents.
+#include "dev_common.hpp"
+#include "h2c.hpp"
+#include "launch.hpp"
+
+using namespace bgls;
+
+// ---- duplicate-message scan: open-addressing table of (index+1), exact byte comparison ----
+// ---- duplicate-message scan: open-addressing table of (index+1), exact byte comparison ----
+__device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= p[i];
+    h *= 0x100000001b3ull;
+  }
+  h ^= h >> 29;
+  h *= 0xbf58476d1ce4e5b9ull;
+  h ^= h >> 32;
+  return h;
+}
+
+__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m = mv.ptr(i);
+  const size_t len = mv.size(i);
+  uint32_t slot = (uint32_t)msg_hash64(m, len) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t prev = atomicCAS(&table[slot], 0u, (uint32_t)i + 1u);
+    if (prev == 0u) return;
+    size_t j = prev - 1u;
+    if (mv.size(j) == len) {
+      const uint8_t* o = mv.ptr(j);
+      bool same = true;
+      for (size_t k = 0; k < len; ++k)
+        if (o[k] != m[k]) {
+          same = false;
+          break;
+        }
+      if (same) {
+        atomicOr(flags, FLAG_DUP);
+        return;
+      }
+    }
+    slot = (slot + 1u) & mask;
+  }
+}
+
+// alt-bn128 try-and-increment as compacting rounds (curves/hash.go:53-77 has data-dependent trip
+// counts: geometric(1/2) per message, so a per-lane loop idles most of the wave).  Round r tests
+// LPM consecutive counters of every still-unfinished message on LPM adjacent lanes; the LOWEST
+// successful counter wins (= what the sequential loop would have found), failures are appended to
+// the next round's work list.  Counters 0..255 are covered by the fixed schedule in h2c_bn().
+template <int LPM>
+__global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const uint32_t* list_in, const uint32_t* count_in,
+                                                     uint32_t c0, uint32_t* list_out, uint32_t* count_out, int last,
+                                                     Aff<F1<BN254>>* out, uint32_t* flags) {
+  typedef BN254 C;
+  const size_t count = count_in ? (size_t)*count_in : n;
+  const size_t slots = (count * LPM + 63) / 64 * 64;
+  const int lane = threadIdx.x;
+  for (size_t slot = (size_t)blockIdx.x * 64 + lane; slot < slots; slot += (size_t)gridDim.x * 64) {
+    const size_t item = slot / LPM;
+    const uint32_t sub = (uint32_t)(slot % LPM);
+    const uint32_t c = c0 + sub;
+    const bool active = item < count && c < 256;
+    size_t idx = 0;
+    Fp<C> x, r;
+    bool ok = false;
+    if (item < count) idx = list_in ? list_in[item] : item;
+    if (active) ok = bn_h2c_test(mv.ptr(idx), mv.size(idx), c, x, r);
+    const unsigned long long ball = __ballot(ok);
+    const int seg = (lane / LPM) * LPM;
+    const unsigned long long segmask = LPM == 64 ? ball : ((ball >> seg) & ((1ull << (LPM & 63)) - 1ull));
+    if (item < count) {
+      if (segmask == 0) {
+        if (sub == 0) {
+          if (last) {
+            atomicOr(flags, FLAG_HASH);
+            out[idx] = {fp_zero<C>(), fp_zero<C>(), true};
+          } else {
+            list_out[atomicAdd(count_out, 1u)] = (uint32_t)idx;
+          }
+        }
+      } else if (sub == (uint32_t)__builtin_ctzll(segmask)) {
+        out[idx] = {x, r, false};             // r holds x^3+3, k_h2c_bn_finish takes the root
+      }
+    }
+  }
+}
+
+// second half of the Legendre-symbol rounds: y = sqrt(x^3+3) with the reference's sign rule, once per message
+__global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<F1<BN254>>* out) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p = out[i];
+  if (p.inf) return;
+  Fp<C> r = fp_sqrt_candidate<C>(p.y);
+  if (bn_h2c_sign(mv.ptr(i), mv.size(i))) r = fp_neg<C>(r);
+  out[i].y = r;
+}
+
+// alt-bn128 try-and-increment with the acceptance test done by the Legendre symbol (fp_jacobi): the lane
+// walks the counters with cheap tests only and pays ONE square-root exponentiation, for the accepted x.
+// Same accepted counter, same (x, y) as curves/hash.go:53-77.
+__global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* msg = mv.ptr(i);
+  const size_t len = mv.size(i);
+  Fp<C> x, y2;
+  bool found = false;
+  for (u32 c = 0; c < 256 && !found; ++c) {
+    ByteSrc src;
+    src.msg = msg; src.len = len; src.pre[0] = (uint8_t)c; src.npre = 1; src.nsuf = 0;
+    u32 d[8];
+    keccak256_legacy(src, d);
+    Fp<C> h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
+    x = fp_to_mont<C>(h);
+    y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), fp_load<C>(C::B));
+    found = fp_jacobi<C>(y2) >= 0;
+  }
+  if (!found) {
+    atomicOr(flags, FLAG_HASH);
+    out[i] = {fp_zero<C>(), fp_zero<C>(), true};
+    return;
+  }
+  Fp<C> r = fp_sqrt_candidate<C>(y2);
+  if (bn_h2c_sign(msg, len)) r = fp_neg<C>(r);
+  out[i] = {x, r, false};
+}
+
+// BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
+// curves/hash.go:254-265), then exactly one square-root exponentiation.
+__global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items, Aff<F1<BLS381>>* pts, uint32_t* kinds) {
+  typedef BLS381 C;
+  size_t item = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const size_t msg = item >> 1;
+  Fp<C> tm;
+  Fp<C> t = bls_h2c_t(mv.ptr(msg), mv.size(msg), (int)(item & 1), tm);
+  uint32_t kind = H2C_SW;
+  if (fp_is_zero<C>(t)) kind = H2C_INF;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) kind = H2C_PLUS_G1;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) kind = H2C_MINUS_G1;
+  kinds[item] = kind;
+  if (kind != H2C_SW) return;
+  BlsSwPrep pr = bls_sw_prep(tm);
+  const Fp<C> b = fp_load<C>(C::B);
+  Fp<C> x = pr.x0;
+  Fp<C> g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+  if (fp_jacobi<C>(g) < 0) {
+    x = fp_sub<C>(fp_neg<C>(pr.x0), fp_one<C>());
+    g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+    if (fp_jacobi<C>(g) < 0) {
+      x = pr.x2;
+      g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+    }
+  }
+  Fp<C> y = fp_sqrt_candidate<C>(g);
+  if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
+  pts[item] = {x, y, false};
+}
+
+// per message: h * (sw_0 + sw_1) + special contributions, to affine.  The sum is normalised once (one
+// Euclidean inversion) so that the 126-bit cofactor multiplication runs on a signed-digit (NAF) chain with
+// mixed additions: 125 doublings + 42 additions of 11 field products instead of 63 of 16.
+//
+// RAW = true is the verification path's form: the cofactor is NOT cleared here.  The reduced ate pairing is
+// bilinear in its first argument on all of E(Fp), e(h S, Q) = e(S, Q)^h, so the whole batch shares ONE
+// exponentiation by h in GT (k_cofactor_epilogue) instead of n 126-bit scalar multiplications; the rare
+// "+-generator" outcomes enter as +-G1K, G1K = (h^-1 mod r) g1.
+template <bool RAW>
+__global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+  typedef BLS381 C;
+  typedef F1<C> F;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac<F> sw = jac_inf<F>(), special = jac_inf<F>();
+  const Aff<F> g1 = {fp_load<C>(RAW ? C::G1KX : C::G1X), fp_load<C>(RAW ? C::G1KY : C::G1Y), false};
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t kind = kinds[2 * i + k];
+    if (kind == H2C_SW) sw = jac_add_aff<F>(sw, pts[2 * i + k]);
+    else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
+    else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
+  }
+  if constexpr (RAW) {
+    out[i] = jac_to_aff<F>(jac_add<F>(sw, special));
+    return;
+  }
+  const Aff<F> S = jac_to_aff<F>(sw);
+  const Aff<F> nS = aff_neg<F>(S);
+  Jac<F> r = jac_inf<F>();
+  for (int d = 0; d < C::COFACTOR_NAF_LEN; ++d) {
+    r = jac_dbl<F>(r);
+    const int dig = C::COFACTOR_NAF[d];
+    if (dig != 0) r = jac_add_aff<F>(r, dig > 0 ? S : nS);
+  }
+  out[i] = jac_to_aff<F>(jac_add<F>(r, special));
+}
+
+// ---- BLAKE2Xb expansion (bgls/blsHAE.go:80-93): node i of the XOF is one compression of the 64-byte root with its
+// own parameter block (hashes.hpp blake2xb_node); one lane per node.  The root is produced on the host side.
+__global__ void __launch_bounds__(64) k_blake2x_expand(const u64* root, u32 xof_len, uint8_t* out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nnodes = (xof_len + 63u) / 64u;
+  if (i >= nnodes) return;
+  u64 r[8], o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = root[k];
+  const u32 rest = xof_len - 64u * i;
+  const u32 take = rest < 64u ? rest : 64u;
+  blake2xb_node(r, i, xof_len, take, o);
+  for (u32 b = 0; b < take; ++b) out[(size_t)64 * i + b] = (uint8_t)(o[b >> 3] >> (8 * (b & 7)));
+}
+
+// ======================================================================= launchers
+namespace bgls {
+namespace kl {
+
+void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
+  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags);
+}
+
+// alt-bn128: (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.  Each
+// round costs one try of latency, so the schedule is short: after three rounds a message is still unfinished with
+// probability 2^-37.  Acceptance test = Legendre symbol, square root once at the end (k_h2c_bn_finish).
+void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn, Aff<F1<BN254>>* out, uint32_t* flags) {
+  if (n < 256) {
+    k_h2c_bn_jacobi<<<nblk(n, 64), 64, 0, st>>>(mv, n, out, flags);
+    return;
+  }
+  uint32_t* L0 = lists;
+  uint32_t* L1 = L0 + n;
+  auto grid = [&](double expect_items, int lpm) {
+    double lanes = expect_items * lpm * 2.0 + 512.0;
+    size_t b = (size_t)(lanes / 64.0) + 1;
+    return (unsigned)(b > 8192 ? 8192 : b);
+  };
+  const double N = (double)n;
+  k_h2c_bn_round<1><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, flags);
+  k_h2c_bn_round<4><<<grid(N / 2, 4), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, flags);
+  k_h2c_bn_round<32><<<grid(N / 32, 32), 64, 0, st>>>(mv, n, L1, cn + 2, 5, L0, cn + 3, 0, out, flags);
+  k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 3, 37, L1, cn + 4, 0, out, flags);
+  k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 4, 101, L0, cn + 5, 0, out, flags);
+  k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L0, cn + 5, 165, L1, cn + 6, 0, out, flags);
+  k_h2c_bn_round<64><<<8, 64, 0, st>>>(mv, n, L1, cn + 6, 229, L0, cn + 7, 1, out, flags);
+  k_h2c_bn_finish<<<nblk(n, 64), 64, 0, st>>>(mv, n, out);
+}
+
+// BLS12-381: pts / kinds hold 2n work items (message, tag); raw = uncleared sum (verification path, cofactor in GT)
+void h2c_bls(hipStream_t st, MsgView mv, size_t n, Aff<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw) {
+  const size_t items = 2 * n;
+  k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, pts, kinds);
+  if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+}
+
+void blake2x_expand(hipStream_t st, const uint64_t* root, uint32_t xof_len, uint8_t* out) {
+  k_blake2x_expand<<<nblk((xof_len + 63) / 64, 64), 64, 0, st>>>((const u64*)root, xof_len, out);
+}
+
+}  // namespace kl
+}  // namespace bgls

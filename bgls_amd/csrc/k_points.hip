@@ -1,0 +1,345 @@
+// Point kernels: parsing / serialisation, AggregatePoints, ScalePoints, compressed wire formats, weighted sums,
+// batch key generation / signing, validity checks, and the multiplier-peak probe.
+#include "dev_common.hpp"
+#include "wire.hpp"
+#include "launch.hpp"
+#include "../../include/bgls_hip.h"
+
+using namespace bgls;
+
+template <class C>
+__global__ void k_g1_to_bytes(const Aff<F1<C>>* in, size_t n, uint8_t* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_to_bytes<C>(out + i * 2 * C::FP_BYTES, in[i]);
+}
+
+// parse n G1 points (optionally negating them); bad encodings / off-curve points set FLAG_ENC
+template <class C>
+__global__ void k_g1_parse(const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p;
+  bool ok = g1_from_bytes<C>(p, in + i * 2 * C::FP_BYTES);
+  ok = ok && aff_on_curve<F1<C>>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+  if (negate) p = aff_neg<F1<C>>(p);
+  out[i] = p;
+}
+
+// ---- point sums ----
+template <class F>
+__device__ __forceinline__ bool aff_from_bytes(Aff<F>& p, const uint8_t* b);
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F1<BN254>>(Aff<F1<BN254>>& p, const uint8_t* b) { return g1_from_bytes<BN254>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F1<BLS381>>(Aff<F1<BLS381>>& p, const uint8_t* b) { return g1_from_bytes<BLS381>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F2<BN254>>(Aff<F2<BN254>>& p, const uint8_t* b) { return g2_from_bytes<BN254>(p, b); }
+template <>
+__device__ __forceinline__ bool aff_from_bytes<F2<BLS381>>(Aff<F2<BLS381>>& p, const uint8_t* b) { return g2_from_bytes<BLS381>(p, b); }
+
+template <class F>
+__device__ __forceinline__ void aff_to_bytes(uint8_t* b, const Aff<F>& p);
+template <>
+__device__ __forceinline__ void aff_to_bytes<F1<BN254>>(uint8_t* b, const Aff<F1<BN254>>& p) { g1_to_bytes<BN254>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F1<BLS381>>(uint8_t* b, const Aff<F1<BLS381>>& p) { g1_to_bytes<BLS381>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F2<BN254>>(uint8_t* b, const Aff<F2<BN254>>& p) { g2_to_bytes<BN254>(b, p); }
+template <>
+__device__ __forceinline__ void aff_to_bytes<F2<BLS381>>(uint8_t* b, const Aff<F2<BLS381>>& p) { g2_to_bytes<BLS381>(b, p); }
+
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_sum_first(const uint8_t* pts, size_t n, int R, Jac<F>* out, uint32_t* flags) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = jac_inf<F>();
+  for (size_t k = lo; k < hi; ++k) {
+    Aff<F> p;
+    bool ok = aff_from_bytes<F>(p, pts + k * PT_BYTES);
+    ok = ok && aff_on_curve<F>(p);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+    acc = jac_add_aff<F>(acc, p);
+  }
+  out[t] = acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) k_sum_next(const Jac<F>* in, size_t n, int R, Jac<F>* out) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = in[lo];
+  for (size_t k = lo + 1; k < hi; ++k) acc = jac_add<F>(acc, in[k]);
+  out[t] = acc;
+}
+
+template <class F>
+__global__ void k_jac_to_bytes(const Jac<F>* in, size_t n, uint8_t* out, int pt_bytes) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aff_to_bytes<F>(out + i * pt_bytes, jac_to_aff<F>(in[i]));
+}
+
+// ---- ScalePoints ----
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
+                                              uint8_t* out, uint32_t* flags, int sbytes = 32) {   // sbytes: 32 or 16, big-endian
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+  ok = ok && aff_on_curve<F>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+  uint8_t sg = signs ? signs[i] : 0;
+  if (sg == 2) {  // nil factor: Copy()
+    aff_to_bytes<F>(out + i * PT_BYTES, p);
+    return;
+  }
+  u32 k[8];
+  const uint8_t* s = scalars + i * (size_t)sbytes;
+  const int nw = sbytes / 4;
+  int top = -1;
+  for (int j = 0; j < 8; ++j) {
+    k[j] = 0;
+    if (j < nw) {
+      const uint8_t* q = s + 4 * (nw - 1 - j);
+      k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+  }
+  for (int j = 7; j >= 0 && top < 0; --j)
+    if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+  if (sg == 1) p = aff_neg<F>(p);
+  Jac<F> r = jac_mul<F>(p, k, top + 1);
+  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(r));
+}
+
+// ---- compressed wire formats of alt-bn128 (wire.hpp; curves/altbn128.go:81-89,203-221,296-376) ----
+// GROUP 1: 64-byte points <-> 32-byte forms; GROUP 2: 128 <-> 64.  One point per thread: the decoders are one
+// (G1) or two (G2) square-root exponentiations plus a Legendre symbol and an inversion, i.e. about the cost of hashing
+// one message; ok[i] = 1 / 0 mirrors the reference's (Point, bool).
+template <int GROUP>
+__global__ void __launch_bounds__(64) k_decompress_bn(const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CB = GROUP == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  bool good;
+  if constexpr (GROUP == BGLS_G1) {
+    Aff<F1<C>> p;
+    good = g1_decompress<C>(p, in + i * CB);
+    if (good) g1_to_bytes<C>(out + i * UB, p);
+  } else {
+    Aff<F2<C>> p;
+    good = g2_decompress<C>(p, in + i * CB);
+    if (good) g2_to_bytes<C>(out + i * UB, p);
+  }
+  if (!good)
+    for (int k = 0; k < UB; ++k) out[i * UB + k] = 0;
+  ok[i] = good ? 1 : 0;
+}
+
+template <int GROUP>
+__global__ void __launch_bounds__(64) k_compress_bn(const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags) {
+  typedef BN254 C;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CB = GROUP == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  if constexpr (GROUP == BGLS_G1) {
+    Aff<F1<C>> p;
+    bool good = g1_from_bytes<C>(p, in + i * UB) && aff_on_curve<F1<C>>(p);
+    if (!good) atomicOr(flags, FLAG_ENC);
+    g1_compress<C>(out + i * CB, p);
+  } else {
+    Aff<F2<C>> p;
+    bool good = g2_from_bytes<C>(p, in + i * UB) && aff_on_curve<F2<C>>(p);
+    if (!good) atomicOr(flags, FLAG_ENC);
+    g2_compress<C>(out + i * CB, p);
+  }
+}
+
+// ---- weighted key sums (hashed aggregation exponents, bgls/blsHAE.go; multiplicities, bgls/blsKosk.go:137-150) ----
+// First pass of sum_i k_i P_i: getAggregatePubKey (blsHAE.go:74-77) = AggregatePoints(ScalePoints(keys, t)) without
+// materialising the scaled points: thread t accumulates its R products in Jacobian form.  Weights are 16-byte
+// big-endian magnitudes with optional sign bytes (1 = negate the point first, curves/curve.go:190-214).
+template <class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_wsum_first(const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, int R,
+                                                   Jac<F>* out, uint32_t* flags) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t lo = t * (size_t)R;
+  if (lo >= n) return;
+  size_t hi = lo + R < n ? lo + R : n;
+  Jac<F> acc = jac_inf<F>();
+  for (size_t i = lo; i < hi; ++i) {
+    Aff<F> p;
+    bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+    ok = ok && aff_on_curve<F>(p);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+    u32 k[4];
+    int top = -1;
+    for (int j = 0; j < 4; ++j) {
+      const uint8_t* q = w16 + i * 16 + 4 * (3 - j);
+      k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    for (int j = 3; j >= 0 && top < 0; --j)
+      if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+    if (signs && signs[i] == 1) p = aff_neg<F>(p);
+    acc = jac_add<F>(acc, jac_mul<F>(p, k, top + 1));
+  }
+  out[t] = acc;
+}
+
+// ---- batch key generation / signing ----
+// out[i] = k_i * P_i with P_i taken from a device array of affine points (the hash-to-G1 output: Sign, bgls/bgls.go:46-56)
+// or, when pts == nullptr, the group generator (LoadPublicKey, bgls/bgls.go:40-43: GetG2().Mul(sk)).  Scalars are 32-byte
+// big-endian, as everywhere at the seam.
+template <class C, class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_scale_aff(const Aff<F>* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  if (pts) {
+    p = pts[i];
+  } else {
+    if constexpr (PT_BYTES == 2 * C::FP_BYTES) p = Aff<F>{fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+    else p = Aff<F>{f2_load<C>(C::G2), f2_load<C>(C::G2 + 2 * C::L), false};
+  }
+  u32 k[8];
+  int top = -1;
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = scalars + i * 32 + 4 * (7 - j);
+    k[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  for (int j = 7; j >= 0 && top < 0; --j)
+    if (k[j]) top = j * 32 + (31 - __clz(k[j]));
+  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul<F>(p, k, top + 1)));
+}
+
+template <class F, int PT_BYTES>
+__global__ void k_check(const uint8_t* pts, size_t n, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p;
+  bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
+  ok = ok && aff_on_curve<F>(p);
+  if (!ok) atomicOr(flags, FLAG_ENC);
+}
+
+template <class C>
+__global__ void k_generator(int group, uint8_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (group == BGLS_G1) {
+    Aff<F1<C>> g = {fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+    g1_to_bytes<C>(out, g);
+  } else {
+    Aff<F2<C>> g = {f2_load<C>(C::G2), f2_load<C>(C::G2 + 2 * C::L), false};
+    g2_to_bytes<C>(out, g);
+  }
+}
+
+// ---- peak probe: dependent-free v_mad_u64_u32 chains (roofline denominator) ----
+__global__ void __launch_bounds__(256) k_mad_probe(uint32_t seed, int iters, uint64_t* sink) {
+  uint32_t a = seed ^ (threadIdx.x * 2654435761u), b = seed + blockIdx.x * 40503u + 1u;
+  uint64_t acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = (uint64_t)j * 0x9e3779b97f4a7c15ull + a;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (uint64_t)(uint32_t)(a + j) * (uint32_t)(b + it) + acc[j];
+  }
+  uint64_t x = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) x ^= acc[j];
+  if (x == 0x1234567ull) sink[0] = x;
+}
+
+// ======================================================================= launchers
+namespace bgls {
+namespace kl {
+
+template <class C>
+void g1_to_bytes(hipStream_t st, const Aff<F1<C>>* in, size_t n, uint8_t* out) {
+  k_g1_to_bytes<C><<<nblk(n, 64), 64, 0, st>>>(in, n, out);
+}
+template <class C>
+void g1_parse(hipStream_t st, const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags) {
+  k_g1_parse<C><<<nblk(n, 64), 64, 0, st>>>(in, n, negate, out, flags);
+}
+
+template <class C>
+void sum_first(hipStream_t st, int group, const uint8_t* pts, size_t n, int R, void* out, uint32_t* flags) {
+  const size_t n1 = (n + R - 1) / R;
+  if (group == BGLS_G1) k_sum_first<F1<C>, 2 * C::FP_BYTES><<<nblk(n1, 64), 64, 0, st>>>(pts, n, R, (Jac<F1<C>>*)out, flags);
+  else k_sum_first<F2<C>, 4 * C::FP_BYTES><<<nblk(n1, 64), 64, 0, st>>>(pts, n, R, (Jac<F2<C>>*)out, flags);
+}
+template <class C>
+void sum_next(hipStream_t st, int group, const void* in, size_t n, int R, void* out) {
+  const size_t nout = (n + R - 1) / R;
+  if (group == BGLS_G1) k_sum_next<F1<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, R, (Jac<F1<C>>*)out);
+  else k_sum_next<F2<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, R, (Jac<F2<C>>*)out);
+}
+template <class C>
+void jac_to_bytes(hipStream_t st, int group, const void* in, size_t n, uint8_t* out) {
+  if (group == BGLS_G1) k_jac_to_bytes<F1<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, out, 2 * C::FP_BYTES);
+  else k_jac_to_bytes<F2<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, out, 4 * C::FP_BYTES);
+}
+template <class C>
+void wsum_first(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, void* out,
+                uint32_t* flags) {
+  if (group == BGLS_G1) k_wsum_first<F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, w16, signs, n, 1, (Jac<F1<C>>*)out, flags);
+  else k_wsum_first<F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, w16, signs, n, 1, (Jac<F2<C>>*)out, flags);
+}
+template <class C>
+void scale(hipStream_t st, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out,
+           uint32_t* flags, int sbytes) {
+  if (group == BGLS_G1) k_scale<F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, scalars, signs, n, out, flags, sbytes);
+  else k_scale<F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, scalars, signs, n, out, flags, sbytes);
+}
+template <class C>
+void scale_aff(hipStream_t st, int group, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (group == BGLS_G1) k_scale_aff<C, F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(g1_pts, scalars, n, out);
+  else k_scale_aff<C, F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(nullptr, scalars, n, out);
+}
+template <class C>
+void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags) {
+  if (group == BGLS_G1) k_check<F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags);
+  else k_check<F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags);
+}
+template <class C>
+void generator(hipStream_t st, int group, uint8_t* out) {
+  k_generator<C><<<1, 64, 0, st>>>(group, out);
+}
+
+void compress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags) {
+  if (group == BGLS_G1) k_compress_bn<BGLS_G1><<<nblk(n, 64), 64, 0, st>>>(in, n, out, flags);
+  else k_compress_bn<BGLS_G2><<<nblk(n, 64), 64, 0, st>>>(in, n, out, flags);
+}
+void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (group == BGLS_G1) k_decompress_bn<BGLS_G1><<<nblk(n, 64), 64, 0, st>>>(in, n, out, ok);
+  else k_decompress_bn<BGLS_G2><<<nblk(n, 64), 64, 0, st>>>(in, n, out, ok);
+}
+void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed, int iters, uint64_t* sink) {
+  k_mad_probe<<<blocks, threads, 0, st>>>(seed, iters, sink);
+}
+
+#define BGLS_INST(C)                                                                                                             \
+  template void g1_to_bytes<C>(hipStream_t, const Aff<F1<C>>*, size_t, uint8_t*);                                                \
+  template void g1_parse<C>(hipStream_t, const uint8_t*, size_t, int, Aff<F1<C>>*, uint32_t*);                                   \
+  template void sum_first<C>(hipStream_t, int, const uint8_t*, size_t, int, void*, uint32_t*);                                   \
+  template void sum_next<C>(hipStream_t, int, const void*, size_t, int, void*);                                                  \
+  template void jac_to_bytes<C>(hipStream_t, int, const void*, size_t, uint8_t*);                                                \
+  template void wsum_first<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, void*, uint32_t*);       \
+  template void scale<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint32_t*, int);    \
+  template void scale_aff<C>(hipStream_t, int, const Aff<F1<C>>*, const uint8_t*, size_t, uint8_t*);                             \
+  template void check<C>(hipStream_t, int, const uint8_t*, size_t, uint32_t*);                                                   \
+  template void generator<C>(hipStream_t, int, uint8_t*);
+BGLS_INST(BN254)
+BGLS_INST(BLS381)
+#undef BGLS_INST
+
+}  // namespace kl
+}  // namespace bgls

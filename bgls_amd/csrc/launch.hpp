@@ -1,0 +1,48 @@
+// Host-callable launchers of every kernel in the library.  Each k_*.hip translation unit defines the launchers of the
+// kernels it holds (a <<<>>> launch must sit in the unit that defines the kernel; the units are compiled in parallel and
+// linked without relocatable device code); engine.hip only sees these declarations.
+#pragma once
+#include "dev_common.hpp"
+
+namespace bgls {
+namespace kl {
+
+// ---- k_hash.hip
+void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags);
+void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* counters, Aff<F1<BN254>>* out, uint32_t* flags);
+void h2c_bls(hipStream_t st, MsgView mv, size_t n, Aff<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw);
+void blake2x_expand(hipStream_t st, const uint64_t* root, uint32_t xof_len, uint8_t* out);
+
+// ---- k_points.hip   (group = BGLS_G1 / BGLS_G2; Jacobian workspaces are passed as void*)
+template <class C> void g1_to_bytes(hipStream_t st, const Aff<F1<C>>* in, size_t n, uint8_t* out);
+template <class C> void g1_parse(hipStream_t st, const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags);
+template <class C> void sum_first(hipStream_t st, int group, const uint8_t* pts, size_t n, int R, void* out, uint32_t* flags);
+template <class C> void sum_next(hipStream_t st, int group, const void* in, size_t n, int R, void* out);
+template <class C> void jac_to_bytes(hipStream_t st, int group, const void* in, size_t n, uint8_t* out);
+template <class C> void wsum_first(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, void* out, uint32_t* flags);
+template <class C> void scale(hipStream_t st, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out, uint32_t* flags, int sbytes);
+template <class C> void scale_aff(hipStream_t st, int group, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out);
+template <class C> void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags);
+template <class C> void generator(hipStream_t st, int group, uint8_t* out);
+void compress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags);
+void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);
+void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed, int iters, uint64_t* sink);
+template <class C> size_t jac_bytes(int group) { return (size_t)3 * (group == 1 ? 1 : 2) * C::L * 4; }
+
+// ---- k_miller_bn.hip / k_miller_bls.hip   (dbg != 0 only in -DBGLS_DEV builds: timing variants, wrong results)
+template <class C>
+void miller_ab64(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                 const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, int dbg);
+template <class C>
+void miller_s60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags,
+                int dbg);
+
+// ---- k_tail_bn.hip / k_tail_bls.hip
+template <class C> void gen_lines(hipStream_t st, LineCoeffs<C>* table, int* nsteps);
+template <class C> void reduce_coop(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out);
+template <class C> void w_to_bytes(hipStream_t st, const Fp2<C>* in, uint8_t* out);
+template <class C> void final36(hipStream_t st, const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict, uint32_t* flags);
+template <class C> void cofactor_epilogue(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, uint8_t* out);
+
+}  // namespace kl
+}  // namespace bgls
