@@ -139,7 +139,7 @@ def bench_multisig(args, lib, cid, fp, n, dev, rank, world):
         raise RuntimeError("multisig correctness gate failed")
     # L verifications in flight (own context and stream each): the key sum of one overlaps the serial hash / pairing /
     # final-exponentiation tail of the others; every step is a complete verification whose verdict is checked
-    L = max(1, min(8, args.in_flight))
+    L = max(1, min(16, args.in_flight))
     lanes = [torch.cuda.Stream(device=dev) for _ in range(L)]
     torch.cuda.synchronize()
 
@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="keep the 64-pairing Miller kernel also when launches overlap")
     ap.add_argument("--in-flight", type=int, default=None,
-                    help="verifications kept in flight (1 = strictly sequential, max 8); default 4, multisig workload 8")
+                    help="verifications kept in flight (1 = strictly sequential, max 16); default 4, multisig workload 8")
     ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae", "decompress"],
                     help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
     args = ap.parse_args()
@@ -358,7 +358,7 @@ def main():
     # L verifications in flight on L library contexts / streams (default 4): every step is still one complete pass (duplicate
     # scan, hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound
     # stages of one step overlap the Miller launch of its neighbours.  --in-flight 1 runs them strictly one after the other.
-    L = max(1, min(8, args.in_flight))
+    L = max(1, min(16, args.in_flight))
     lanes = [{"stream": torch.cuda.Stream(device=dev), "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
               "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for _ in range(L)]
     torch.cuda.synchronize()

@@ -23,6 +23,8 @@ struct F1 {  // coordinate field of G1
   static BGLS_HD T dbl(const T& a) { return fp_dbl<C>(a); }
   static BGLS_HD T mul(const T& a, const T& b) { return fp_mul<C>(a, b); }
   static BGLS_HD T sqr(const T& a) { return fp_sqr<C>(a); }
+  static BGLS_HD T mul_inl(const T& a, const T& b) { return fp_mul_inl<C>(a, b); }      // expanded in place (hot loops)
+  static BGLS_HD T sqr_inl(const T& a) { return fp_sqr_inl<C>(a); }
   static BGLS_HD T inv(const T& a) { return fp_inv<C>(a); }
   static BGLS_HD bool is_zero(const T& a) { return fp_is_zero<C>(a); }
   static BGLS_HD bool eq(const T& a, const T& b) { return fp_eq<C>(a, b); }
@@ -42,6 +44,8 @@ struct F2 {  // coordinate field of G2 (the twist)
   static BGLS_HD T dbl(const T& a) { return f2_dbl<C>(a); }
   static BGLS_HD T mul(const T& a, const T& b) { return f2_mul<C>(a, b); }
   static BGLS_HD T sqr(const T& a) { return f2_sqr<C>(a); }
+  static BGLS_HD T mul_inl(const T& a, const T& b) { return f2_mul_inl<C>(a, b); }
+  static BGLS_HD T sqr_inl(const T& a) { return f2_sqr_inl<C>(a); }
   static BGLS_HD T inv(const T& a) { return f2_inv<C>(a); }
   static BGLS_HD bool is_zero(const T& a) { return f2_is_zero<C>(a); }
   static BGLS_HD bool eq(const T& a, const T& b) { return f2_eq<C>(a, b); }

@@ -122,7 +122,7 @@ struct Ctx {
 // let one thread keep several verifications in flight, so the serial, latency-bound stages of one (hashing rounds,
 // reduction tail, final exponentiation) overlap the Miller launch of another; contexts of different devices are what
 // the multi-GPU entry points drive from their worker threads.
-constexpr int NCTX = 8;
+constexpr int NCTX = 16;
 constexpr int MAX_DEVICES = 16;
 std::atomic<int> g_default_device{0};
 thread_local int g_sel = 0;
@@ -164,6 +164,11 @@ bool throughput_mode() {
   }
   return v == 1;
 }
+
+// Miller shape (bgls_set_miller_shape): 0 = fused producer/consumer blocks (k_miller_ab64 / k_miller_s60), 1..3 = decoupled
+// k_lines + k_fold through a line table in HBM (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs with Karatsuba dot
+// products; alt-bn128 only for 2 and 3), ng = pairings folded per group and squaring.
+std::atomic<int> g_shape{0}, g_ng{6};
 
 #ifdef BGLS_DEV
 // development builds only: BGLS_MILLER_DBG=1/2 times the producer / consumer half of the fused Miller kernels (WRONG results)
@@ -311,6 +316,34 @@ struct Engine {
     void *pa, *pb;
     Fp2<C>* red = nullptr;
     bool epilogue = cofactor;
+    if (g_shape.load() > 0 && npairs >= 1) {
+      // decoupled: line table in HBM, then folds; batches above 2^16 pairings go chunk by chunk through one table
+      int variant = g_shape.load() - 1;
+      if (C::CURVE_ID != 0 && variant > 0) variant = 0;
+      const int ng = g_ng.load();
+      const size_t chunk = (size_t)1 << 18;
+      const size_t per_wave = (size_t)ng * 10;
+      const size_t max_pad = ((npairs < chunk ? npairs : chunk) + per_wave - 1) / per_wave * per_wave;
+      const size_t groups_total = ((npairs + chunk - 1) / chunk) * (max_pad / ng);
+      void* tab;
+      if ((rc = c.get(WS_LINES, kl::lines_bytes<C>(variant, max_pad), &tab))) return rc;
+      if ((rc = c.get(WS_F_A, (groups_total + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+      if ((rc = c.get(WS_F_B, (groups_total / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      size_t gdone = 0;
+      {
+        Scope sc(c, st, ST_MILLER);
+        for (size_t p0 = 0; p0 < npairs; p0 += chunk) {
+          const size_t np = npairs - p0 < chunk ? npairs - p0 : chunk;
+          const size_t n_pad = (np + per_wave - 1) / per_wave * per_wave;
+          kl::miller_lines<C>(st, variant, g1s + p0, g2s + p0 * G2B, np, n_pad, (uint32_t*)tab, d_flags);
+          kl::miller_fold<C>(st, variant, (const uint32_t*)tab, n_pad, ng, (Fp2<C>*)pa + gdone * 6);
+          gdone += n_pad / ng;
+        }
+        HIPCHK(hipGetLastError());
+      }
+      if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, gdone, &red))) return rc;
+      return emit_partial(c, st, red, cofactor || sig != nullptr, sig, gl, d_partial);
+    }
     if constexpr (C::CURVE_ID == 0) {
       if (throughput_mode() && npairs >= 1) {
         // 60 pairings per block, 28-bit-limb consumer; the signature pair goes to the epilogue kernel
@@ -410,39 +443,40 @@ struct Engine {
     return finalize_collect(c);
   }
 
-  // AggregatePoints (curves/curve.go:73-121): affine bytes of the sum of n points to d_out
-  static int sum_points(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, uint8_t* d_out, uint32_t* d_flags) {
+  // AggregatePoints (curves/curve.go:73-121): affine bytes of the sum of n points to d_out.  parsed: d_pts are the
+  // resident Montgomery affine points of a key-set handle instead of wire bytes.
+  static int sum_points(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, uint8_t* d_out, uint32_t* d_flags,
+                        bool parsed = false) {
     const size_t PTB = group == BGLS_G1 ? G1B : G2B;
     if (n == 0) {
       HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
       return 0;
     }
-    // Fan-in per pass.  A pass costs (fan-in - 1) dependent additions of latency, so once the partial sums no longer
-    // fill the chip (two resident waves per SIMD at these register counts = 131 072 threads) the tree narrows by 2
-    // per pass instead of 16: log2 passes of ONE addition each instead of a few passes of 15.
-    auto fan = [&](size_t items) {
-      size_t r = (items + 131071) / 131072;
-      return (int)(r < 2 ? 2 : r > 16 ? 16 : r);
-    };
+    // main pass: at most two waves per SIMD (2048 waves), at least ~4 points per lane; then the per-thread partials
+    // are folded 64 at a time
+    size_t waves = (n + 255) / 256;
+    if (waves > 2048) waves = 2048;
     void *ja, *jb;
     int rc;
     Scope sc(c, st, ST_SUM);
     const size_t JB = kl::jac_bytes<C>(group);
-    const int R1 = fan(n);
-    size_t n1 = (n + R1 - 1) / R1;
-    if ((rc = c.get(WS_JAC_A, (n1 + 1) * JB, &ja))) return rc;
-    if ((rc = c.get(WS_JAC_B, (n1 / 2 + 2) * JB, &jb))) return rc;
-    kl::sum_first<C>(st, group, d_pts, n, R1, ja, d_flags);
+    if ((rc = c.get(WS_JAC_A, (waves * 64 + 1) * JB, &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (waves * 32 + 2) * JB, &jb))) return rc;
+    kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
     void *a = ja, *b = jb;
-    size_t cnt = n1;
+    size_t cnt = waves * 64;
     while (cnt > 1) {
-      const int R = fan(cnt);
-      size_t nout = (cnt + R - 1) / R;
-      kl::sum_next<C>(st, group, a, cnt, R, b);
+      // halving launches while there is parallelism to speak of, then 64 -> 1 per wave with lane shuffles
+      if (cnt > 4096) {
+        kl::sum_pair<C>(st, group, a, cnt, b);
+        cnt = (cnt + 1) / 2;
+      } else {
+        kl::sum_wave<C>(st, group, a, cnt, b);
+        cnt = (cnt + 63) / 64;
+      }
       void* t = a;
       a = b;
       b = t;
-      cnt = nout;
     }
     kl::jac_to_bytes<C>(st, group, a, 1, d_out);
     HIPCHK(hipGetLastError());
@@ -1272,6 +1306,13 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
 
 int bgls_set_throughput_mode(int on) {
   g_throughput.store(on ? 1 : 0);
+  return 0;
+}
+
+int bgls_set_miller_shape(int shape, int pairings_per_group) {
+  if (shape < 0 || shape > 3 || pairings_per_group < 1 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
+  g_shape.store(shape);
+  g_ng.store(pairings_per_group);
   return 0;
 }
 

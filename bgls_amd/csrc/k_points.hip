@@ -50,23 +50,188 @@ __device__ __forceinline__ void aff_to_bytes<F2<BN254>>(uint8_t* b, const Aff<F2
 template <>
 __device__ __forceinline__ void aff_to_bytes<F2<BLS381>>(uint8_t* b, const Aff<F2<BLS381>>& p) { g2_to_bytes<BLS381>(b, p); }
 
-template <class F, int PT_BYTES>
-__global__ void __launch_bounds__(64) k_sum_first(const uint8_t* pts, size_t n, int R, Jac<F>* out, uint32_t* flags) {
-  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  size_t lo = t * (size_t)R;
-  if (lo >= n) return;
-  size_t hi = lo + R < n ? lo + R : n;
-  Jac<F> acc = jac_inf<F>();
-  for (size_t k = lo; k < hi; ++k) {
-    Aff<F> p;
-    bool ok = aff_from_bytes<F>(p, pts + k * PT_BYTES);
-    ok = ok && aff_on_curve<F>(p);
-    if (!ok) atomicOr(flags, FLAG_ENC);
-    acc = jac_add_aff<F>(acc, p);
+// ---- AggregatePoints main pass (curves/curve.go:73-121; BASELINE config 4: 2^20 G2 keys) -------------------------------
+// Thread t walks points t, t + T, t + 2T, ... (neighbouring lanes read neighbouring points) and keeps a Jacobian
+// running sum; the mixed addition is expanded in place (no calls, no private stack in the loop) and the grid is sized to
+// two waves per SIMD, which is what hides the multiplier's dependent-carry latency.  The per-thread sums are then folded
+// 64 at a time with lane shuffles (k_sum_wave).
+// Exceptional inputs keep the result exact: infinity on either side is a select, equal x (P = +-Q, e.g. a key listed
+// twice) takes the out-of-line general addition.
+template <class F>
+__device__ __forceinline__ Jac<F> jac_dbl_inl(const Jac<F>& p) {       // dbl-2009-l, products expanded in place
+  typedef typename F::T T;
+  const T A = F::sqr_inl(p.X);
+  const T B = F::sqr_inl(p.Y);
+  const T Cc = F::sqr_inl(B);
+  const T D = F::dbl(F::sub(F::sub(F::sqr_inl(F::add(p.X, B)), A), Cc));
+  const T E = F::add(F::dbl(A), A);
+  Jac<F> r;
+  r.X = F::sub(F::sqr_inl(E), F::dbl(D));
+  r.Y = F::sub(F::mul_inl(E, F::sub(D, r.X)), F::dbl(F::dbl(F::dbl(Cc))));
+  r.Z = F::dbl(F::mul_inl(p.Y, p.Z));
+  return r;
+}
+
+template <class F>
+__device__ __forceinline__ Jac<F> jac_madd_inl(const Jac<F>& p, const Aff<F>& q) {
+  typedef typename F::T T;
+  const T Z1Z1 = F::sqr_inl(p.Z);
+  const T U2 = F::mul_inl(q.x, Z1Z1);
+  const T S2 = F::mul_inl(F::mul_inl(q.y, p.Z), Z1Z1);
+  const T H = F::sub(U2, p.X);
+  if (__builtin_expect(F::is_zero(H) && !jac_is_inf<F>(p) && !q.inf, 0)) {     // same x: P = Q (double) or P = -Q (infinity)
+    if (F::is_zero(F::sub(S2, p.Y))) return jac_dbl_inl<F>(p);
+    return jac_inf<F>();
   }
+  const T rr = F::dbl(F::sub(S2, p.Y));
+  const T HH = F::sqr_inl(H);
+  const T I = F::dbl(F::dbl(HH));
+  const T J = F::mul_inl(H, I);
+  const T V = F::mul_inl(p.X, I);
+  Jac<F> r;
+  r.X = F::sub(F::sub(F::sqr_inl(rr), J), F::dbl(V));
+  r.Y = F::sub(F::mul_inl(rr, F::sub(V, r.X)), F::dbl(F::mul_inl(p.Y, J)));
+  r.Z = F::sub(F::sub(F::sqr_inl(F::add(p.Z, H)), Z1Z1), HH);
+  const bool pinf = jac_is_inf<F>(p);
+  r.X = F::select(q.inf, p.X, F::select(pinf, q.x, r.X));
+  r.Y = F::select(q.inf, p.Y, F::select(pinf, q.y, r.Y));
+  r.Z = F::select(q.inf, p.Z, F::select(pinf, F::one(), r.Z));
+  return r;
+}
+
+// general Jacobian addition (add-2007-bl), products expanded in place; exceptional cases exact
+template <class F>
+__device__ __forceinline__ Jac<F> jac_add_inl(const Jac<F>& p, const Jac<F>& q) {
+  typedef typename F::T T;
+  const T Z1Z1 = F::sqr_inl(p.Z);
+  const T Z2Z2 = F::sqr_inl(q.Z);
+  const T U1 = F::mul_inl(p.X, Z2Z2);
+  const T U2 = F::mul_inl(q.X, Z1Z1);
+  const T S1 = F::mul_inl(F::mul_inl(p.Y, q.Z), Z2Z2);
+  const T S2 = F::mul_inl(F::mul_inl(q.Y, p.Z), Z1Z1);
+  const T H = F::sub(U2, U1);
+  const bool pinf = jac_is_inf<F>(p), qinf = jac_is_inf<F>(q);
+  if (__builtin_expect(F::is_zero(H) && !pinf && !qinf, 0)) {
+    if (F::is_zero(F::sub(S2, S1))) return jac_dbl_inl<F>(p);
+    return jac_inf<F>();
+  }
+  const T rr = F::dbl(F::sub(S2, S1));
+  const T I = F::sqr_inl(F::dbl(H));
+  const T J = F::mul_inl(H, I);
+  const T V = F::mul_inl(U1, I);
+  Jac<F> r;
+  r.X = F::sub(F::sub(F::sqr_inl(rr), J), F::dbl(V));
+  r.Y = F::sub(F::mul_inl(rr, F::sub(V, r.X)), F::dbl(F::mul_inl(S1, J)));
+  r.Z = F::mul_inl(F::sub(F::sub(F::sqr_inl(F::add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+  r.X = F::select(qinf, p.X, F::select(pinf, q.X, r.X));
+  r.Y = F::select(qinf, p.Y, F::select(pinf, q.Y, r.Y));
+  r.Z = F::select(qinf, p.Z, F::select(pinf, q.Z, r.Z));
+  return r;
+}
+
+template <class F>
+__device__ __forceinline__ Jac<F> jac_shfl_down(const Jac<F>& a, int off) {
+  Jac<F> r;
+  constexpr int ND = sizeof(Jac<F>) / 4;
+  const u32* src = reinterpret_cast<const u32*>(&a);
+  u32* dst = reinterpret_cast<u32*>(&r);
+#pragma unroll
+  for (int k = 0; k < ND; ++k) dst[k] = __shfl_down(src[k], off);
+  return r;
+}
+
+// big-endian field element through 16-byte loads (the wire formats are multiples of 16 bytes; p must be 16-byte aligned)
+template <class C>
+__device__ __forceinline__ Fp<C> fp_from_be16(const uint8_t* p) {
+  Fp<C> r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int k = 0; k < C::L / 4; ++k) {
+    const uint4 v = q[k];                      // bytes 16k .. 16k+15 = limbs L-1-4k .. L-4-4k, most significant first
+    r.v[C::L - 1 - 4 * k] = __builtin_bswap32(v.x);
+    r.v[C::L - 2 - 4 * k] = __builtin_bswap32(v.y);
+    r.v[C::L - 3 - 4 * k] = __builtin_bswap32(v.z);
+    r.v[C::L - 4 - 4 * k] = __builtin_bswap32(v.w);
+  }
+  return r;
+}
+template <class F, class C>
+__device__ __forceinline__ bool aff_from_bytes16(Aff<F>& p, const uint8_t* b) {
+  constexpr int N = C::FP_BYTES;
+  if constexpr (F::NFP == 1) {
+    const Fp<C> x = fp_from_be16<C>(b), y = fp_from_be16<C>(b + N);
+    const bool ok = !fp_geq_p<C>(x) && !fp_geq_p<C>(y);
+    p.inf = fp_is_zero<C>(x) && fp_is_zero<C>(y);
+    p.x = fp_mul_inl<C>(x, fp_load<C>(C::R2));
+    p.y = fp_mul_inl<C>(y, fp_load<C>(C::R2));
+    return ok;
+  } else {
+    const Fp<C> xi = fp_from_be16<C>(b), xr = fp_from_be16<C>(b + N), yi = fp_from_be16<C>(b + 2 * N), yr = fp_from_be16<C>(b + 3 * N);
+    const bool ok = !fp_geq_p<C>(xi) && !fp_geq_p<C>(xr) && !fp_geq_p<C>(yi) && !fp_geq_p<C>(yr);
+    p.inf = fp_is_zero<C>(xi) && fp_is_zero<C>(xr) && fp_is_zero<C>(yi) && fp_is_zero<C>(yr);
+    const Fp<C> r2 = fp_load<C>(C::R2);
+    p.x = {fp_mul_inl<C>(xr, r2), fp_mul_inl<C>(xi, r2)};
+    p.y = {fp_mul_inl<C>(yr, r2), fp_mul_inl<C>(yi, r2)};
+    return ok;
+  }
+}
+template <class F>
+__device__ __forceinline__ bool aff_on_curve_inl(const Aff<F>& a) {
+  if (a.inf) return true;
+  return F::eq(F::sqr_inl(a.y), F::add(F::mul_inl(F::sqr_inl(a.x), a.x), F::curve_b()));
+}
+
+// PARSED = false: pts are wire-format bytes (parsed and checked here); true: resident Montgomery affine points of a
+// key-set handle (validated when the handle was made).
+template <class C, class F, int PT_BYTES, bool PARSED>
+__global__ void __launch_bounds__(64, 2) k_sum_main(const uint8_t* pts, size_t n, Jac<F>* out, uint32_t* flags) {
+  const size_t T = (size_t)gridDim.x * 64;
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const bool aligned = (reinterpret_cast<uintptr_t>(pts) & 15) == 0;       // uniform
+  Jac<F> acc = jac_inf<F>();
+  bool bad = false;
+#pragma unroll 1
+  for (size_t k = t; k < n; k += T) {
+    Aff<F> p;
+    if constexpr (PARSED) {
+      p = reinterpret_cast<const Aff<F>*>(pts)[k];
+    } else {
+      bool ok = aligned ? aff_from_bytes16<F, C>(p, pts + k * PT_BYTES) : aff_from_bytes<F>(p, pts + k * PT_BYTES);
+      ok = ok && aff_on_curve_inl<F>(p);
+      bad = bad || !ok;
+    }
+    acc = jac_madd_inl<F>(acc, p);
+  }
+  if (bad) atomicOr(flags, FLAG_ENC);
   out[t] = acc;
 }
 
+// one partial per wave from up to 64 Jacobian partials per wave (the upper levels of the tree: few elements, latency-bound)
+template <class F>
+__global__ void __launch_bounds__(64, 2) k_sum_wave(const Jac<F>* in, size_t n, Jac<F>* out) {
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  Jac<F> acc = t < n ? in[t] : jac_inf<F>();
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) {
+    const Jac<F> o = jac_shfl_down<F>(acc, off);
+    acc = jac_add_inl<F>(acc, o);
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+// out[t] = in[2t] + in[2t+1]: one addition per thread.  The upper levels of the tree are latency-bound whatever their
+// shape; halving with half as many threads per launch keeps their MACHINE time small (a wave-shuffle tree runs every
+// level on all lanes), so the tail of one verification leaves the SIMDs to the main pass of the next.
+template <class F>
+__global__ void __launch_bounds__(64, 2) k_sum_pair(const Jac<F>* in, size_t n, Jac<F>* out) {
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const size_t lo = 2 * t;
+  if (lo >= n) return;
+  Jac<F> acc = in[lo];
+  if (lo + 1 < n) acc = jac_add_inl<F>(acc, in[lo + 1]);
+  out[t] = acc;
+}
+// fan-in R, out-of-line additions: used by the weighted sums (few elements per thread)
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_next(const Jac<F>* in, size_t n, int R, Jac<F>* out) {
   size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -271,10 +436,25 @@ void g1_parse(hipStream_t st, const uint8_t* in, size_t n, int negate, Aff<F1<C>
 }
 
 template <class C>
-void sum_first(hipStream_t st, int group, const uint8_t* pts, size_t n, int R, void* out, uint32_t* flags) {
-  const size_t n1 = (n + R - 1) / R;
-  if (group == BGLS_G1) k_sum_first<F1<C>, 2 * C::FP_BYTES><<<nblk(n1, 64), 64, 0, st>>>(pts, n, R, (Jac<F1<C>>*)out, flags);
-  else k_sum_first<F2<C>, 4 * C::FP_BYTES><<<nblk(n1, 64), 64, 0, st>>>(pts, n, R, (Jac<F2<C>>*)out, flags);
+void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags) {
+  if (group == BGLS_G1) {
+    if (parsed) k_sum_main<C, F1<C>, 2 * C::FP_BYTES, true><<<waves, 64, 0, st>>>(pts, n, (Jac<F1<C>>*)out, flags);
+    else k_sum_main<C, F1<C>, 2 * C::FP_BYTES, false><<<waves, 64, 0, st>>>(pts, n, (Jac<F1<C>>*)out, flags);
+  } else {
+    if (parsed) k_sum_main<C, F2<C>, 4 * C::FP_BYTES, true><<<waves, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
+    else k_sum_main<C, F2<C>, 4 * C::FP_BYTES, false><<<waves, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
+  }
+}
+template <class C>
+void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out) {
+  const size_t nout = (n + 1) / 2;
+  if (group == BGLS_G1) k_sum_pair<F1<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
+  else k_sum_pair<F2<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
+}
+template <class C>
+void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out) {
+  if (group == BGLS_G1) k_sum_wave<F1<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
+  else k_sum_wave<F2<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
 }
 template <class C>
 void sum_next(hipStream_t st, int group, const void* in, size_t n, int R, void* out) {
@@ -329,7 +509,9 @@ void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed,
 #define BGLS_INST(C)                                                                                                             \
   template void g1_to_bytes<C>(hipStream_t, const Aff<F1<C>>*, size_t, uint8_t*);                                                \
   template void g1_parse<C>(hipStream_t, const uint8_t*, size_t, int, Aff<F1<C>>*, uint32_t*);                                   \
-  template void sum_first<C>(hipStream_t, int, const uint8_t*, size_t, int, void*, uint32_t*);                                   \
+  template void sum_main<C>(hipStream_t, int, bool, const uint8_t*, size_t, unsigned, void*, uint32_t*);                         \
+  template void sum_wave<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
+  template void sum_pair<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
   template void sum_next<C>(hipStream_t, int, const void*, size_t, int, void*);                                                  \
   template void jac_to_bytes<C>(hipStream_t, int, const void*, size_t, uint8_t*);                                                \
   template void wsum_first<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, void*, uint32_t*);       \

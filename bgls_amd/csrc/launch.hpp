@@ -16,7 +16,9 @@ void blake2x_expand(hipStream_t st, const uint64_t* root, uint32_t xof_len, uint
 // ---- k_points.hip   (group = BGLS_G1 / BGLS_G2; Jacobian workspaces are passed as void*)
 template <class C> void g1_to_bytes(hipStream_t st, const Aff<F1<C>>* in, size_t n, uint8_t* out);
 template <class C> void g1_parse(hipStream_t st, const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags);
-template <class C> void sum_first(hipStream_t st, int group, const uint8_t* pts, size_t n, int R, void* out, uint32_t* flags);
+template <class C> void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
+template <class C> void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out);
+template <class C> void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out);
 template <class C> void sum_next(hipStream_t st, int group, const void* in, size_t n, int R, void* out);
 template <class C> void jac_to_bytes(hipStream_t st, int group, const void* in, size_t n, uint8_t* out);
 template <class C> void wsum_first(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, void* out, uint32_t* flags);
@@ -36,6 +38,11 @@ void miller_ab64(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const 
 template <class C>
 void miller_s60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags,
                 int dbg);
+
+template <class C> size_t lines_bytes(int variant, size_t n_pad);
+template <class C>
+void miller_lines(hipStream_t st, int variant, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, size_t n_pad, uint32_t* table, uint32_t* flags);
+template <class C> void miller_fold(hipStream_t st, int variant, const uint32_t* table, size_t n_pad, int ng, Fp2<C>* out);
 
 // ---- k_tail_bn.hip / k_tail_bls.hip
 template <class C> void gen_lines(hipStream_t st, LineCoeffs<C>* table, int* nsteps);

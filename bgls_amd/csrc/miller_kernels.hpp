@@ -359,4 +359,248 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
   }
 }
 
+
+// =====================================================================================================================
+// Decoupled Miller loop: the point steps and the accumulator folds run as two kernels joined through HBM.
+//
+//   k_lines   thread per pairing: parses the key, walks the G2 point steps and writes the scaled line of every step
+//             (three Fp2 coefficients) to a line table in HBM -- no LDS, no barrier, its own register budget
+//   k_fold    wave = 10 groups x 6 lanes, no block-level synchronisation at all: a group folds the lines of NG
+//             pairings per step into its shared Fp12 accumulator, f <- f^2 * l_1 * ... * l_NG (one squaring per NG
+//             pairings instead of per 6), reading the lines back through a small per-wave LDS ring
+//
+// The fused kernels above tie both roles to one block (one barrier per step, one register allocation sized by the
+// hungrier role, LDS footprint fixing two waves per SIMD).  Here the 288 GB of HBM, otherwise idle on this path, is
+// the hand-over buffer: 88 (alt-bn128) / 69 (BLS12-381) lines of 240 / 288 B per pairing, about 1.4 GB per 2^16
+// pairings, written and read once (a few hundred GB/s of the 8 TB/s).  A line table depends on the key and the hash
+// point only through the final scaling by (xP, yP); tables of UNSCALED lines are what a key-set handle caches
+// (bgls_keys_upload), so that verifications against a resident key set skip the point steps altogether.
+//
+// Table layout: entry-major per (step, pairing):  table[(s * n_pad + i) * LINE_DW + e * S2 + d],  e = 0..2, so the NG
+// lines a group needs for one step are contiguous.
+template <class C, bool R28>
+struct LineTab {
+  static constexpr int S2 = R28 ? R28_S2 : 2 * C::L;
+  static constexpr int LINE_DW = 3 * S2;
+  // number of line steps of the Miller loop (doublings + additions [+ 2 Frobenius steps on alt-bn128])
+  static constexpr int nsteps() {
+    int s = 0;
+    for (int i = 1; i < C::LOOP_LEN; ++i) s += 1 + (C::LOOP_NAF[i] != 0 ? 1 : 0);
+    return s + (C::CURVE_ID == 0 ? 2 : 0);
+  }
+  static constexpr int NSTEPS = nsteps();
+};
+
+// emitter for dbl_step_emit / add_step_emit: scales coefficient `which` by yP / xP and stores it as entry 0..2 of the
+// pairing's line in the table (entry order as LineEmitter: D-type c0 yP, c1 xP, c2; M-type c2, c1 xP, c0 yP)
+template <class C, bool R28>
+struct GlobalLineEmitter {
+  u32* line;             // this pairing's line of the current step
+  const Fp<C>& xP;
+  const Fp<C>& yP;
+  bool valid;
+  __device__ __forceinline__ void store(int entry, const Fp2<C>& e) const {
+    uint4* p = reinterpret_cast<uint4*>(line + entry * LineTab<C, R28>::S2);
+    if constexpr (R28) {
+      const F28x2 r = to_r28<C>(e);
+      u32 w[20];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { w[k] = r.c0.v[k]; w[10 + k] = r.c1.v[k]; }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) p[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::L / 4; ++k) p[k] = make_uint4(e.c0.v[4 * k], e.c0.v[4 * k + 1], e.c0.v[4 * k + 2], e.c0.v[4 * k + 3]);
+#pragma unroll
+      for (int k = 0; k < C::L / 4; ++k) p[C::L / 4 + k] = make_uint4(e.c1.v[4 * k], e.c1.v[4 * k + 1], e.c1.v[4 * k + 2], e.c1.v[4 * k + 3]);
+    }
+  }
+  __device__ __forceinline__ void operator()(int which, const Fp2<C>& v) const {
+    Fp2<C> e;
+    int entry;
+    if (which == 0) {
+      e = f2ms<C, true>(v, yP);
+      entry = C::TWIST_D ? 0 : 2;
+    } else if (which == 1) {
+      e = f2ms<C, true>(v, xP);
+      entry = 1;
+    } else {
+      e = v;
+      entry = C::TWIST_D ? 2 : 0;
+    }
+    if (!valid) e = (entry == 0) ? f2_one<C>() : f2_zero<C>();
+    store(entry, e);
+  }
+};
+
+// one thread per pairing i < n_pad; pairings i >= n (padding up to whole fold groups), infinite points and bad keys
+// contribute the constant line 1
+template <class C, bool R28>
+__global__ void __launch_bounds__(64, 2) k_lines(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, size_t n_pad, u32* table, uint32_t* flags) {
+  typedef LineTab<C, R28> T;
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pad) return;
+  Aff<F2<C>> Q;
+  Aff<F1<C>> P;
+  bool valid = i < n;
+  if (valid) {
+    bool ok = g2_from_bytes<C>(Q, g2s + i * 4 * C::FP_BYTES);
+    ok = ok && aff_on_curve<F2<C>>(Q);
+    if (!ok) atomicOr(flags, FLAG_ENC);
+    P = g1s[i];
+    valid = !P.inf && !Q.inf;
+  }
+  if (!valid) {
+    Q.x = f2_load<C>(C::G2);
+    Q.y = f2_load<C>(C::G2 + 2 * C::L);
+    P.x = fp_load<C>(C::G1X);
+    P.y = fp_load<C>(C::G1Y);
+  }
+  G2Proj<C> R = {Q.x, Q.y, f2_one<C>()};
+  u32* line = table + i * T::LINE_DW;
+  const size_t step_dw = n_pad * T::LINE_DW;
+#pragma unroll 1
+  for (int k = 1; k < C::LOOP_LEN; ++k) {
+    dbl_step_emit<C>(R, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
+    line += step_dw;
+    const int d = C::LOOP_NAF[k];
+    if (d != 0) {
+      add_step_emit<C>(R, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
+      line += step_dw;
+    }
+  }
+  if constexpr (C::CURVE_ID == 0) {
+    {
+      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+      add_step_emit<C>(R, x1, y1, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
+      line += step_dw;
+    }
+    {
+      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+      add_step_emit<C>(R, x2, y2, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
+    }
+  }
+}
+
+// LDS of one fold wave: 10 groups x (accumulator region + two line slots)
+template <class C, bool R28>
+struct FoldLds {
+  static constexpr int S2 = LineTab<C, R28>::S2;
+  static constexpr bool XF = !R28 && C::XI_RE == 1;       // 32-bit BLS12-381: plain coefficients only, xi applied after the load
+  static constexpr int RBN = XF ? 6 : 12;
+  static constexpr int RB = 0, RL = RBN * S2;             // line slots: RL + slot * 3 * S2
+  static constexpr int GROUP_DW = (RBN + 2 * 3) * S2;
+  static constexpr int WAVE_BYTES = 10 * GROUP_DW * 4;
+};
+
+// KARA (R28 only): three-pile Karatsuba dot products (fewer multiplications, ~190 registers) or the four-pile
+// schoolbook form (fits the 168 registers of three waves per SIMD)
+template <class C, bool R28, bool KARA>
+__global__ void __launch_bounds__(64, KARA ? 2 : 3) k_fold(const u32* table, size_t n_pad, int ng, Fp2<C>* out) {
+  typedef LineTab<C, R28> T;
+  typedef FoldLds<C, R28> K;
+  extern __shared__ u32 lds[];
+  const int lane = threadIdx.x;
+  const bool live = lane < 60;
+  const int g = live ? lane / 6 : 9;
+  const int j = live ? lane % 6 : lane - 60;
+  const int gb = g * K::GROUP_DW;
+  const size_t G = (size_t)blockIdx.x * 10 + g;                 // global group: pairings [G * ng, (G + 1) * ng)
+  // each of the 6 lanes of a group fetches chunks j, j + 6, j + 12 (16 B each) of a line
+  constexpr int NCH = T::LINE_DW / 4;                            // 15 (r28) / 12 (alt-bn128, 32-bit) / 18 (BLS12-381)
+  const u32* src = table + (G * (size_t)ng) * T::LINE_DW + 4 * j;
+  const size_t step_dw = n_pad * T::LINE_DW;
+  uint4 pf[3];
+  auto prefetch = [&](const u32* ln) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (j + 6 * q < NCH) pf[q] = *reinterpret_cast<const uint4*>(ln + 24 * q);
+  };
+  auto stash = [&](int slot) {
+    if (live) {
+      uint4* dst = reinterpret_cast<uint4*>(lds + gb + K::RL + slot * T::LINE_DW + 4 * j);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (j + 6 * q < NCH) dst[6 * q] = pf[q];
+    }
+    wave_sync();
+  };
+  const int nsteps = T::NSTEPS;
+  // line sequence: step-major, the ng lines of a step one after the other
+  int s = 0, m = 0, slot = 0;
+  auto next_line = [&]() {                                       // address of the line after (s, m), or nullptr at the end
+    int s2 = s, m2 = m + 1;
+    if (m2 == ng) { m2 = 0; ++s2; }
+    return s2 < nsteps ? src + (size_t)s2 * step_dw + (size_t)m2 * T::LINE_DW : (const u32*)nullptr;
+  };
+  prefetch(src);
+  if constexpr (R28) {
+    const int rbo = gb + K::RB;
+    F28x2 fj;
+    {
+      const F28 one = r28_load<C>(C::R28_ONE);
+#pragma unroll
+      for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
+    }
+    coop_publish28<C>(rbo, j, fj, live);
+    auto fold_step = [&]() {
+#pragma unroll 1
+      for (m = 0; m < ng; ++m) {
+        stash(slot);
+        const u32* nx = next_line();
+        if (nx) prefetch(nx);
+        const int rlo = gb + K::RL + slot * T::LINE_DW;
+        if constexpr (KARA) fj = coop_dot28_k3<C>(rlo, 0, rbo, j, COOP_SH_D);
+        else fj = coop_dot28<C, 3>(rlo, 0, rbo, j, COOP_SH_D);
+        coop_publish28<C>(rbo, j, fj, live);
+        slot ^= 1;
+      }
+      ++s;
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      fj = coop_sqr_sym28<C>(rbo, j);
+      coop_publish28<C>(rbo, j, fj, live);
+      fold_step();
+      if (C::LOOP_NAF[i] != 0) fold_step();
+    }
+    fold_step();
+    fold_step();
+    if (live) out[G * 6 + j] = from_r28<C>(fj);
+  } else {
+    const LReg rb = {gb + K::RB, 12};
+    Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
+    coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
+    auto fold_step = [&]() {
+#pragma unroll 1
+      for (m = 0; m < ng; ++m) {
+        stash(slot);
+        const u32* nx = next_line();
+        if (nx) prefetch(nx);
+        const LReg rl = {gb + K::RL + slot * T::LINE_DW, 3};
+        fj = coop_dot_inl<C, 3, K::XF>(rl, 0, 1, rb, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
+        coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
+        slot ^= 1;
+      }
+      ++s;
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
+      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
+      fold_step();
+      if (C::LOOP_NAF[i] != 0) fold_step();
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      fold_step();
+      fold_step();
+    } else {
+      if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
+    }
+    if (live) out[G * 6 + j] = fj;
+  }
+}
+
 }  // namespace bgls

@@ -192,7 +192,12 @@ int bgls_final_verify_collect(int curve);
  * (60 pairings per block: a 2^16 batch is 1093 blocks, one more round than fit at once when it runs alone).  Results are
  * identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the environment. */
 int bgls_set_throughput_mode(int on);
-/* Contexts 0..7: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
+/* Shape of the Miller stage.  0 (default): fused producer/consumer blocks.  1..3: decoupled -- k_lines writes every
+ * pairing's scaled line coefficients to a table in HBM, k_fold folds them into shared accumulators, pairings_per_group
+ * pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs + Karatsuba; 2 and 3 alt-bn128 only, others
+ * fall back to 1).  Results are identical for every shape. */
+int bgls_set_miller_shape(int shape, int pairings_per_group);
+/* Contexts 0..15: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
  * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */
 int bgls_select_context(int index);
 
