@@ -39,6 +39,18 @@ SIGNATURES = {
     "bgls_scale_points": (ci, [ci, ci, u8p, u8p, u8p, sz, u8p]),
     "bgls_point_add": (ci, [ci, ci, u8p, u8p, u8p]),
     "bgls_point_check": (ci, [ci, ci, u8p]),
+    "bgls_check_points": (ci, [ci, ci, u8p, sz, u8p]),
+    "bgls_select_device": (ci, [ci]),
+    "bgls_keys_upload": (ci, [ci, u8p, sz, ctypes.POINTER(ctypes.c_int), ci, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64)]),
+    "bgls_keys_free": (ci, [ctypes.c_uint64]),
+    "bgls_keys_info": (ci, [ctypes.c_uint64, ctypes.POINTER(ci), ctypes.POINTER(sz), ctypes.POINTER(ci)]),
+    "bgls_verify_aggregate_h": (ci, [ctypes.c_uint64, u8p, u8p, u64p, sz, ci]),
+    "bgls_verify_multi_h": (ci, [ctypes.c_uint64, u8p, u8p, sz]),
+    "bgls_verify_aggregate_multi": (ci, [ci, u8p, u8p, u8p, u64p, sz, ci, ctypes.POINTER(ctypes.c_int), ci]),
+    "bgls_verify_multi_multi": (ci, [ci, u8p, u8p, sz, u8p, sz, ctypes.POINTER(ctypes.c_int), ci]),
+    "bgls_last_exchange": (ci, []),
+    "bgls_rccl_available": (ci, []),
+    "bgls_verify_aggregate_h_gt": (ci, [ctypes.c_uint64, u8p, u8p, u64p, sz, ci, u8p]),
     "bgls_generator": (ci, [ci, ci, u8p]),
     "bgls_pair": (ci, [ci, u8p, u8p, u8p]),
     "bgls_gt_mul": (ci, [ci, u8p, u8p, u8p]),

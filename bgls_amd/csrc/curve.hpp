@@ -182,6 +182,48 @@ BGLS_FN Jac<F> jac_mul(const Aff<F>& p, const u32* k, int nbits) {
   return r;
 }
 
+// ---- G2 subgroup membership ------------------------------------------------------------------------------------------
+// The reference validates G2 inputs when a Point is constructed: alt-bn128 MakeG2Point / UnmarshalG2
+// (curves/altbn128.go:157-179,329-376) reach upstream bn256's G2.Unmarshal, which rejects twist points outside the
+// order-r subgroup, BLS12-381 has Check() (curves/bls12_381.go:242-264).  A twist point outside G2 must never reach the
+// Miller loop: the pairing is not bilinear there.  Membership is decided with the endomorphism psi = twist o Frobenius o
+// untwist (psi acts on G2 as multiplication by p), one 63/64-bit scalar multiplication instead of a 254/255-bit one:
+//     alt-bn128   [u+1]Q + psi([u]Q) + psi^2([u]Q) = psi^3([2u]Q)
+//     BLS12-381   psi(Q) = [x]Q
+// Both accept EXACTLY the points with [r]Q = infinity: oracle/pyref/subgroup.py proves it for these two curves by
+// checking every prime-order component of the cofactor part of E'(Fp2) (tests/test_oracle.py).
+template <class C>
+BGLS_HD Jac<F2<C>> g2_psi(const Jac<F2<C>>& q) {        // conjugation is a field automorphism: acts coordinate-wise, Z included
+  const Fp2<C> px = f2_load<C>(C::PSI_X), py = f2_load<C>(C::PSI_Y);
+  return {f2_mul<C>(f2_conj<C>(q.X), px), f2_mul<C>(f2_conj<C>(q.Y), py), f2_conj<C>(q.Z)};
+}
+template <class F>
+BGLS_FN bool jac_eq(const Jac<F>& a, const Jac<F>& b) {
+  const bool ai = jac_is_inf<F>(a), bi = jac_is_inf<F>(b);
+  if (ai || bi) return ai && bi;
+  typedef typename F::T T;
+  const T za = F::sqr(a.Z), zb = F::sqr(b.Z);
+  if (!F::eq(F::mul(a.X, zb), F::mul(b.X, za))) return false;
+  return F::eq(F::mul(a.Y, F::mul(zb, b.Z)), F::mul(b.Y, F::mul(za, a.Z)));
+}
+// q: on the twist (caller checked).  Exact also for points of small order: the group law below handles P = +-Q and
+// infinity explicitly.
+template <class C>
+BGLS_FN bool g2_in_subgroup(const Aff<F2<C>>& q) {
+  typedef F2<C> F;
+  if (q.inf) return true;
+  Jac<F> xq = jac_mul<F>(q, C::U_ABS, C::U_BITS);
+  if constexpr (C::CURVE_ID == 0) {
+    const Jac<F> p1 = g2_psi<C>(xq), p2 = g2_psi<C>(p1);
+    const Jac<F> lhs = jac_add<F>(jac_add<F>(jac_add_aff<F>(xq, q), p1), p2);
+    const Jac<F> rhs = g2_psi<C>(g2_psi<C>(g2_psi<C>(jac_dbl<F>(xq))));
+    return jac_eq<F>(lhs, rhs);
+  } else {
+    xq.Y = f2_neg<C>(xq.Y);                              // x < 0
+    return jac_eq<F>(g2_psi<C>(jac_from_aff<F>(q)), xq);
+  }
+}
+
 // ---- (de)serialisation of affine points at the seam (uncompressed wire formats) ----
 //  G1: x || y big-endian (curves/altbn128.go:42-57; bls12G1Hash.dat)
 //  G2: x_im || x_re || y_im || y_re (curves/altbn128.go:157-179, altbn128_test.go:26-38;

@@ -16,6 +16,11 @@
 #include <vector>
 #include <atomic>
 #include <string>
+#include <thread>
+#include <memory>
+#include <unordered_map>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include "dev_common.hpp"
 #include "coop.hpp"
@@ -53,7 +58,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 constexpr size_t MAX_BATCH = (size_t)1 << 30;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -452,6 +457,23 @@ struct Engine {
       HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
       return 0;
     }
+    void* jac;
+    int rc;
+    if ((rc = c.get(WS_SUMJ, 4 * kl::jac_bytes<C>(group), &jac))) return rc;
+    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, parsed))) return rc;
+    Scope sc(c, st, ST_SUM);
+    kl::jac_to_bytes<C>(st, group, jac, 1, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // the same sum left in Jacobian form at d_jac (multi-device key sums exchange projective partials);
+  // n == 0 gives the point at infinity (all-zero record: Z = 0)
+  static int sum_points_jac(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, void* d_jac, uint32_t* d_flags,
+                            bool parsed = false) {
+    if (n == 0) {
+      HIPCHK(hipMemsetAsync(d_jac, 0, kl::jac_bytes<C>(group), st));
+      return 0;
+    }
     // main pass: at most two waves per SIMD (2048 waves), at least ~4 points per lane; then the per-thread partials
     // are folded 64 at a time
     size_t waves = (n + 255) / 256;
@@ -478,7 +500,7 @@ struct Engine {
       a = b;
       b = t;
     }
-    kl::jac_to_bytes<C>(st, group, a, 1, d_out);
+    HIPCHK(hipMemcpyAsync(d_jac, a, JB, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -706,11 +728,35 @@ int point_check_t(int group, const uint8_t* a) {
   if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
   HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
   HIPCHK(hipMemcpyAsync(d_in, a, PB, hipMemcpyHostToDevice, st));
-  kl::check<C>(st, group, (const uint8_t*)d_in, 1, (uint32_t*)d_flags);
+  kl::check<C>(st, group, (const uint8_t*)d_in, 1, (uint32_t*)d_flags, nullptr);
   uint32_t f = 0;
   HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return f ? 0 : 1;
+}
+
+template <class C>
+int check_points_t(int group, const uint8_t* pts, size_t n, uint8_t* ok_out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  if (n == 0) return 0;
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  void *d_in, *d_ok, *d_flags;
+  if ((rc = c.get(WS_IN_B, n * PB, &d_in))) return rc;
+  if ((rc = c.get(WS_IN_D, n, &d_ok))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d_in, pts, n * PB, hipMemcpyHostToDevice, st));
+  kl::check<C>(st, group, (const uint8_t*)d_in, n, (uint32_t*)d_flags, (uint8_t*)d_ok);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ok_out, d_ok, n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
 }
 
 template <class C>
@@ -1143,6 +1189,342 @@ int sign_batch_t(const uint8_t* sks, const uint8_t* blob, const uint64_t* off, s
   return flags_to_rc(f);
 }
 
+
+// ======================================================================= key sets and multi-device verification
+// RCCL is loaded at run time (dlopen) so that the library has no link-time dependency on it: the exchange of the
+// per-device partials falls back to peer copies whenever RCCL is missing, a device id repeats, or a call fails.
+struct Rccl {
+  void* so = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false;
+  Rccl() {
+    if (const char* e = getenv("BGLS_NO_RCCL")) { if (e[0] == '1') return; }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (so) break;
+    }
+    if (!so) return;
+    CommInitAll = (decltype(CommInitAll))dlsym(so, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(so, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(so, "ncclAllGather");
+    GroupStart = (decltype(GroupStart))dlsym(so, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(so, "ncclGroupEnd");
+    ok = CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+  }
+};
+Rccl& rccl() {
+  static Rccl r;
+  return r;
+}
+
+struct KeyShard {
+  int device = 0;
+  size_t lo = 0, hi = 0;
+  void* d_wire = nullptr;    // (hi - lo) wire-format keys
+  void* d_mont = nullptr;    // the same keys as Aff<F2<C>> (Montgomery form), for the key sums
+  void* d_rec = nullptr;     // this shard's exchange record: GT partial + status word (send buffer)
+  void* d_all = nullptr;     // every shard's record (receive buffer)
+};
+struct KeySet {
+  int curve = 0;
+  size_t n = 0;
+  std::vector<KeyShard> shards;
+  std::vector<ncclComm_t> comms;     // one per shard when the RCCL exchange is usable, else empty
+  std::mutex mu;                     // one verification at a time per key set (the shards' buffers are part of it)
+  ~KeySet() {
+    for (auto cm : comms) if (cm) (void)rccl().CommDestroy(cm);
+    for (auto& sh : shards) {
+      if (hipSetDevice(sh.device) != hipSuccess) continue;
+      for (void* q : {sh.d_wire, sh.d_mont, sh.d_rec, sh.d_all}) if (q) (void)hipFree(q);
+    }
+  }
+};
+std::mutex g_keys_mu;
+std::unordered_map<uint64_t, std::shared_ptr<KeySet>> g_keys;
+uint64_t g_keys_next = 1;
+thread_local int g_last_exchange = 0;
+
+std::shared_ptr<KeySet> keyset(bgls_keys_t h) {
+  std::lock_guard<std::mutex> lk(g_keys_mu);
+  auto it = g_keys.find(h);
+  return it == g_keys.end() ? nullptr : it->second;
+}
+
+constexpr size_t REC_PAD = 16;     // status word + padding behind the GT bytes of an exchange record
+
+template <class C>
+int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* out) {
+  typedef Engine<C> E;
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "key set too large (n must be below 2^30)");
+  auto ks = std::make_shared<KeySet>();
+  ks->curve = C::CURVE_ID;
+  ks->n = n;
+  const size_t REC = E::GTB + REC_PAD;
+  bool distinct = true;
+  for (int s = 0; s < n_devices; ++s) {
+    KeyShard sh;
+    sh.device = devices ? devices[s] : s;
+    if (sh.device < 0 || sh.device >= MAX_DEVICES) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
+    for (int t = 0; t < s; ++t) distinct = distinct && ks->shards[t].device != sh.device;
+    sh.lo = n * (size_t)s / n_devices;
+    sh.hi = n * (size_t)(s + 1) / n_devices;
+    ks->shards.push_back(sh);
+  }
+  const int prev_dev = g_dev, prev_sel = g_sel;
+  int rc = 0;
+  for (int s = 0; s < n_devices && rc == 0; ++s) {
+    KeyShard& sh = ks->shards[s];
+    const size_t cnt = sh.hi - sh.lo;
+    g_dev = sh.device;
+    g_sel = 0;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = [&]() -> int {
+      int r;
+      if ((r = c.enter())) return r;
+      HIPCHK(hipMalloc(&sh.d_wire, cnt ? cnt * E::G2B : 16));
+      HIPCHK(hipMalloc(&sh.d_mont, cnt ? cnt * kl::g2_parsed_bytes<C>() : 16));
+      HIPCHK(hipMalloc(&sh.d_rec, REC));
+      HIPCHK(hipMalloc(&sh.d_all, REC * n_devices));
+      void* d_flags;
+      if ((r = c.get(WS_FLAGS, 16, &d_flags))) return r;
+      HIPCHK(hipMemsetAsync(d_flags, 0, 4, c.stream));
+      if (cnt) {
+        HIPCHK(hipMemcpyAsync(sh.d_wire, keys + sh.lo * E::G2B, cnt * E::G2B, hipMemcpyHostToDevice, c.stream));
+        kl::g2_parse<C>(c.stream, (const uint8_t*)sh.d_wire, cnt, (flags & BGLS_KEYS_CHECK) ? 1 : 0, sh.d_mont, (uint32_t*)d_flags);
+        HIPCHK(hipGetLastError());
+      }
+      uint32_t f = 0;
+      HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, c.stream));
+      HIPCHK(hipStreamSynchronize(c.stream));
+      if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "key set: non-canonical coordinate or key not on the twist");
+      if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "key set: key outside the order-r subgroup");
+      return 0;
+    }();
+  }
+  g_dev = prev_dev;
+  g_sel = prev_sel;
+  if (rc) return rc;                  // ~KeySet frees what was allocated
+  if (n_devices > 1 && distinct && rccl().ok) {
+    std::vector<int> devs;
+    for (auto& sh : ks->shards) devs.push_back(sh.device);
+    ks->comms.assign(n_devices, nullptr);
+    if (rccl().CommInitAll(ks->comms.data(), n_devices, devs.data()) != ncclSuccess) ks->comms.clear();
+  }
+  std::lock_guard<std::mutex> lk(g_keys_mu);
+  const uint64_t h = g_keys_next++;
+  g_keys[h] = ks;
+  *out = h;
+  return 0;
+}
+
+// Gather every shard's exchange record on shard 0 (sh[0].d_all, shard order).  Each shard's record is complete on its
+// context-`s` stream.  RCCL: one all-gather enqueued on every device's stream; else peer / device copies.
+template <class C>
+int exchange_records(KeySet& ks) {
+  typedef Engine<C> E;
+  const size_t REC = E::GTB + REC_PAD;
+  const int S = (int)ks.shards.size();
+  g_last_exchange = S > 1 ? 1 : 0;
+  if (!ks.comms.empty()) {
+    bool good = rccl().GroupStart() == ncclSuccess;
+    for (int s = 0; s < S && good; ++s) {
+      KeyShard& sh = ks.shards[s];
+      good = hipSetDevice(sh.device) == hipSuccess &&
+             rccl().AllGather(sh.d_rec, sh.d_all, REC, ncclUint8, ks.comms[s], ctx_of(sh.device, s % NCTX).stream) == ncclSuccess;
+    }
+    good = (rccl().GroupEnd() == ncclSuccess) && good;
+    if (good) {
+      g_last_exchange = 2;
+      return 0;
+    }
+  }
+  KeyShard& root = ks.shards[0];
+  for (int s = 0; s < S; ++s) {
+    KeyShard& sh = ks.shards[s];
+    hipStream_t st = ctx_of(sh.device, s % NCTX).stream;
+    HIPCHK(hipSetDevice(sh.device));
+    uint8_t* dst = (uint8_t*)root.d_all + (size_t)s * REC;
+    if (sh.device == root.device) HIPCHK(hipMemcpyAsync(dst, sh.d_rec, REC, hipMemcpyDeviceToDevice, st));
+    else HIPCHK(hipMemcpyPeerAsync(dst, root.device, sh.d_rec, sh.device, REC, st));
+    if (s) HIPCHK(hipStreamSynchronize(st));         // shard 0 continues on its own stream
+  }
+  return 0;
+}
+
+// runs fn(shard index) on one host thread per shard, each bound to its shard's device and to context `s`
+template <class Fn>
+int for_each_shard(KeySet& ks, Fn&& fn) {
+  const int S = (int)ks.shards.size();
+  std::vector<int> rcs(S, 0);
+  std::vector<std::string> errs(S);
+  auto body = [&](int s) {
+    g_dev = ks.shards[s].device;
+    g_sel = s % NCTX;
+    rcs[s] = fn(s);
+    if (rcs[s] < 0) errs[s] = g_err;
+  };
+  if (S == 1) {
+    const int pd = g_dev, ps = g_sel;
+    body(0);
+    g_dev = pd;
+    g_sel = ps;
+  } else {
+    std::vector<std::thread> th;
+    for (int s = 0; s < S; ++s) th.emplace_back(body, s);
+    for (auto& t : th) t.join();
+  }
+  for (int s = 0; s < S; ++s)
+    if (rcs[s] < 0) { g_err = errs[s]; return rcs[s]; }
+  return 0;
+}
+
+int merged_flags_rc(uint32_t f) {
+  if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+  if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
+  return 0;
+}
+
+template <class C>
+int verify_aggregate_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* blob, const uint64_t* off, size_t n, int allow_dups, uint8_t* gt_out) {
+  typedef Engine<C> E;
+  if (n != ks.n) return fail(BGLS_ERR_ARG, "message count differs from the key set's size");
+  for (size_t i = 0; i < n; ++i)
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+  std::lock_guard<std::mutex> lk_set(ks.mu);
+  const size_t REC = E::GTB + REC_PAD;
+  const int S = (int)ks.shards.size();
+  int rc = for_each_shard(ks, [&](int s) -> int {
+    KeyShard& sh = ks.shards[s];
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    int r;
+    if ((r = c.enter())) return r;
+    hipStream_t st = c.stream;
+    const size_t cnt = sh.hi - sh.lo;
+    // shard 0 holds ALL messages: the duplicate rule is a property of the whole list (two equal messages may sit in
+    // different shards); the other shards upload their own range only
+    const size_t mlo = s == 0 ? 0 : sh.lo, mhi = s == 0 ? n : sh.hi;
+    const size_t bytes = off[mhi] - off[mlo];
+    void *d_sig, *d_blob, *d_off, *d_flags;
+    if ((r = c.get(WS_IN_A, E::G1B, &d_sig))) return r;
+    if ((r = c.get(WS_IN_C, bytes, &d_blob))) return r;
+    if ((r = c.get(WS_IN_D, (mhi - mlo + 1) * 8, &d_off))) return r;
+    if ((r = c.get(WS_FLAGS, 16, &d_flags))) return r;
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+    if (s == 0) HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+    if (bytes) HIPCHK(hipMemcpyAsync(d_blob, blob + off[mlo], bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, off + mlo, (mhi - mlo + 1) * 8, hipMemcpyHostToDevice, st));
+    // offsets keep their global values: the view's base is shifted instead (never dereferenced below d_blob)
+    MsgView all = {(const uint8_t*)d_blob - off[mlo], (const uint64_t*)d_off, 0, 0};
+    if (s == 0 && !allow_dups && (r = E::dup_scan(c, st, all, n, (uint32_t*)d_flags))) return r;
+    MsgView mine = all;
+    if (s == 0) mine.off = (const uint64_t*)d_off + sh.lo;      // sh.lo == 0; kept for clarity
+    if ((r = E::miller_product(c, st, s == 0 ? (const uint8_t*)d_sig : nullptr, (const uint8_t*)sh.d_wire, mine, cnt, 0,
+                               (uint8_t*)sh.d_rec, (uint32_t*)d_flags)))
+      return r;
+    HIPCHK(hipMemcpyAsync((uint8_t*)sh.d_rec + E::GTB, d_flags, 4, hipMemcpyDeviceToDevice, st));
+    if (s) HIPCHK(hipStreamSynchronize(st));       // record complete before the exchange reads it (shard 0: stream order)
+    return 0;
+  });
+  if (rc) return rc;
+  if ((rc = exchange_records<C>(ks))) return rc;
+  // shard 0: product of the S partials, one final exponentiation, compare with 1; status words OR-ed on the host
+  KeyShard& root = ks.shards[0];
+  const int pd = g_dev, ps = g_sel;
+  g_dev = root.device;
+  g_sel = 0;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  rc = [&]() -> int {
+    int r;
+    if ((r = c.enter())) return r;
+    void* d_parts;
+    if ((r = c.get(WS_HAE_KEYS, (size_t)S * E::GTB, &d_parts))) return r;
+    std::vector<uint8_t> recs((size_t)S * REC);
+    HIPCHK(hipMemcpyAsync(recs.data(), root.d_all, recs.size(), hipMemcpyDeviceToHost, c.stream));
+    for (int s = 0; s < S; ++s)
+      HIPCHK(hipMemcpyAsync((uint8_t*)d_parts + (size_t)s * E::GTB, (uint8_t*)root.d_all + (size_t)s * REC, E::GTB, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    uint32_t f = 0;
+    for (int s = 0; s < S; ++s) {
+      uint32_t w;
+      memcpy(&w, recs.data() + (size_t)s * REC + E::GTB, 4);
+      f |= w;
+    }
+    if ((r = merged_flags_rc(f))) return r;
+    r = E::finalize(c, c.stream, (const uint8_t*)d_parts, (size_t)S, 1, nullptr, gt_out);
+    if (r < 0) return r;
+    return (f & FLAG_DUP) ? 0 : r;
+  }();
+  g_dev = pd;
+  g_sel = ps;
+  return rc;
+}
+
+template <class C>
+int verify_multi_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* msg, size_t msg_len) {
+  typedef Engine<C> E;
+  std::lock_guard<std::mutex> lk_set(ks.mu);
+  const int S = (int)ks.shards.size();
+  const size_t JB = kl::jac_bytes<C>(BGLS_G2);
+  const size_t REC = E::GTB + REC_PAD;
+  static_assert(E::GTB >= 3 * 2 * C::L * 4, "a projective G2 partial fits an exchange record");
+  // per-device partial key sums (projective): the exchange record carries the Jacobian point instead of a GT partial
+  int rc = for_each_shard(ks, [&](int s) -> int {
+    KeyShard& sh = ks.shards[s];
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    int r;
+    if ((r = c.enter())) return r;
+    void* d_flags;
+    if ((r = c.get(WS_FLAGS, 16, &d_flags))) return r;
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4, c.stream));
+    HIPCHK(hipMemsetAsync(sh.d_rec, 0, REC, c.stream));
+    if ((r = E::sum_points_jac(c, c.stream, BGLS_G2, (const uint8_t*)sh.d_mont, sh.hi - sh.lo, sh.d_rec, (uint32_t*)d_flags, true))) return r;
+    if (s) HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+  });
+  if (rc) return rc;
+  if ((rc = exchange_records<C>(ks))) return rc;
+  KeyShard& root = ks.shards[0];
+  const int pd = g_dev, ps = g_sel;
+  g_dev = root.device;
+  g_sel = 0;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  rc = [&]() -> int {
+    int r;
+    if ((r = c.enter())) return r;
+    hipStream_t st = c.stream;
+    void *d_jacs, *d_tmp, *d_apk, *d_sig, *d_msg;
+    if ((r = c.get(WS_JAC_A, (size_t)(S + 64) * JB, &d_jacs))) return r;
+    if ((r = c.get(WS_JAC_B, 4 * JB, &d_tmp))) return r;
+    if ((r = c.get(WS_HAE_APK, E::G2B, &d_apk))) return r;
+    if ((r = c.get(WS_IN_A, E::G1B, &d_sig))) return r;
+    if ((r = c.get(WS_IN_C, msg_len, &d_msg))) return r;
+    for (int s = 0; s < S; ++s)
+      HIPCHK(hipMemcpyAsync((uint8_t*)d_jacs + (size_t)s * JB, (uint8_t*)root.d_all + (size_t)s * REC, JB, hipMemcpyDeviceToDevice, st));
+    void* cur = d_jacs;
+    if (S > 1) {
+      kl::sum_wave<C>(st, BGLS_G2, d_jacs, (size_t)S, d_tmp);       // S <= 16 partials: one wave
+      cur = d_tmp;
+    }
+    kl::jac_to_bytes<C>(st, BGLS_G2, cur, 1, (uint8_t*)d_apk);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
+    if (msg_len) HIPCHK(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, st));
+    return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_apk, 1, (const uint8_t*)d_msg, msg_len);
+  }();
+  g_dev = pd;
+  g_sel = ps;
+  return rc;
+}
+
 bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
 
 }  // namespace
@@ -1150,7 +1532,7 @@ bool group_ok(int g) { return g == BGLS_G1 || g == BGLS_G2; }
 // ======================================================================= C ABI
 extern "C" {
 
-int bgls_abi_version(void) { return 1; }
+int bgls_abi_version(void) { return 2; }
 
 const char* bgls_last_error(void) { return g_err.c_str(); }
 
@@ -1214,6 +1596,98 @@ int bgls_point_check(int curve, int group, const uint8_t* a) {
   if (!group_ok(group) || !a) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, point_check_t<CV>(group, a));
 }
+
+int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out) {
+  if (!group_ok(group) || (n && (!pts || !ok_out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, check_points_t<CV>(group, pts, n, ok_out));
+}
+
+int bgls_select_device(int device) {
+  if (device < -1 || device >= MAX_DEVICES) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
+  g_dev = device;
+  return 0;
+}
+
+int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out) {
+  if (!handle_out || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (n_devices < 1 || n_devices > NCTX) return fail(BGLS_ERR_ARG, "n_devices out of range (1..16)");
+  int dflt = cur_device();
+  if (!devices && n_devices == 1) devices = &dflt;
+  DISPATCH(curve, keys_upload_t<CV>(keys, n, devices, n_devices, flags, handle_out));
+}
+
+int bgls_keys_free(bgls_keys_t handle) {
+  std::shared_ptr<KeySet> ks;
+  {
+    std::lock_guard<std::mutex> lk(g_keys_mu);
+    auto it = g_keys.find(handle);
+    if (it == g_keys.end()) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+    ks = it->second;
+    g_keys.erase(it);
+  }
+  std::lock_guard<std::mutex> lk(ks->mu);      // wait for a verification in progress
+  return 0;
+}
+
+int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (curve) *curve = ks->curve;
+  if (n) *n = ks->n;
+  if (n_devices) *n_devices = (int)ks->shards.size();
+  return 0;
+}
+
+int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
+                            int allow_duplicates) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (!sig || !msg_off) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(ks->curve, verify_aggregate_h_t<CV>(*ks, sig, msg_blob, msg_off, n, allow_duplicates, nullptr));
+}
+
+int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
+                               int allow_duplicates, uint8_t* gt_out) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (!sig || !msg_off || !gt_out) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(ks->curve, verify_aggregate_h_t<CV>(*ks, sig, msg_blob, msg_off, n, allow_duplicates, gt_out));
+}
+
+int bgls_rccl_available(void) { return rccl().ok ? 1 : 0; }
+
+int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (!sig || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(ks->curve, verify_multi_h_t<CV>(*ks, sig, msg, msg_len));
+}
+
+int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                                size_t n, int allow_duplicates, const int* devices, int n_devices) {
+  bgls_keys_t h;
+  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
+  if (rc) return rc;
+  rc = bgls_verify_aggregate_h(h, sig, msg_blob, msg_off, n, allow_duplicates);
+  const int ex = g_last_exchange;
+  (void)bgls_keys_free(h);
+  g_last_exchange = ex;
+  return rc;
+}
+
+int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len,
+                            const int* devices, int n_devices) {
+  bgls_keys_t h;
+  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
+  if (rc) return rc;
+  rc = bgls_verify_multi_h(h, sig, msg, msg_len);
+  const int ex = g_last_exchange;
+  (void)bgls_keys_free(h);
+  g_last_exchange = ex;
+  return rc;
+}
+
+int bgls_last_exchange(void) { return g_last_exchange; }
 
 int bgls_generator(int curve, int group, uint8_t* out) {
   if (!group_ok(group) || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");

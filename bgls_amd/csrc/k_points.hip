@@ -301,6 +301,7 @@ __global__ void __launch_bounds__(64) k_decompress_bn(const uint8_t* in, size_t 
   } else {
     Aff<F2<C>> p;
     good = g2_decompress<C>(p, in + i * CB);
+    good = good && g2_in_subgroup<C>(p);                   // UnmarshalG2 rejects twist points outside G2 (upstream G2.Unmarshal)
     if (good) g2_to_bytes<C>(out + i * UB, p);
   }
   if (!good)
@@ -384,14 +385,34 @@ __global__ void __launch_bounds__(64) k_scale_aff(const Aff<F>* pts, const uint8
   aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul<F>(p, k, top + 1)));
 }
 
-template <class F, int PT_BYTES>
-__global__ void k_check(const uint8_t* pts, size_t n, uint32_t* flags) {
+// validity of n points: canonical coordinates, on the curve and, for G2, in the order-r subgroup (what the reference
+// checks when a Point is constructed, see g2_in_subgroup).  ok == nullptr: failures only set flags; else ok[i] = 1 / 0.
+template <class C, class F, int PT_BYTES>
+__global__ void __launch_bounds__(64) k_check(const uint8_t* pts, size_t n, uint32_t* flags, uint8_t* ok_out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff<F> p;
   bool ok = aff_from_bytes<F>(p, pts + i * PT_BYTES);
   ok = ok && aff_on_curve<F>(p);
+  uint32_t f = ok ? 0u : FLAG_ENC;
+  if constexpr (F::NFP == 2) {
+    if (ok && !g2_in_subgroup<C>(p)) { ok = false; f = FLAG_SUBGROUP; }
+  }
+  if (f) atomicOr(flags, f);
+  if (ok_out) ok_out[i] = ok ? 1 : 0;
+}
+
+// key-set upload: wire bytes -> resident Montgomery affine points; invalid keys set FLAG_ENC / FLAG_SUBGROUP
+template <class C>
+__global__ void __launch_bounds__(64) k_g2_parse(const uint8_t* in, size_t n, int check_subgroup, Aff<F2<C>>* out, uint32_t* flags) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F2<C>> p;
+  bool ok = g2_from_bytes<C>(p, in + i * 4 * C::FP_BYTES);
+  ok = ok && aff_on_curve<F2<C>>(p);
   if (!ok) atomicOr(flags, FLAG_ENC);
+  else if (check_subgroup && !g2_in_subgroup<C>(p)) atomicOr(flags, FLAG_SUBGROUP);
+  out[i] = p;
 }
 
 template <class C>
@@ -485,10 +506,16 @@ void scale_aff(hipStream_t st, int group, const Aff<F1<C>>* g1_pts, const uint8_
   else k_scale_aff<C, F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(nullptr, scalars, n, out);
 }
 template <class C>
-void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags) {
-  if (group == BGLS_G1) k_check<F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags);
-  else k_check<F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags);
+void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags, uint8_t* ok) {
+  if (group == BGLS_G1) k_check<C, F1<C>, 2 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags, ok);
+  else k_check<C, F2<C>, 4 * C::FP_BYTES><<<nblk(n, 64), 64, 0, st>>>(pts, n, flags, ok);
 }
+template <class C>
+void g2_parse(hipStream_t st, const uint8_t* in, size_t n, int check_subgroup, void* out, uint32_t* flags) {
+  k_g2_parse<C><<<nblk(n, 64), 64, 0, st>>>(in, n, check_subgroup, (Aff<F2<C>>*)out, flags);
+}
+template <class C>
+size_t g2_parsed_bytes() { return sizeof(Aff<F2<C>>); }
 template <class C>
 void generator(hipStream_t st, int group, uint8_t* out) {
   k_generator<C><<<1, 64, 0, st>>>(group, out);
@@ -517,7 +544,9 @@ void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed,
   template void wsum_first<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, void*, uint32_t*);       \
   template void scale<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint32_t*, int);    \
   template void scale_aff<C>(hipStream_t, int, const Aff<F1<C>>*, const uint8_t*, size_t, uint8_t*);                             \
-  template void check<C>(hipStream_t, int, const uint8_t*, size_t, uint32_t*);                                                   \
+  template void check<C>(hipStream_t, int, const uint8_t*, size_t, uint32_t*, uint8_t*);                                                  \
+  template void g2_parse<C>(hipStream_t, const uint8_t*, size_t, int, void*, uint32_t*);                                         \
+  template size_t g2_parsed_bytes<C>();                                                                                          \
   template void generator<C>(hipStream_t, int, uint8_t*);
 BGLS_INST(BN254)
 BGLS_INST(BLS381)

@@ -24,7 +24,9 @@ template <class C> void jac_to_bytes(hipStream_t st, int group, const void* in, 
 template <class C> void wsum_first(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, void* out, uint32_t* flags);
 template <class C> void scale(hipStream_t st, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out, uint32_t* flags, int sbytes);
 template <class C> void scale_aff(hipStream_t st, int group, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out);
-template <class C> void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags);
+template <class C> void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags, uint8_t* ok);
+template <class C> void g2_parse(hipStream_t st, const uint8_t* in, size_t n, int check_subgroup, void* out, uint32_t* flags);
+template <class C> size_t g2_parsed_bytes();
 template <class C> void generator(hipStream_t st, int group, uint8_t* out);
 void compress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags);
 void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);

@@ -45,14 +45,17 @@ extern "C" {
 #define BGLS_G2 2
 
 #define BGLS_ERR_ARG (-1)       /* bad curve/group id, NULL pointer, inconsistent offsets */
-#define BGLS_ERR_ENCODING (-2)  /* a coordinate >= q, or a point not on its curve */
+#define BGLS_ERR_ENCODING (-2)  /* a coordinate >= q, a point not on its curve, or (where checked) a G2 point outside the subgroup */
 #define BGLS_ERR_HASH (-3)      /* try-and-increment exhausted 256 counters (probability 2^-256) */
 #define BGLS_ERR_NO_DEVICE (-4) /* no usable HIP device */
 #define BGLS_ERR_HIP (-5)       /* a HIP runtime call failed; see bgls_last_error() */
 
 /* ---- runtime ---------------------------------------------------------------------------- */
-/* Select the HIP device used by the calling process (default 0).  Idempotent. */
+/* Select the default HIP device of the calling process (default 0) and bring it up.  May be called again with another
+ * device; contexts, workspaces and key sets of devices used earlier stay valid. */
 int bgls_init(int device);
+/* Device used by the calling thread's subsequent calls (-1 = the process default set by bgls_init). */
+int bgls_select_device(int device);
 /* Human-readable text for the last error on this thread ("" if none). */
 const char* bgls_last_error(void);
 /* ABI version; bumped on any signature change. */
@@ -64,6 +67,11 @@ size_t bgls_g2_size(int curve); /* 128 / 192 */
 size_t bgls_gt_size(int curve); /* 384 / 576 */
 
 /* ---- the hot path, host buffers ------------------------------------------------------------ */
+/* The Verify* entry points take keys as the reference's Verify* functions take Points: already constructed, i.e.
+ * validated by MakeG2Point / UnmarshalG2 (here: bgls_point_check, bgls_check_points, bgls_decompress_points or
+ * bgls_keys_upload with BGLS_KEYS_CHECK).  They re-check canonical encoding and curve membership of every key (an
+ * encoding error is BGLS_ERR_ENCODING, never an accept) but not G2 subgroup membership, exactly as bgls.Verify*
+ * does not re-validate its Point arguments. */
 
 /* bgls.VerifyAggregateSignature (bgls/bgls.go:82-84) -> verifyAggSig (bgls/bgls.go:94-119).
  * keys: n G2 points; messages: msg_blob[msg_off[i] .. msg_off[i+1]), i < n (msg_off has n+1
@@ -149,6 +157,10 @@ int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uin
 /* MakeG1Point/MakeG2Point/Unmarshal* validation (curves/altbn128.go:42-57,157-179;
  * curves/bls12_381.go:196-226): 1 if canonical and on the curve, 0 otherwise. */
 int bgls_point_check(int curve, int group, const uint8_t* a);
+/* The same validation over a batch (what constructing n Points costs in the reference: MakeG1Point / MakeG2Point with
+ * check, UnmarshalG1 / UnmarshalG2; curves/altbn128.go:149-179,296-376, curves/bls12_381.go:196-264): ok_out[i] = 1 iff
+ * point i has canonical coordinates, lies on its curve and -- G2 -- in the order-r subgroup.  Returns 0 or < 0. */
+int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out);
 /* GetG1 / GetG2 (curves/altbn128.go:423-429, curves/bls12_381.go:275-281) */
 int bgls_generator(int curve, int group, uint8_t* out);
 /* CurveSystem.Pair (curves/altbn128.go:130-141, curves/bls12_381.go:228-236) */
@@ -213,6 +225,43 @@ int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_key
                                  size_t msg_len, void* stream);
 
 /* ---- measurement hooks (bench.py; not part of the reference's interface) ------------------ */
+/* ---- device-resident key sets (opaque handles so keys uploaded once are verified many times) -------------
+ * A key set is n G2 public keys, parsed and validated once, resident in HBM as Montgomery-form affine points next to
+ * their wire bytes, cut into contiguous ranges over n_devices GPUs (devices[] lists them; NULL = 0 .. n_devices-1; an id
+ * may repeat, which is how the multi-device code is exercised on a one-GPU box).  This is what the Go shim's
+ * altbn128Point2 / bls12Point2 slices become (curves/altbn128.go:19-29, curves/bls12_381.go:18-28): the shim uploads a
+ * []Point once, keeps the handle (runtime.SetFinalizer -> bgls_keys_free) and passes it to every Verify*.
+ * flags: BGLS_KEYS_CHECK also requires every key to lie in the order-r subgroup (the reference's construction-time
+ * check); any invalid key fails the upload with BGLS_ERR_ENCODING. */
+typedef uint64_t bgls_keys_t;
+#define BGLS_KEYS_CHECK 1u
+int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out);
+int bgls_keys_free(bgls_keys_t handle);
+int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices);
+/* verifyAggSig (bgls/bgls.go:94-119) against a resident key set: message i belongs to key i; n must equal the set's size.
+ * Every device of the set hashes its message range and multiplies its Miller values (one host thread per device), the
+ * 384 / 576-byte partial products and status words meet on the first device (ncclAllGather over the devices' streams
+ * when RCCL is usable and the devices are distinct, peer copies otherwise), which runs the single final exponentiation.
+ * Same GT element, hence the same verdict, for any number of devices. */
+int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
+                            int allow_duplicates);
+/* The same verification, also returning the GT element e(-sig, g2) * prod_i e(H(m_i), pk_i) (the PairingProduct value of
+ * bgls/bgls.go:113-114; the identity iff the verdict is 1): canonical bytes, identical for any number of devices. */
+int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
+                               int allow_duplicates, uint8_t* gt_out);
+/* verifyMultiSignature (bgls/bgls.go:89-92) against a resident key set: per-device partial key sums (projective G2
+ * points) are gathered on the first device, added, and the two-pairing check runs there. */
+int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len);
+/* The same two calls with host keys, for callers without a resident set: upload, verify, free. */
+int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
+                                size_t n, int allow_duplicates, const int* devices, int n_devices);
+int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len,
+                            const int* devices, int n_devices);
+/* Which exchange the last multi-device call on this thread used: 0 none (one device), 1 peer / device copies, 2 RCCL. */
+int bgls_last_exchange(void);
+/* 1 if librccl was found and its entry points resolved (dlopen at first use), else 0. */
+int bgls_rccl_available(void);
+
 /* Per-stage device time, measured with HIP events on the stream the kernels are launched on.
  * Stages: "dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points". */
 int bgls_profile_enable(int on); /* also resets the counters */

@@ -518,3 +518,15 @@ int FN(scale_point)(int group, const uint8_t* pt, const uint8_t* k_be32, int neg
   else { g2a p, r; if (!g2_read(&p, pt)) return -2; if (negative && !p.inf) f2_neg(&p.y, &p.y); g2_mul(&r, &p, k, 256); g2_write(out, &r); }
   return 0;
 }
+/* G2 membership by the DEFINITION: canonical coordinates, on the twist y^2 = x^3 + b', and [r]Q = infinity.  What the
+ * reference gets from upstream when a G2 Point is constructed (curves/altbn128.go:157-179,329-376 -> bn256 G2.Unmarshal;
+ * curves/bls12_381.go:242-264 Check()).  1 = member, 0 = not, -2 = non-canonical encoding. */
+int FN(g2_in_subgroup)(const uint8_t* pt) {
+  g2a p, r; if (!g2_read(&p, pt)) return -2;
+  if (p.inf) return 1;
+  fp2 l, rr, b2; f2_load(&b2, CB2);
+  f2_sqr(&l, &p.y); f2_sqr(&rr, &p.x); f2_mul(&rr, &rr, &p.x); f2_add(&rr, &rr, &b2);
+  if (!f2_eq(&l, &rr)) return 0;
+  g2_mul(&r, &p, ORDER, 256);
+  return r.inf ? 1 : 0;
+}

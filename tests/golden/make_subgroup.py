@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/subgroup_{altbn128,bls12}.json from the Python oracle (oracle/pyref/subgroup.py): G2 wire-format
+points with the verdict of the DEFINITION of subgroup membership (on the twist and [r]Q = infinity).  Run from the repo
+root: python tests/golden/make_subgroup.py"""
+import json, os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.pyref.params import BN254, BLS381
+from oracle.pyref.subgroup import Subgroup, factor
+
+for cv in (BN254, BLS381):
+    S = Subgroup(cv)
+    G = S.G
+    rnd = random.Random(0x5B6 + len(cv.name))
+    N = S.twist_order()
+    fs = factor(N // cv.r)
+    rows = []
+
+    def add(Q, note):
+        rows.append({"pt": G.g2_bytes(Q).hex(), "on_twist": G.g2_on_curve(Q), "in_subgroup": S.in_subgroup(Q), "note": note})
+
+    add(None, "infinity")
+    for k in (1, 2, 3, 0xDEADBEEF, cv.r - 1, rnd.randrange(cv.r)):
+        add(G.g2_mul(cv.g2, k), "[k]g2")
+    for _ in range(4):
+        add(S.random_twist_point(rnd), "random point of E'(Fp2)")
+    for q in sorted(set(fs)):
+        e = fs.count(q)
+        P = S.small_order_point(rnd, N, q, e)
+        add(P, "point of order %s" % (q if q < 1 << 40 else "a %d-bit prime" % q.bit_length()))
+        add(G.g2_add(G.g2_mul(cv.g2, rnd.randrange(1, cv.r)), P), "subgroup point + point of order %s" % (q if q < 1 << 40 else "a %d-bit prime" % q.bit_length()))
+    add(G.g2_mul(S.random_twist_point(rnd), cv.r), "[r] random: in the cofactor part")
+    add(G.g2_mul(S.random_twist_point(rnd), N // cv.r), "[cofactor] random: back in G2")
+    bad = bytearray(G.g2_bytes(G.g2_mul(cv.g2, 5))); bad[-1] ^= 1
+    rows.append({"pt": bytes(bad).hex(), "on_twist": False, "in_subgroup": False, "note": "off the twist"})
+    assert any(r["in_subgroup"] for r in rows) and any(r["on_twist"] and not r["in_subgroup"] for r in rows)
+    for r in rows:      # the endomorphism criterion agrees with the definition on every row
+        if r["on_twist"]:
+            assert S.in_subgroup_fast(G.g2_from_bytes(bytes.fromhex(r["pt"]))) == r["in_subgroup"], r["note"]
+    json.dump({"curve": cv.name, "twist_order_bits": N.bit_length(), "cofactor_factors": [str(q) for q in fs], "points": rows},
+              open(os.path.join(ROOT, "tests", "golden", "subgroup_%s.json" % cv.name), "w"), indent=1)
+    print(cv.name, len(rows), "points;", sum(r["in_subgroup"] for r in rows), "in the subgroup")

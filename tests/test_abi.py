@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported():
 def test_sizes_and_identity():
     from bgls_amd import _lib
     lib = _lib.load()
-    assert lib.bgls_abi_version() == 1
+    assert lib.bgls_abi_version() == 2
     assert [lib.bgls_fp_size(c) for c in (0, 1, 7)] == [32, 48, 0]
     assert (lib.bgls_g1_size(0), lib.bgls_g2_size(0), lib.bgls_gt_size(0)) == (64, 128, 384)
     assert (lib.bgls_g1_size(1), lib.bgls_g2_size(1), lib.bgls_gt_size(1)) == (96, 192, 576)

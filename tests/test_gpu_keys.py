@@ -1,0 +1,194 @@
+"""GPU tier: point validation (G2 subgroup membership), device-resident key sets and the multi-device entry points.
+
+The multi-device code is exercised on this one-GPU box by listing device 0 several times (one host thread, context and
+stream per shard; partials gathered by device copies); with distinct devices the same code uses peer copies or RCCL."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import coracle
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+ORDER = {0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+         1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+
+
+def B(b):
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
+
+
+def out(n):
+    return (ctypes.c_uint8 * max(1, n))()
+
+
+def offsets(msgs):
+    off = (ctypes.c_uint64 * (len(msgs) + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        off[i] = acc
+        acc += len(m)
+    off[len(msgs)] = acc
+    return off
+
+
+def devs(k):
+    return (ctypes.c_int * k)(*([0] * k))
+
+
+def test_g2_subgroup_fixture(gpu_lib, curve):
+    """bgls_point_check / bgls_check_points on the fixture of tests/golden/make_subgroup.py: points of G2, random points
+    of the twist, points of every prime order dividing the twist's cofactor, and G2 points shifted by such points."""
+    cid, fp = curve["id"], curve["fp"]
+    rows = load_golden("subgroup_%s.json" % curve["name"])["points"]
+    pts = b"".join(bytes.fromhex(r["pt"]) for r in rows)
+    ok = out(len(rows))
+    assert gpu_lib.bgls_check_points(cid, 2, B(pts), len(rows), ok) == 0
+    for r, got in zip(rows, bytes(ok)):
+        assert bool(got) == r["in_subgroup"], r["note"]
+        assert gpu_lib.bgls_point_check(cid, 2, B(bytes.fromhex(r["pt"]))) == (1 if r["in_subgroup"] else 0), r["note"]
+        assert coracle.g2_in_subgroup(cid, bytes.fromhex(r["pt"])) == (1 if r["in_subgroup"] else 0), r["note"]
+    # G1 has cofactor 1 (alt-bn128) / is checked for curve membership only, as the reference's MakeG1Point does
+    g1 = out(2 * fp); gpu_lib.bgls_generator(cid, 1, g1)
+    ok1 = out(2)
+    assert gpu_lib.bgls_check_points(cid, 1, B(bytes(g1) + bytes(2 * fp)), 2, ok1) == 0 and bytes(ok1) == b"\x01\x01"
+
+
+def test_g2_subgroup_random_vs_oracle(gpu_lib, curve):
+    """Random G2 points, and the same points with one coordinate bit flipped (almost never on the twist; those that are,
+    are outside G2): identical verdicts from the HIP criterion and the oracle's [r]Q test."""
+    cid, fp = curve["id"], curve["fp"]
+    rnd = random.Random(99 + cid)
+    g2 = out(4 * fp); gpu_lib.bgls_generator(cid, 2, g2)
+    n = 48
+    keys = out(n * 4 * fp)
+    ks = b"".join(rnd.randrange(1, ORDER[cid]).to_bytes(32, "big") for _ in range(n))
+    assert gpu_lib.bgls_scale_generator(cid, 2, B(ks), n, keys) == 0
+    rows = load_golden("subgroup_%s.json" % curve["name"])["points"]
+    off_sub = [bytes.fromhex(r["pt"]) for r in rows if r["on_twist"] and not r["in_subgroup"]]
+    pts = [bytes(keys[i * 4 * fp:(i + 1) * 4 * fp]) for i in range(n)]
+    # sums of a subgroup point and an off-subgroup twist point, through the engine's own G2 addition
+    for i in range(8):
+        s = out(4 * fp)
+        assert gpu_lib.bgls_point_add(cid, 2, B(pts[i]), B(off_sub[i % len(off_sub)]), s) == 0
+        pts.append(bytes(s))
+    ok = out(len(pts))
+    assert gpu_lib.bgls_check_points(cid, 2, B(b"".join(pts)), len(pts), ok) == 0
+    want = [coracle.g2_in_subgroup(cid, p) for p in pts]
+    assert list(bytes(ok)) == want and want[:n] == [1] * n and 0 in want[n:]
+
+
+def test_decompress_rejects_off_subgroup_points(gpu_lib):
+    """UnmarshalG2 (curves/altbn128.go:329-376) goes through upstream's G2.Unmarshal, which rejects twist points outside
+    the subgroup: compress the fixture's on-twist points and decompress them again."""
+    rows = [r for r in load_golden("subgroup_altbn128.json")["points"] if r["on_twist"] and r["note"] != "infinity"]
+    pts = b"".join(bytes.fromhex(r["pt"]) for r in rows)
+    comp = out(64 * len(rows))
+    assert gpu_lib.bgls_compress_points(0, 2, B(pts), len(rows), comp) == 0
+    back, ok = out(128 * len(rows)), out(len(rows))
+    assert gpu_lib.bgls_decompress_points(0, 2, comp, len(rows), back, ok) == 0
+    for i, r in enumerate(rows):
+        assert bool(ok[i]) == r["in_subgroup"], r["note"]
+        if r["in_subgroup"]:
+            assert bytes(back[128 * i:128 * (i + 1)]).hex() == r["pt"]
+
+
+def make_instance(lib, cid, fp, n, seed):
+    rnd = random.Random(seed)
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+    kb = b"".join(s.to_bytes(32, "big") for s in sks)
+    keys = out(n * 4 * fp)
+    assert lib.bgls_scale_generator(cid, 2, B(kb), n, keys) == 0
+    msgs = [rnd.randbytes(rnd.choice((8, 32, 64, 65))) for _ in range(n)]
+    sigs = out(n * 2 * fp)
+    assert lib.bgls_sign_batch(cid, B(kb), B(b"".join(msgs)), offsets(msgs), n, sigs) == 0
+    agg = out(2 * fp)
+    assert lib.bgls_aggregate_points(cid, 1, sigs, n, agg) == 0
+    return sks, bytes(keys), msgs, bytes(sigs), bytes(agg)
+
+
+def test_key_set_aggregate_verify_any_sharding(gpu_lib, curve):
+    """bgls_keys_upload + bgls_verify_aggregate_h over 1, 2, 4 and 8 shards: same verdicts as the host-buffer call and
+    the oracle, identical GT bytes for every sharding, duplicates that straddle shards rejected, status of one shard
+    (a key that is not on the twist) reaching the verdict."""
+    lib, cid, fp = gpu_lib, curve["id"], curve["fp"]
+    n = 333
+    sks, keys, msgs, sigs, agg = make_instance(lib, cid, fp, n, 4711 + cid)
+    blob, off = b"".join(msgs), offsets(msgs)
+    assert coracle.verify_aggregate(cid, agg, keys, msgs, threads=8) == 1
+    assert lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(blob), off, n, 0) == 1
+    bad = list(msgs); bad[200] = bytes([bad[200][0] ^ 4]) + bad[200][1:]
+    # a valid instance with msgs[170] == msgs[5] (copies in different shards for 2, 4 and 8 shards)
+    dup = list(msgs); dup[170] = dup[5]
+    h5 = coracle.hash_to_g1(cid, msgs[5])
+    three = agg + coracle.scale_point(cid, 1, sigs[2 * fp * 170:2 * fp * 171], ORDER[cid] - 1) + coracle.scale_point(cid, 1, h5, sks[170])
+    agg_dup = out(2 * fp)
+    assert lib.bgls_aggregate_points(cid, 1, B(three), 3, agg_dup) == 0
+    wrong_sig = sigs[:2 * fp]                      # a valid G1 point that is not the aggregate: GT value != 1
+    gts = []
+    for shards in (1, 2, 4, 8):
+        h = ctypes.c_uint64()
+        assert lib.bgls_keys_upload(cid, B(keys), n, devs(shards), shards, 1, ctypes.byref(h)) == 0
+        cv, cnt, nd = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int()
+        assert lib.bgls_keys_info(h, ctypes.byref(cv), ctypes.byref(cnt), ctypes.byref(nd)) == 0
+        assert (cv.value, cnt.value, nd.value) == (cid, n, shards)
+        assert lib.bgls_verify_aggregate_h(h, B(agg), B(blob), off, n, 0) == 1
+        assert lib.bgls_last_exchange() == (0 if shards == 1 else 1)
+        assert lib.bgls_verify_aggregate_h(h, B(agg), B(b"".join(bad)), offsets(bad), n, 0) == 0
+        assert lib.bgls_verify_aggregate_h(h, agg_dup, B(b"".join(dup)), offsets(dup), n, 1) == 1      # allowDuplicates
+        assert lib.bgls_verify_aggregate_h(h, agg_dup, B(b"".join(dup)), offsets(dup), n, 0) == 0      # the duplicate rule
+        assert lib.bgls_verify_aggregate_h(h, B(agg), B(blob), off, n - 1, 0) < 0                       # length mismatch
+        gt = out(12 * fp)
+        assert lib.bgls_verify_aggregate_h_gt(h, B(wrong_sig), B(blob), off, n, 0, gt) == 0
+        gts.append(bytes(gt))
+        assert lib.bgls_keys_free(h) == 0
+        assert lib.bgls_keys_free(h) < 0 and lib.bgls_verify_aggregate_h(h, B(agg), B(blob), off, n, 0) < 0
+        assert lib.bgls_verify_aggregate_multi(cid, B(agg), B(keys), B(blob), off, n, 0, devs(shards), shards) == 1
+    assert len(set(gts)) == 1 and gts[0] != bytes(12 * fp - 1) + b"\x01"
+    # the GT value is the oracle's: e(-wrong, g2) * prod e(H(m_i), pk_i)
+    g2 = out(4 * fp); lib.bgls_generator(cid, 2, g2)
+    hs = b"".join(coracle.hash_to_g1(cid, m) for m in msgs)
+    neg = coracle.scale_point(cid, 1, wrong_sig, ORDER[cid] - 1)
+    assert gts[0] == coracle.pairing_product(cid, hs + neg, keys + bytes(g2), n + 1, threads=8)
+    # upload-time validation: an off-subgroup key fails BGLS_KEYS_CHECK, an off-twist key fails any upload
+    rows = load_golden("subgroup_%s.json" % curve["name"])["points"]
+    off_sub = next(bytes.fromhex(r["pt"]) for r in rows if r["on_twist"] and not r["in_subgroup"])
+    kk = bytearray(keys); kk[4 * fp * 300:4 * fp * 301] = off_sub
+    h = ctypes.c_uint64()
+    assert lib.bgls_keys_upload(cid, B(bytes(kk)), n, devs(4), 4, 1, ctypes.byref(h)) == -2
+    assert lib.bgls_keys_upload(cid, B(bytes(kk)), n, devs(4), 4, 0, ctypes.byref(h)) == 0 and lib.bgls_keys_free(h) == 0
+    kk[4 * fp * 300 + 5] ^= 0x10
+    assert lib.bgls_keys_upload(cid, B(bytes(kk)), n, devs(4), 4, 0, ctypes.byref(h)) == -2
+    assert lib.bgls_verify_aggregate_multi(cid, B(agg), B(bytes(kk)), B(blob), off, n, 0, devs(4), 4) == -2
+
+
+def test_key_set_multisig_any_sharding(gpu_lib, curve):
+    """bgls_verify_multi_h: per-shard projective key sums gathered and added on the first device (SURVEY 8e multisig
+    variant); same verdicts for 1, 2, 4, 8 shards, ragged sizes, a key listed twice (the doubling case of the sum)."""
+    lib, cid, fp = gpu_lib, curve["id"], curve["fp"]
+    rnd = random.Random(31 + cid)
+    for n in (1, 7, 1000):
+        sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+        if n > 5:
+            sks[n - 2] = sks[1]                       # the same signer twice
+        keys = out(n * 4 * fp)
+        assert lib.bgls_scale_generator(cid, 2, B(b"".join(s.to_bytes(32, "big") for s in sks)), n, keys) == 0
+        msg = rnd.randbytes(40)
+        sig = coracle.scale_point(cid, 1, coracle.hash_to_g1(cid, msg), sum(sks) % ORDER[cid])
+        assert coracle.verify_multi(cid, sig, bytes(keys), n, msg) == 1
+        for shards in (1, 2, 4, 8):
+            h = ctypes.c_uint64()
+            assert lib.bgls_keys_upload(cid, keys, n, devs(shards), shards, 0, ctypes.byref(h)) == 0
+            assert lib.bgls_verify_multi_h(h, B(sig), B(msg), len(msg)) == 1, (n, shards)
+            assert lib.bgls_verify_multi_h(h, B(sig), B(msg + b"x"), len(msg) + 1) == 0
+            assert lib.bgls_keys_free(h) == 0
+            assert lib.bgls_verify_multi_multi(cid, B(sig), keys, n, B(msg), len(msg), devs(shards), shards) == 1
+        if n > 1:
+            assert lib.bgls_verify_multi_multi(cid, B(sig), keys, n - 1, B(msg), len(msg), devs(2), 2) == 0
+
+
+def test_rccl_is_loadable(gpu_lib):
+    """The exchange uses RCCL when the devices of a key set are distinct; on a one-GPU box only its loading can be checked."""
+    assert gpu_lib.bgls_rccl_available() == 1

@@ -129,3 +129,20 @@ def test_scheme_accept_reject_pyref():
     assert not scheme.verify_aggregate_signature(c, agg, keys[:2], msgs)
     assert not scheme.verify_aggregate_signature(c, agg, keys, [msgs[1], msgs[0], msgs[2]])
     assert not scheme.verify_aggregate_signature(c, agg, keys, [msgs[0], msgs[0], msgs[2]])
+
+
+def test_subgroup_fixture_and_criterion():
+    """G2 subgroup membership: the C oracle's definition ([r]Q = infinity) on the committed fixture, and the proof that the
+    endomorphism criterion used by the HIP kernels accepts exactly G2 on both curves (every prime-order component of the
+    twist's cofactor part is rejected; oracle/pyref/subgroup.py)."""
+    from oracle import coracle
+    from oracle.pyref.params import BN254, BLS381
+    from oracle.pyref.subgroup import criterion_is_exact
+    from tests.conftest import load_golden
+    for cid, cv in ((0, BN254), (1, BLS381)):
+        fx = load_golden("subgroup_%s.json" % cv.name)
+        for r in fx["points"]:
+            assert coracle.g2_in_subgroup(cid, bytes.fromhex(r["pt"])) == (1 if r["in_subgroup"] else 0), r["note"]
+        exact, report = criterion_is_exact(cv)
+        assert exact, report
+        assert sorted(str(q) for q in fx["cofactor_factors"]) == sorted(fx["cofactor_factors"]) and len(report) == len(set(fx["cofactor_factors"]))

@@ -74,6 +74,12 @@ def emit(cname, cid, L, p, r, b, xi, twist, loop, extra):
             g += limbs(M(cur[0]), L) + limbs(M(cur[1]), L)
             cur = f2.mul(cur, g1)
     o += arr("GAMMA", g)
+    # psi = twist o Frobenius o untwist on E'(Fp2): psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y) with
+    # PSI_X = xi^((p-1)/3), PSI_Y = xi^((p-1)/2) on a D-type twist and their inverses on an M-type twist (subgroup test)
+    px, py = f2.pow(xi, (p - 1) // 3), f2.pow(xi, (p - 1) // 2)
+    if twist != "D":
+        px, py = f2.inv(px), f2.inv(py)
+    o += arr("PSI_X", limbs(M(px[0]), L) + limbs(M(px[1]), L)) + arr("PSI_Y", limbs(M(py[0]), L) + limbs(M(py[1]), L))
     o += arr("EXP_SQRT", limbs((p + 1) // 4, L))   # calcQuadRes exponent, hash.go:178-190
     o += arr("EXP_INV", limbs(p - 2, L))
     o += arr("ORDER", limbs(r, 8))
