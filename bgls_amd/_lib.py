@@ -54,6 +54,7 @@ SIGNATURES = {
     "bgls_generator": (ci, [ci, ci, u8p]),
     "bgls_pair": (ci, [ci, u8p, u8p, u8p]),
     "bgls_gt_mul": (ci, [ci, u8p, u8p, u8p]),
+    "bgls_gt_pow": (ci, [ci, u8p, u8p, ci, u8p]),
     "bgls_gt_identity": (ci, [ci, u8p]),
     "bgls_miller_product_dev": (ci, [ci, vp, vp, vp, sz, sz, sz, ci, vp, vp, vp]),
     "bgls_duplicate_scan_dev": (ci, [vp, sz, sz, sz, vp, vp]),

@@ -3,7 +3,7 @@
 import ctypes
 import secrets
 from . import _lib
-from .curves import AggregatePoints, ScalePoints, Point, G1, G2
+from .curves import _reduce_scalar, AggregatePoints, ScalePoints, Point, G1, G2
 
 
 def KeyGen(curve):                                   # bgls/bgls.go:30-37
@@ -31,21 +31,62 @@ def AggregateKeys(keys):                             # bgls/bgls.go:129-131
     return AggregatePoints(keys)
 
 
-def _verify_agg(curve, aggsig, keys, msgs, allow_duplicates):
-    if len(keys) != len(msgs):                       # bgls/bgls.go:95-97
-        return False
-    n = len(keys)
-    for k in keys:
-        if not (isinstance(k, Point) and k.curve is curve and k.group == G2):
-            return False
-    if not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
-        return False
-    off = (ctypes.c_uint64 * (n + 1))()
+class KeySet:
+    """n public keys resident on the GPU(s) behind a bgls_keys_t handle (include/bgls_hip.h): what a []Point of public
+    keys becomes in the Go shim.  Accepted wherever the Verify* functions take `keys`.  check = the construction-time
+    validation of MakeG2Point / UnmarshalG2 (subgroup membership included); devices = one entry per shard."""
+
+    def __init__(self, curve, keys, devices=None, check=True):
+        raw = b"".join(k.raw for k in keys) if keys and isinstance(keys[0], Point) else bytes(keys)
+        n = len(raw) // (4 * curve.fp_bytes)
+        devs = list(devices) if devices else [0]
+        h = ctypes.c_uint64()
+        rc = _lib.load().bgls_keys_upload(curve.id, _lib.buf(raw), n, (ctypes.c_int * len(devs))(*devs), len(devs), 1 if check else 0,
+                                          ctypes.byref(h))
+        if rc != 0:
+            raise ValueError("bgls_keys_upload: %d %s" % (rc, _lib.last_error()))
+        self.curve, self.n, self.handle = curve, n, h.value
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self.handle:
+            _lib.load().bgls_keys_free(self.handle)
+            self.handle = 0
+
+    def __del__(self):                                # the Go shim's runtime.SetFinalizer
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _offsets(msgs):
+    off = (ctypes.c_uint64 * (len(msgs) + 1))()
     acc = 0
     for i, m in enumerate(msgs):
         off[i] = acc
         acc += len(m)
-    off[n] = acc
+    off[len(msgs)] = acc
+    return off
+
+
+def _verify_agg(curve, aggsig, keys, msgs, allow_duplicates):
+    if len(keys) != len(msgs):                       # bgls/bgls.go:95-97
+        return False
+    n = len(keys)
+    if not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False
+    if isinstance(keys, KeySet):
+        if keys.curve is not curve:
+            return False
+        return _lib.load().bgls_verify_aggregate_h(keys.handle, _lib.buf(aggsig.raw), _lib.buf(b"".join(bytes(m) for m in msgs)),
+                                                   _offsets(msgs), n, 1 if allow_duplicates else 0) == 1
+    for k in keys:
+        if not (isinstance(k, Point) and k.curve is curve and k.group == G2):
+            return False
+    off = _offsets(msgs)
     rc = _lib.load().bgls_verify_aggregate(curve.id, _lib.buf(aggsig.raw), _lib.buf(b"".join(k.raw for k in keys)),
                                            _lib.buf(b"".join(bytes(m) for m in msgs)), off, n, 1 if allow_duplicates else 0)
     return rc == 1                                   # every failure collapses to false (bgls.go:115-118)
@@ -60,6 +101,12 @@ def KoskVerifyAggregateSignature(curve, aggsig, keys, msgs):  # bgls/blsKosk.go:
 
 
 def _verify_multi(curve, aggsig, keys, msg):                  # bgls/bgls.go:89-92
+    if isinstance(keys, KeySet):
+        if keys.curve is not curve or not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+            return False
+        return _lib.load().bgls_verify_multi_h(keys.handle, _lib.buf(aggsig.raw), _lib.buf(msg), len(msg)) == 1
+    if not (isinstance(aggsig, Point) and aggsig.curve is curve and aggsig.group == G1):
+        return False                                 # a nil / foreign aggsig is `false`, never an exception
     for k in keys:
         if not (isinstance(k, Point) and k.curve is curve and k.group == G2):
             return False
@@ -104,7 +151,9 @@ def _g2_keys_ok(curve, keys):
 def hashPubKeysToExponents(pubkeys):                          # bgls/blsHAE.go:80-93
     if not pubkeys:
         return []
-    curve = pubkeys[0].curve
+    curve = pubkeys[0].curve if isinstance(pubkeys[0], Point) else None
+    if curve is None or not _g2_keys_ok(curve, pubkeys):      # the C side reads n * g2_size bytes: G2 points of ONE curve only
+        raise TypeError("hashPubKeysToExponents takes G2 public keys of one curve")
     o = _lib.out(16 * len(pubkeys))
     rc = _lib.load().bgls_hae_exponents(curve.id, _lib.buf(b"".join(k.raw for k in pubkeys)), len(pubkeys), o)
     if rc != 0:
@@ -174,7 +223,7 @@ def LoadPublicKeys(curve, sks):
         return []
     size = len(curve.GetG2().raw)
     o = _lib.out(n * size)
-    rc = _lib.load().bgls_scale_generator(curve.id, G2, _lib.buf(b"".join((sk % (1 << 256)).to_bytes(32, "big") for sk in sks)), n, o)
+    rc = _lib.load().bgls_scale_generator(curve.id, G2, _lib.buf(b"".join(_reduce_scalar(curve, sk if sk >= 0 else sk % curve.GetG1Order()).to_bytes(32, "big") for sk in sks)), n, o)
     if rc != 0:
         raise RuntimeError("bgls_scale_generator: %s" % _lib.last_error())
     raw = bytes(o)
@@ -197,7 +246,7 @@ def SignBatch(curve, sks, msgs, kosk=False):
     off[n] = acc
     size = len(curve.GetG1().raw)
     o = _lib.out(n * size)
-    rc = _lib.load().bgls_sign_batch(curve.id, _lib.buf(b"".join((sk % (1 << 256)).to_bytes(32, "big") for sk in sks)),
+    rc = _lib.load().bgls_sign_batch(curve.id, _lib.buf(b"".join(_reduce_scalar(curve, sk if sk >= 0 else sk % curve.GetG1Order()).to_bytes(32, "big") for sk in sks)),
                                      _lib.buf(b"".join(ms)), off, n, o)
     if rc != 0:
         raise RuntimeError("bgls_sign_batch: %s" % _lib.last_error())

@@ -793,6 +793,30 @@ int gt_mul_t(const uint8_t* a, const uint8_t* b, uint8_t* out) {
 }
 
 template <class C>
+int gt_pow_t(const uint8_t* gt, const uint8_t* k_be32, int negate, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  void *d_in, *d_flags;
+  if ((rc = c.get(WS_IN_A, 2 * E::GTB + 32, &d_in))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  uint8_t* d = (uint8_t*)d_in;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(d, gt, E::GTB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d + E::GTB, k_be32, 32, hipMemcpyHostToDevice, st));
+  kl::gt_pow<C>(st, d, d + E::GTB, negate, d + E::GTB + 32, (uint32_t*)d_flags);
+  HIPCHK(hipGetLastError());
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d + E::GTB + 32, E::GTB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flags_to_rc(f);
+}
+
+template <class C>
 int miller_product_dev_t(const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
                          int check_dups, void* d_partial, void* d_flags, void* stream) {
   typedef Engine<C> E;
@@ -1701,6 +1725,11 @@ int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out) 
 int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (!a || !b || !out) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, gt_mul_t<CV>(a, b, out));
+}
+
+int bgls_gt_pow(int curve, const uint8_t* gt, const uint8_t* k_be32, int negative, uint8_t* out) {
+  if (!gt || !k_be32 || !out) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, gt_pow_t<CV>(gt, k_be32, negative ? 1 : 0, out));
 }
 
 int bgls_gt_identity(int curve, uint8_t* out) {

@@ -14,6 +14,13 @@ ALTBN128, BLS12_381 = 0, 1
 G1, G2 = 1, 2
 
 
+def _reduce_scalar(curve, mag):
+    """The ABI takes 32-byte magnitudes.  The reference multiplies by the exact big.Int; on points of order r (every
+    validated Point, every GT element) a magnitude of 2^256 or more acts as its residue modulo the group order, so larger
+    factors are reduced modulo GetG1Order() -- in every path, never modulo 2^256."""
+    return mag if mag < 1 << 256 else mag % curve.GetG1Order()
+
+
 class Point:
     """curves.Point (curves/curve.go:51-59) over uncompressed wire bytes."""
 
@@ -55,9 +62,7 @@ class Point:
         """Point.Mul (altbn128.go:107-121,235-249; bls12_381.go:65-76,126-137): negative scalars
         negate then multiply, zero gives infinity.  The caller's scalar is NOT mutated."""
         sign = 1 if scalar < 0 else 0
-        mag = -scalar if scalar < 0 else scalar
-        if mag >= 1 << 256:
-            mag %= self.curve.GetG1Order()
+        mag = _reduce_scalar(self.curve, -scalar if scalar < 0 else scalar)
         o = _lib.out(len(self.raw))
         rc = _lib.load().bgls_scale_points(self.curve.id, self.group, _lib.buf(self.raw), _lib.buf(mag.to_bytes(32, "big")),
                                            _lib.buf(bytes([sign])), 1, o)
@@ -96,6 +101,16 @@ class PointT:
 
     def Marshal(self):
         return self.raw
+
+    def Mul(self, scalar):
+        """PointT.Mul (curves/altbn128.go:273-281, curves/bls12_381.go:170-173): exponentiation in GT."""
+        sign = 1 if scalar < 0 else 0
+        mag = _reduce_scalar(self.curve, -scalar if scalar < 0 else scalar)
+        o = _lib.out(len(self.raw))
+        rc = _lib.load().bgls_gt_pow(self.curve.id, _lib.buf(self.raw), _lib.buf(mag.to_bytes(32, "big")), sign, o)
+        if rc != 0:
+            return None
+        return PointT(self.curve, bytes(o))
 
 
 class CurveSystem:
@@ -260,7 +275,7 @@ def ScalePoints(pts, factors):
         return []
     c, g = pts[0].curve, pts[0].group
     signs = bytes(2 if f is None else (1 if f < 0 else 0) for f in factors)
-    mags = b"".join((0 if f is None else abs(f) % (1 << 256)).to_bytes(32, "big") for f in factors)
+    mags = b"".join((0 if f is None else _reduce_scalar(c, abs(f))).to_bytes(32, "big") for f in factors)
     s = len(pts[0].raw)
     o = _lib.out(len(pts) * s)
     rc = _lib.load().bgls_scale_points(c.id, g, _lib.buf(b"".join(p.raw for p in pts)), _lib.buf(mags), _lib.buf(signs), len(pts), o)

@@ -19,6 +19,7 @@ import "C"
 import (
 	"bytes"
 	"math/big"
+	"runtime"
 	"unsafe"
 )
 
@@ -75,8 +76,10 @@ func (pt *hipPoint) Equals(o Point) bool {
 }
 func (pt *hipPoint) MarshalUncompressed() []byte { return append([]byte(nil), pt.raw...) }
 
-// Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221); BLS12-381's compressed layout is the
-// upstream library's and unpinned, so the uncompressed bytes are returned there.
+// Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221).  BLS12-381's compressed layout belongs to
+// the un-vendored dis2/bls12 and carries TODOs in the reference (curves/bls12_381.go:55,60,116,121): it is NOT restated,
+// Marshal returns the UNCOMPRESSED bytes there and Unmarshal accepts only those -- a documented deviation, byte parity of
+// bls12 Marshal() with upstream is unpinned.
 func (pt *hipPoint) Marshal() []byte {
 	if pt.c.id != C.BGLS_CURVE_ALTBN128 {
 		return pt.MarshalUncompressed()
@@ -87,15 +90,26 @@ func (pt *hipPoint) Marshal() []byte {
 	}
 	return out
 }
-func (pt *hipPoint) Mul(k *big.Int) Point {
-	sign := []byte{0}
-	mag := new(big.Int).Set(k) // the caller's scalar is never mutated (unlike curves/bls12_381.go:70)
+// scalar32 returns |k| as the 32-byte big-endian magnitude the C ABI takes.  Magnitudes of 2^256 or more are reduced
+// modulo the group order first (on points of order r -- every validated Point, every GT element -- that is the same
+// multiple); the caller's big.Int is never mutated (unlike curves/bls12_381.go:70) and FillBytes never panics.
+func (c *hipCurve) scalar32(k *big.Int) ([]byte, C.int) {
+	neg := C.int(0)
+	mag := new(big.Int).Abs(k)
 	if k.Sign() < 0 {
-		sign[0] = 1
-		mag.Neg(mag)
+		neg = 1
+	}
+	if mag.BitLen() > 256 {
+		mag.Mod(mag, c.base.GetG1Order())
 	}
 	sc := make([]byte, 32)
 	mag.FillBytes(sc)
+	return sc, neg
+}
+
+func (pt *hipPoint) Mul(k *big.Int) Point {
+	sc, neg := pt.c.scalar32(k)
+	sign := []byte{byte(neg)}
 	out := make([]byte, len(pt.raw))
 	if C.bgls_scale_points(pt.c.id, pt.group, p(pt.raw), p(sc), p(sign), 1, p(out)) != 0 {
 		return nil
@@ -129,7 +143,14 @@ func (t hipPointT) Equals(o PointT) bool {
 	q, ok := o.(hipPointT)
 	return ok && bytes.Equal(q.raw, t.raw)
 }
-func (t hipPointT) Mul(k *big.Int) PointT { panic("GT exponentiation: not on the verify path (SURVEY 8f)") }
+func (t hipPointT) Mul(k *big.Int) PointT {
+	sc, neg := t.c.scalar32(k)
+	out := make([]byte, len(t.raw))
+	if C.bgls_gt_pow(t.c.id, p(t.raw), p(sc), neg, p(out)) != 0 {
+		return nil // the interface never panics (curves/curve.go:15-22)
+	}
+	return hipPointT{t.c, out}
+}
 
 // ---- CurveSystem (curves/curve.go:12-49) -------------------------------------------------
 func (c *hipCurve) Name() string { return c.name }
@@ -156,7 +177,7 @@ func (c *hipCurve) UnmarshalGT(d []byte) (PointT, bool) {
 	}
 	return hipPointT{c, append([]byte(nil), d...)}, true
 }
-func (c *hipCurve) makePoint(group C.int, coords []*big.Int) (Point, bool) {
+func (c *hipCurve) makePoint(group C.int, coords []*big.Int, check bool) (Point, bool) {
 	n := int(C.bgls_fp_size(c.id))
 	if len(coords)*n != c.size(group) {
 		return nil, false
@@ -168,10 +189,15 @@ func (c *hipCurve) makePoint(group C.int, coords []*big.Int) (Point, bool) {
 		}
 		v.FillBytes(raw[i*n : (i+1)*n])
 	}
+	// bgls_point_check = canonical coordinates, on the curve and (G2) in the order-r subgroup: what upstream's Unmarshal
+	// checks.  alt-bn128 validates regardless of `check` (curves/altbn128.go:39-41,157-160), bls12 only with check.
+	if !check && c.id != C.BGLS_CURVE_ALTBN128 {
+		return &hipPoint{c, group, raw}, true
+	}
 	return c.unmarshal(group, raw)
 }
-func (c *hipCurve) MakeG1Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G1, co) }
-func (c *hipCurve) MakeG2Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G2, co) }
+func (c *hipCurve) MakeG1Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G1, co, check) }
+func (c *hipCurve) MakeG2Point(co []*big.Int, check bool) (Point, bool) { return c.makePoint(C.BGLS_G2, co, check) }
 
 func (c *hipCurve) gen(group C.int) Point {
 	out := make([]byte, c.size(group))
@@ -284,6 +310,81 @@ func HipVerifyMulti(curve CurveSystem, aggsig Point, keys []Point, msg []byte) b
 		kb = append(kb, q.raw...)
 	}
 	return C.bgls_verify_multi(c.id, p(s.raw), p(kb), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
+}
+
+// ---- device-resident key sets -------------------------------------------------------------------------------------------
+// HipKeySet is a []Point of public keys uploaded once (parsed, validated, resident in HBM, optionally cut over several
+// GPUs); the handle is released by a finalizer, as every other Go-owned device resource would be.
+type HipKeySet struct {
+	c *hipCurve
+	h C.bgls_keys_t
+	n int
+}
+
+// HipUploadKeys uploads keys to `devices` (nil = the default device).  check = true re-runs the construction-time
+// validation (subgroup membership included) on the device.
+func HipUploadKeys(curve CurveSystem, keys []Point, devices []int, check bool) *HipKeySet {
+	c, ok := curve.(*hipCurve)
+	if !ok {
+		return nil
+	}
+	kb, ok2 := hipKeyBytes(c, keys)
+	if !ok2 {
+		return nil
+	}
+	devs := make([]C.int, 0, len(devices))
+	for _, d := range devices {
+		devs = append(devs, C.int(d))
+	}
+	var dp *C.int
+	nd := C.int(1)
+	if len(devs) > 0 {
+		dp, nd = &devs[0], C.int(len(devs))
+	}
+	flags := C.uint(0)
+	if check {
+		flags = C.BGLS_KEYS_CHECK
+	}
+	var h C.bgls_keys_t
+	if C.bgls_keys_upload(c.id, p(kb), C.size_t(len(keys)), dp, nd, flags, &h) != 0 {
+		return nil
+	}
+	ks := &HipKeySet{c, h, len(keys)}
+	runtime.SetFinalizer(ks, func(k *HipKeySet) { C.bgls_keys_free(k.h) })
+	return ks
+}
+
+// VerifyAggregate is bgls.verifyAggSig (bgls/bgls.go:94-119) against the resident keys, on every GPU of the set.
+func (ks *HipKeySet) VerifyAggregate(aggsig Point, msgs [][]byte, allowDuplicates bool) bool {
+	s, ok := aggsig.(*hipPoint)
+	if !ok || s.c != ks.c || s.group != C.BGLS_G1 || len(msgs) != ks.n {
+		return false
+	}
+	off := make([]C.uint64_t, len(msgs)+1)
+	var blob []byte
+	for i, m := range msgs {
+		off[i] = C.uint64_t(len(blob))
+		blob = append(blob, m...)
+	}
+	off[len(msgs)] = C.uint64_t(len(blob))
+	dup := C.int(0)
+	if allowDuplicates {
+		dup = 1
+	}
+	ok = C.bgls_verify_aggregate_h(ks.h, p(s.raw), p(blob), &off[0], C.size_t(ks.n), dup) == 1
+	runtime.KeepAlive(ks)
+	return ok
+}
+
+// VerifyMulti is bgls.verifyMultiSignature (bgls/bgls.go:89-92) against the resident keys.
+func (ks *HipKeySet) VerifyMulti(aggsig Point, msg []byte) bool {
+	s, ok := aggsig.(*hipPoint)
+	if !ok || s.c != ks.c || s.group != C.BGLS_G1 {
+		return false
+	}
+	ok = C.bgls_verify_multi_h(ks.h, p(s.raw), p(msg), C.size_t(len(msg))) == 1
+	runtime.KeepAlive(ks)
+	return ok
 }
 
 func hipKeyBytes(c *hipCurve, keys []Point) ([]byte, bool) {
@@ -408,10 +509,8 @@ func HipUnmarshalG2Batch(curve CurveSystem, data []byte, n int) ([]Point, []bool
 			return nil, nil
 		}
 	} else {
-		for i := range oks {
-			if C.bgls_point_check(c.id, C.BGLS_G2, p(raw[i*sz:(i+1)*sz])) == 1 {
-				oks[i] = 1
-			}
+		if C.bgls_check_points(c.id, C.BGLS_G2, p(raw), C.size_t(n), p(oks)) != 0 {
+			return nil, nil
 		}
 	}
 	pts := make([]Point, n)

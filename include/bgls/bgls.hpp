@@ -57,6 +57,7 @@ inline bool KoskVerifyAggregateSignature(const CurveSystem* curve, const Point& 
 }
 // verifyMultiSignature, bgls/bgls.go:89-92
 inline bool verifyMultiSignature(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys, const Bytes& msg) {
+  if (aggsig.curve != curve || aggsig.group != BGLS_G1) return false;      // a nil / foreign aggsig is `false`
   Bytes kb;
   for (const Point& k : keys) {
     if (k.curve != curve || k.group != BGLS_G2) return false;
@@ -74,6 +75,45 @@ inline bool KoskVerifyMultiSignature(const CurveSystem* curve, const Point& aggs
   m.insert(m.end(), msg.begin(), msg.end());
   return verifyMultiSignature(curve, aggsig, keys, m);
 }
+
+// A []Point of public keys resident on the GPU(s) (bgls_keys_t): uploaded, parsed and validated once, verified many times.
+class KeySet {
+ public:
+  KeySet(const CurveSystem* curve, const std::vector<Point>& keys, const std::vector<int>& devices = {}, bool check = true) : curve_(curve), n_(keys.size()) {
+    Bytes kb;
+    for (const Point& k : keys) {
+      if (k.curve != curve || k.group != BGLS_G2) return;
+      kb.insert(kb.end(), k.raw.begin(), k.raw.end());
+    }
+    const int nd = devices.empty() ? 1 : (int)devices.size();
+    ok_ = bgls_keys_upload(curve->id, kb.data(), n_, devices.empty() ? nullptr : devices.data(), nd, check ? BGLS_KEYS_CHECK : 0u, &h_) == 0;
+  }
+  ~KeySet() { if (ok_) bgls_keys_free(h_); }
+  KeySet(const KeySet&) = delete;
+  KeySet& operator=(const KeySet&) = delete;
+  bool ok() const { return ok_; }
+  // verifyAggSig (bgls/bgls.go:94-119) / verifyMultiSignature (bgls/bgls.go:89-92) against the resident keys
+  bool VerifyAggregateSignature(const Point& aggsig, const std::vector<Bytes>& msgs, bool allowDuplicates = false) const {
+    if (!ok_ || msgs.size() != n_ || aggsig.curve != curve_ || aggsig.group != BGLS_G1) return false;
+    Bytes blob;
+    std::vector<uint64_t> off(msgs.size() + 1, 0);
+    for (size_t i = 0; i < msgs.size(); ++i) {
+      blob.insert(blob.end(), msgs[i].begin(), msgs[i].end());
+      off[i + 1] = blob.size();
+    }
+    return bgls_verify_aggregate_h(h_, aggsig.raw.data(), blob.data(), off.data(), n_, allowDuplicates ? 1 : 0) == 1;
+  }
+  bool VerifyMultiSignature(const Point& aggsig, const Bytes& msg) const {
+    if (!ok_ || aggsig.curve != curve_ || aggsig.group != BGLS_G1) return false;
+    return bgls_verify_multi_h(h_, aggsig.raw.data(), msg.data(), msg.size()) == 1;
+  }
+
+ private:
+  const CurveSystem* curve_;
+  size_t n_;
+  bgls_keys_t h_ = 0;
+  bool ok_ = false;
+};
 
 // ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ----
 namespace detail {

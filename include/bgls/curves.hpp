@@ -42,6 +42,8 @@ struct PointT {
   PointT Copy() const { return *this; }
   bool Equals(const PointT& o) const { return curve == o.curve && raw == o.raw; }
   Bytes Marshal() const { return raw; }
+  // PointT.Mul (curves/altbn128.go:273-281): exponentiation in GT; an invalid PointT on failure, never an exception
+  PointT Mul(const Bytes& magnitude_be32, bool negative = false) const;
 };
 
 // curves.CurveSystem (curves/curve.go:12-49)
@@ -111,6 +113,12 @@ inline std::pair<Point, bool> Point::Add(const Point& o) const {
   Bytes out(raw.size());
   if (bgls_point_add(curve->id, group, raw.data(), o.raw.data(), out.data()) != 0) return {Point{}, false};
   return {Point{curve, group, out}, true};
+}
+inline PointT PointT::Mul(const Bytes& mag, bool negative) const {
+  if (!curve || mag.size() != 32) return PointT{};
+  Bytes o(raw.size());
+  if (bgls_gt_pow(curve->id, raw.data(), mag.data(), negative ? 1 : 0, o.data()) != 0) return PointT{};
+  return PointT{curve, o};
 }
 inline Point Point::Mul(const Bytes& mag, bool negative) const {
   uint8_t sign = negative ? 1 : 0;

@@ -167,6 +167,9 @@ int bgls_generator(int curve, int group, uint8_t* out);
 int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out);
 /* PointT.Add = Fp12 multiplication (curves/altbn128.go:264-271, curves/bls12_381.go:160-168) */
 int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out);
+/* PointT.Mul (curves/altbn128.go:273-281, curves/bls12_381.go:170-173): gt^k, k a 32-byte big-endian magnitude,
+ * negative != 0 for k < 0 (the inverse of a GT element is its conjugate: GT elements are unitary). */
+int bgls_gt_pow(int curve, const uint8_t* gt, const uint8_t* k_be32, int negative, uint8_t* out);
 /* GetGTIdentity (curves/altbn128.go:441-443,478; curves/bls12_381.go:295-297,341) */
 int bgls_gt_identity(int curve, uint8_t* out);
 

@@ -9,8 +9,10 @@ statement by statement, quirks included:
                  G2  curves/altbn128.go:329-376   compressed branch (len 64), square root by calcComplexQuadRes
                                                   (curves/hash.go:196-223, "Algorithm 18")
   final check        MakeG1Point / MakeG2Point -> upstream Unmarshal (curves/altbn128.go:42-57,157-179): canonical
-                     coordinates (< q) and curve membership.  The upstream G2 subgroup test is version dependent and
-                     not reproduced (same stance as for uncompressed keys).
+                     coordinates (< q), curve membership and -- G2 -- membership in the order-r subgroup (upstream
+                     bn256's twistPoint.IsOnCurve multiplies by the group order; oracle/pyref/subgroup.py).
+                     decompress_g2(..., subgroup=False) stops before that last test (what wire.hpp's g2_decompress
+                     computes; the kernel applies g2_in_subgroup to its result).
 
 BLS12-381's compressed encodings come from the un-vendored dis2/bls12 and carry TODOs in the reference
 (curves/bls12_381.go:55,60,116,121): unpinned, not restated.
@@ -113,7 +115,7 @@ def decompress_g1(data):
     return (x, y), True
 
 
-def decompress_g2(data):
+def decompress_g2(data, subgroup=True):
     assert len(data) == 64
     di, dr = bytearray(data[:32]), bytearray(data[32:])
     yisgn, yrsgn = di[0] >= 128, dr[0] >= 128
@@ -143,4 +145,8 @@ def decompress_g2(data):
         yr = Q - yr
     if xi >= Q or xr >= Q or yi >= Q or yr >= Q or not g2_on_curve((xr, xi), (yr, yi)):   # MakeG2Point -> upstream Unmarshal
         return None, False
+    if subgroup:
+        from .subgroup import Subgroup
+        if not Subgroup(BN254).in_subgroup(((xr, xi), (yr, yi))):
+            return None, False
     return ((xr, xi), (yr, yi)), True

@@ -97,9 +97,42 @@ static void TestHAE(const CurveSystem* curve) {
   CHECK(!KoskVerifyMultiSignatureWithMultiplicity(curve, am, ks, &mult, kmsg), "multiplicity verification succeeded on wrong factors");
 }
 
+// resident key sets (bgls_keys_t) through the C++ mirror: same verdicts as the []Point calls, on 1 and 3 shards of device 0;
+// GT exponentiation (PointT.Mul): e(g1, g2)^k == e(k g1, g2) (the bilinearity check of curves/curve_test.go:120-141)
+static void TestKeySetAndGtMul(const CurveSystem* curve) {
+  const int N = 17;
+  std::vector<Point> keys, sigs;
+  std::vector<Bytes> msgs;
+  for (int j = 0; j < N; ++j) { Bytes sk = randScalar(); msgs.push_back(randBytes(24 + j)); sigs.push_back(Sign(curve, sk, msgs.back())); keys.push_back(LoadPublicKey(curve, sk)); }
+  Point agg = AggregateSignatures(sigs);
+  CHECK(VerifyAggregateSignature(curve, agg, keys, msgs), "aggregate verification failed");
+  for (int shards : {1, 3}) {
+    KeySet ks(curve, keys, std::vector<int>(shards, 0));
+    CHECK(ks.ok(), "key-set upload failed");
+    CHECK(ks.VerifyAggregateSignature(agg, msgs), "key-set aggregate verification failed");
+    std::vector<Bytes> sw = msgs; std::swap(sw[0], sw[N - 1]);
+    CHECK(!ks.VerifyAggregateSignature(agg, sw), "key-set aggregate verification succeeded with messages switched");
+    std::vector<Bytes> fewer(msgs.begin(), msgs.end() - 1);
+    CHECK(!ks.VerifyAggregateSignature(agg, fewer), "key-set aggregate verification succeeded with a missing message");
+  }
+  Bytes m = randBytes(32);
+  std::vector<Point> ksigs;
+  std::vector<Point> kkeys;
+  for (int j = 0; j < N; ++j) { Bytes sk = randScalar(); ksigs.push_back(KoskSign(curve, sk, m)); kkeys.push_back(LoadPublicKey(curve, sk)); }
+  Bytes km(1, 1); km.insert(km.end(), m.begin(), m.end());
+  KeySet kk(curve, kkeys, {0, 0});
+  CHECK(kk.VerifyMultiSignature(AggregateSignatures(ksigs), km), "key-set multi-signature verification failed");
+  CHECK(!kk.VerifyMultiSignature(AggregateSignatures(ksigs), m), "key-set multi-signature verification succeeded on the wrong message");
+  Bytes k = randScalar();
+  auto e = curve->Pair(curve->GetG1(), curve->GetG2());
+  auto ek = curve->Pair(curve->GetG1().Mul(k), curve->GetG2());
+  CHECK(e.second && ek.second && e.first.Mul(k).Equals(ek.first), "e(g1, g2)^k != e(k g1, g2)");
+  CHECK(e.first.Mul(k, true).Add(ek.first).first.Equals(curve->GetGTIdentity()), "e(g1, g2)^-k * e(k g1, g2) != 1");
+}
+
 int main() {
   if (bgls_init(0) != 0) { std::printf("bgls_init: %s\n", bgls_last_error()); return 2; }
-  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); TestHAE(curve); }
+  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); TestHAE(curve); TestKeySetAndGtMul(curve); }
   std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -206,8 +206,10 @@ def wire_vectors(seed):
         pt, ok = wire.decompress_g1(d)
         return {"in": d.hex(), "ok": ok, "pt": G.g1_bytes(pt).hex() if ok else None}
     def dec2(d):
-        pt, ok = wire.decompress_g2(d)
-        return {"in": d.hex(), "ok": ok, "pt": G.g2_bytes(pt).hex() if ok else None}
+        # ok: UnmarshalG2's answer (subgroup membership included); decoded / pt: the decoding before that last test
+        pt, dec = wire.decompress_g2(d, subgroup=False)
+        _, ok = wire.decompress_g2(d)
+        return {"in": d.hex(), "ok": ok, "decoded": dec, "pt": G.g2_bytes(pt).hex() if dec else None}
     for row in v["g1"]:
         d = bytearray(bytes.fromhex(row["compressed"]))
         v["g1_decode"].append(dec1(bytes(d)))

@@ -229,3 +229,37 @@ def test_ams_consistency(curve):
     assert not AmsVerifySignatureWithSetCheck(curve, lambda s: len(s) > 5, apk, signer_set, aggKey, aggSig, msg)
     assert not AmsVerifySignature(curve, apk, signer_set, aggKey, aggSig, secrets.token_bytes(64))
     assert not AmsVerifySignature(curve, apk, signer_set[:-1], aggKey, aggSig, msg)
+
+
+@pytest.mark.parametrize("curve", curves, ids=lambda c: c.Name())
+def test_key_set_through_the_scheme_mirror(curve):
+    """bgls.KeySet in place of the []Point of public keys: VerifyAggregateSignature / KoskVerifyMultiSignature give the
+    same answers (bgls/bgls_test.go:40-77, blsKosk_test.go:35-64 re-read through a resident key set); PointT.Mul."""
+    import os
+    from bgls_amd import bgls
+    N = 12
+    sks = [bgls.KeyGen(curve)[0] for _ in range(N)]
+    keys = bgls.LoadPublicKeys(curve, sks)
+    msgs = [os.urandom(20 + i) for i in range(N)]
+    agg = bgls.AggregateSignatures(bgls.SignBatch(curve, sks, msgs))
+    for devices in ([0], [0, 0, 0]):
+        ks = bgls.KeySet(curve, keys, devices)
+        assert len(ks) == N
+        assert bgls.VerifyAggregateSignature(curve, agg, ks, msgs) is True
+        assert bgls.VerifyAggregateSignature(curve, agg, ks, msgs[:-1]) is False
+        assert bgls.VerifyAggregateSignature(curve, agg, ks, msgs[1:] + msgs[:1]) is False
+        assert bgls.VerifyAggregateSignature(curve, None, ks, msgs) is False
+        m = os.urandom(32)
+        kagg = bgls.AggregateSignatures(bgls.SignBatch(curve, sks, [m] * N, kosk=True))
+        assert bgls.KoskVerifyMultiSignature(curve, kagg, ks, m) is True
+        assert bgls.KoskVerifyMultiSignature(curve, kagg, ks, m + b"!") is False
+        assert bgls.KoskVerifyMultiSignature(curve, None, keys, m) is False       # nil aggsig: false, not an exception
+        ks.free()
+    with pytest.raises(TypeError):
+        bgls.hashPubKeysToExponents([curve.GetG1()])                               # G1 points are not public keys
+    e, ok = curve.Pair(curve.GetG1(), curve.GetG2())
+    k = sks[0]
+    ek, _ = curve.Pair(curve.GetG1().Mul(k), curve.GetG2())
+    assert ok and e.Mul(k).Equals(ek) and e.Mul(-k).Add(ek)[0].Equals(curve.GetGTIdentity())
+    big = k + 5 * curve.GetG1Order() + (1 << 300) * 0                              # > 2^256 scalars act modulo the order
+    assert curve.GetG2().Mul(k + 7 * curve.GetG1Order()).Equals(curve.GetG2().Mul(k))

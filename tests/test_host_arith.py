@@ -156,7 +156,7 @@ def test_wire_formats_and_blake2x_node(host_harness):
         assert rc == (1 if ok else 0) and (not ok or u == G.g1_bytes(pt))
     for _ in range(16):
         d2 = bytearray(rnd.randbytes(64)); d2[0] &= rnd.choice((0x3f, 0xbf)); d2[32] &= rnd.choice((0x3f, 0xbf))
-        pt, ok = wire.decompress_g2(bytes(d2))
+        pt, ok = wire.decompress_g2(bytes(d2), subgroup=False)        # wire.hpp decodes; the kernel adds the subgroup test
         rc, u = run(3, d2, 128)
         assert rc == (1 if ok else 0) and (not ok or u == G.g2_bytes(pt))
     assert run(2, bytes(32), 64) == (1, bytes(64)) and run(3, bytes(64), 128) == (1, bytes(128))
