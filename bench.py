@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: aggregate-verify signer-pairs/sec (BASELINE.json `metric`).
+"""Headline benchmark: aggregate-verify signer-pairs/sec (BASELINE.json `metric`: alt-bn128 & BLS12-381).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One "step" = one complete VerifyAggregateSignature over the resident batch: duplicate-message
-scan, n hash-to-G1, n+1 Miller loops, GT product, ONE final exponentiation, compare with 1 --
-everything bgls/bgls.go:94-119 does, inputs already in HBM (keys as the reference's wire-format
-bytes, 64-byte messages as in bgls/bgls_test.go:186-202).
-N = 1 workload: BASELINE.json configs[1] (alt-bn128, 2^16 signers, 1 MI355X).
-N > 1: weak scaling -- every rank verifies its own 2^16-signer shard of ONE n = N * 2^16
-aggregate signature: partial Miller product per rank, one RCCL all-gather of the 384-byte
-partials, local combine + final exponentiation on every rank (bgls_amd/sharding.py).
+One "step" = one complete VerifyAggregateSignature over the resident batch: duplicate-message scan, n hash-to-G1, n+1
+Miller loops, GT product, ONE final exponentiation, compare with 1 -- everything bgls/bgls.go:94-119 does, inputs already
+in HBM (keys as the reference's wire-format bytes, 64-byte messages as in bgls/bgls_test.go:186-202).
+
+Headline (`value`): alt-bn128, ONE 2^20-signer batch (north_star's target size) cut into contiguous signer ranges over the
+N GPUs (strong scaling: 2^20 / N signers per GPU): partial Miller product per rank, one all-gather of the 384-byte
+partials + status words, local combine + final exponentiation on every rank (bgls_amd/sharding.py; BASELINE config 5's
+decomposition).  The same JSON line carries, under "records", the other BASELINE configs measured in the same process:
+BLS12-381 at 2^20 (every N), and at N = 1 both curves at 2^16 (configs 2, 3), the alt-bn128 multi-signature check at 2^20
+signers (config 4) and the reference's own CPU-runnable shape, alt-bn128 n = 64 (config 1).  Every record has the headline's
+schema: value, ms_per_step (median / min over the repetitions), roofline {frac, kernel, launch_ms, traffic}, and
+cpu_baseline where one was taken.
+
+`python bench.py --only aggregate --curve bls12 --n 65536 --in-flight 1` etc. run a single record (profiling runs).
 """
 import argparse
 import ctypes
 import json
 import os
 import random
+import statistics
 import sys
 import time
 
@@ -30,16 +37,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from bgls_amd import _lib  # noqa: E402
-from bgls_amd.sharding import all_gather_bytes, gather_partials_and_flags, global_duplicate_scan  # noqa: E402
+from bgls_amd.sharding import all_gather_bytes, gather_partials_and_flags, global_duplicate_scan, shard_range  # noqa: E402
 
 # Algorithmic work model (SURVEY.md 8d / DESIGN.md): 32x32->64 MACs per unit.
 MAC_PER_FPMUL = {0: 136, 1: 300}                       # CIOS 2L^2+L, L = 8 / 12
 MILLER_FPMUL = {0: 8250, 1: 6700}                      # Miller loop, Fp multiplications per pair
 PAIR_FPMUL = {0: 9030, 1: 14650}                       # whole path per signer-pair (hash + Miller + product)
-MULTISIG_FPMUL = {0: 29, 1: 29}                        # one G2 mixed addition per signer
+MULTISIG_FPMUL = 29                                    # one G2 mixed addition per signer
 ALGO_BYTES_PER_PAIR = {0: 128 + 64, 1: 192 + 64}       # key + message read once
 ORDER = {0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
          1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+CURVE = {"altbn128": 0, "bls12": 1}
+CNAME = {0: "altbn128", 1: "bls12"}
+LAUNCH_PAIRS = 1 << 16                                 # pairings per Miller launch (engine.hip: 1024 blocks of 64)
 
 
 def B(b):
@@ -52,26 +62,33 @@ def check(rc, what):
     return rc
 
 
-def make_shard(lib, cid, n, seed):
-    """n keys, n distinct 64-byte messages and the shard's partial aggregate signature, all
-    produced by the engine itself on the GPU (setup, untimed)."""
+def make_instance(lib, cid, n, seed):
+    """n keys, n distinct 64-byte messages and the n individual signatures, produced by the engine itself on the GPU
+    (setup, untimed).  Sub-instances (the first k signers) reuse the same arrays."""
     fp = 32 if cid == 0 else 48
     rnd = random.Random(seed)
     msgs = rnd.randbytes(64 * n)
     sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
-    kb = b"".join(s.to_bytes(32, "big") for s in sks)
-    g2 = (ctypes.c_uint8 * (4 * fp))()
-    check(lib.bgls_generator(cid, 2, g2), "generator")
+    kb = B(b"".join(s.to_bytes(32, "big") for s in sks))
     keys = (ctypes.c_uint8 * (n * 4 * fp))()
-    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(kb), None, n, keys), "scale_points(G2)")
-    off = (ctypes.c_uint64 * (n + 1))(*[64 * i for i in range(n + 1)])
-    hs = (ctypes.c_uint8 * (n * 2 * fp))()
-    check(lib.bgls_hash_to_g1(cid, B(msgs), off, n, hs), "hash_to_g1")
+    check(lib.bgls_scale_generator(cid, 2, kb, n, keys), "scale_generator(G2)")
+    off = (ctypes.c_uint64 * (n + 1))(*range(0, 64 * (n + 1), 64))
     sigs = (ctypes.c_uint8 * (n * 2 * fp))()
-    check(lib.bgls_scale_points(cid, 1, hs, B(kb), None, n, sigs), "scale_points(G1)")
+    check(lib.bgls_sign_batch(cid, kb, B(msgs), off, n, sigs), "sign_batch")
+    return {"cid": cid, "fp": fp, "n": n, "n_local": n, "keys": bytes(keys), "msgs": msgs, "sigs": bytes(sigs), "sks": sks}
+
+
+def make_shard(lib, cid, n, seed):
+    """(keys, msgs, aggregate signature, signatures) of an n-signer instance -- kept for the development tools"""
+    inst = make_instance(lib, cid, n, seed)
+    return inst["keys"], inst["msgs"], aggregate_sig(lib, inst, 0, n), inst["sigs"]
+
+
+def aggregate_sig(lib, inst, lo, hi):
+    fp, cid = inst["fp"], inst["cid"]
     agg = (ctypes.c_uint8 * (2 * fp))()
-    check(lib.bgls_aggregate_points(cid, 1, sigs, n, agg), "aggregate_points")
-    return bytes(keys), msgs, bytes(agg), bytes(sigs)
+    check(lib.bgls_aggregate_points(cid, 1, B(inst["sigs"][lo * 2 * fp:hi * 2 * fp]), hi - lo, agg), "aggregate_points")
+    return bytes(agg)
 
 
 def stage(lib, name):
@@ -80,242 +97,377 @@ def stage(lib, name):
     return ms.value, cnt.value
 
 
-def cpu_baseline(cid, keys, msgs, sigs, n, fp, lib):
-    """Oracle (C restatement, oracle/c) timed on this box's host cores over a bounded sample of the
-    same instance, in the reference's parallel shape: one task per hash and per FULL pairing
-    (final exponentiation inside every pairing, curves/curve.go:132-134)."""
+_PEAK = {}
+
+
+def pinned_peak(lib):
+    """Roofline denominator: the multiplier's issue peak measured live by the library's probe (16 independent
+    v_mad_u64_u32 chains per lane, 8 waves per SIMD); the MAXIMUM of six probe calls, taken once per process and reused by
+    every record, so that `frac` does not move with the probe's run-to-run spread."""
+    if "v" not in _PEAK:
+        best = 0.0
+        for _ in range(6):
+            p = ctypes.c_double()
+            check(lib.bgls_probe_mad_peak(ctypes.byref(p)), "probe_mad_peak")
+            best = max(best, p.value)
+        _PEAK["v"] = best
+    return _PEAK["v"]
+
+
+def traffic_for(kernel_key):
+    """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r2): a
+    builder-held constant of the evidence run, not measured in this process (labelled as such)."""
+    path = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+    if os.path.exists(path):
+        det = json.load(open(path))
+        if kernel_key in det:
+            return det[kernel_key].get("bytes_per_launch_fetch_x2"), dict(det[kernel_key], source="profiles/r2/pmc_traffic.json (evidence run, not this process)")
+    return None, None
+
+
+def cpu_baseline(cid, inst, lib):
+    """Oracle (C restatement, oracle/c) timed on this box's host cores over a bounded sample of the same instance, in the
+    reference's parallel shape: one task per hash and per FULL pairing (final exponentiation inside every pairing,
+    curves/curve.go:132-134)."""
     from oracle import coracle
+    fp, n = inst["fp"], inst["n"]
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)
     probe = min(n, 4 * cores)
 
     def run(cnt, faithful):
-        agg = (ctypes.c_uint8 * (2 * fp))()
-        check(lib.bgls_aggregate_points(cid, 1, B(sigs[:cnt * 2 * fp]), cnt, agg), "aggregate_points(sample)")
-        ms = [msgs[64 * i:64 * i + 64] for i in range(cnt)]
+        agg = aggregate_sig(lib, inst, 0, cnt)
+        ms = [inst["msgs"][64 * i:64 * i + 64] for i in range(cnt)]
         t0 = time.perf_counter()
-        ok = coracle.verify_aggregate(cid, bytes(agg), keys[:cnt * 4 * fp], ms, False, cores, faithful)
+        ok = coracle.verify_aggregate(cid, agg, inst["keys"][:cnt * 4 * fp], ms, False, cores, faithful)
         dt = time.perf_counter() - t0
         if ok != 1:
             raise RuntimeError("oracle rejected the GPU-generated instance (cpu_baseline sample)")
         return dt
 
     t_probe = run(probe, 1)
-    cnt = int(min(n, max(probe, probe * 12.0 / max(t_probe, 1e-3))))     # ~12 s of CPU work
+    cnt = int(min(n, max(probe, probe * 10.0 / max(t_probe, 1e-3))))     # ~10 s of CPU work
     dt = run(cnt, 1)
     dt_shared = run(min(cnt, 4096), 0)
     return {"value": cnt / dt, "unit": "signer-pairs/s", "cores": cores, "kind": "port",
-            "sample": "first %d signers of the same instance, C oracle, %d threads, final exponentiation per pairing "
-                      "(reference shape); with one shared final exponentiation: %.0f pairs/s" % (cnt, cores, min(cnt, 4096) / dt_shared)}
+            "sample": "first %d signers of the same instance, C oracle (oracle/c, a plain restatement: about 3-4x slower per core "
+                      "than the reference's published Go figure of 1.96 / 1.54 ms per pairing, README.md:19,23), %d threads, final "
+                      "exponentiation per pairing (reference shape); with one shared final exponentiation: %.0f pairs/s"
+                      % (cnt, cores, min(cnt, 4096) / dt_shared)}
 
 
-def bench_multisig(args, lib, cid, fp, n, dev, rank, world):
-    """BASELINE.json config 4: n signers on ONE message -- G2 key sum (AggregatePoints,
-    curves/curve.go:73-121) + hash + 2 pairings (bgls/bgls.go:59-70,89-92).  Single GPU."""
-    if world != 1:
-        raise SystemExit("multisig workload is single-GPU in this round")
+class Lanes:
+    """L verifications in flight on L library contexts / streams: every step is still one complete pass (duplicate scan,
+    hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound stages
+    of one step overlap the Miller launch of its neighbours."""
+
+    _streams = []          # one pool per process: every record reuses the same HIP streams (hardware queues are few)
+
+    def __init__(self, lib, dev, cid, L, gtb):
+        self.lib, self.cid, self.L = lib, cid, L
+        while len(Lanes._streams) < L:
+            Lanes._streams.append(torch.cuda.Stream(device=dev))
+        self.lanes = [{"stream": Lanes._streams[k], "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
+                       "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for k in range(L)]
+
+    def run(self, count, submit, overlap):
+        lib, L, cid = self.lib, self.L, self.cid
+
+        def collect(k):
+            check(lib.bgls_select_context(k), "select_context")
+            return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
+
+        try:
+            if not overlap:
+                for _ in range(count):
+                    submit(0)
+                    if collect(0) != 1:
+                        raise RuntimeError("verification failed inside the timed region")
+                return
+            for i in range(count):
+                submit(i % L)
+                if i >= L - 1 and collect((i - L + 1) % L) != 1:
+                    raise RuntimeError("verification failed inside the timed region")
+            for i in range(max(0, count - L + 1), count):
+                if collect(i % L) != 1:
+                    raise RuntimeError("verification failed inside the timed region")
+        finally:
+            check(lib.bgls_select_context(0), "select_context")
+
+
+def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, in_flight, throughput, label, with_h2d=True):
+    """VerifyAggregateSignature over an n_total-signer batch of which this rank holds inst['n_local'] signers (the first
+    n_local of `inst`).  Returns the record dict on rank 0 (None elsewhere)."""
+    cid, fp = inst["cid"], inst["fp"]
+    gtb = 12 * fp
+    n = inst["n_local"]
+    t_keys = torch.frombuffer(bytearray(inst["keys"][:n * 4 * fp]), dtype=torch.uint8).to(dev)
+    t_msgs = torch.frombuffer(bytearray(inst["msgs"][:n * 64]), dtype=torch.uint8).to(dev)
+    part_sig = aggregate_sig(lib, inst, 0, n)
+    t_psig = torch.frombuffer(bytearray(part_sig), dtype=torch.uint8).to(dev)
+    all_sigs = all_gather_bytes(t_psig, world)
+    agg = (ctypes.c_uint8 * (2 * fp))()
+    check(lib.bgls_aggregate_points(cid, 1, B(bytes(all_sigs.cpu().numpy().tobytes())), world, agg), "aggregate_points(global)")
+    t_sig = torch.frombuffer(bytearray(bytes(agg)), dtype=torch.uint8).to(dev)
+    L = max(1, min(16, in_flight))
+    lanes = Lanes(lib, dev, cid, L, gtb)
+    h_msgs = torch.frombuffer(bytearray(inst["msgs"][:n * 64]), dtype=torch.uint8).pin_memory() if with_h2d else None
+    torch.cuda.synchronize()
+
+    def submit(k, msgs_t=t_msgs, h2d=False):
+        ln = lanes.lanes[k]
+        h = ln["stream"].cuda_stream
+        check(lib.bgls_select_context(k), "select_context")
+        with torch.cuda.stream(ln["stream"]):
+            ln["flags"].zero_()
+            if h2d:                       # SURVEY 8d: messages arrive from the host inside the timed region (keys stay resident)
+                msgs_t.copy_(h_msgs, non_blocking=True)
+            if world > 1:                 # duplicates may straddle shards: exact scan over every rank's messages
+                global_duplicate_scan(lambda buf, count: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, ln["flags"].data_ptr(), h),
+                                                               "duplicate_scan_dev"), msgs_t, n, world)
+            check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
+                                              64, 64, n, 1 if world == 1 else 0, ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
+            if world == 1:
+                check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
+            else:
+                parts, merged = gather_partials_and_flags(ln["part"], ln["flags"], world)
+                check(lib.bgls_final_verify_submit_dev(cid, parts.data_ptr(), world, merged.data_ptr(), h), "final_verify_submit_dev")
+
+    def one(msgs_t=t_msgs):
+        submit(0, msgs_t)
+        check(lib.bgls_select_context(0), "select_context")
+        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # correctness gate: the valid instance verifies, one flipped message bit rejects
+    if one() != 1:
+        raise RuntimeError("valid instance rejected (%s)" % label)
+    bad = t_msgs.clone()
+    if rank == world - 1:
+        bad[64 * (n // 2) + 3] ^= 0x20
+    torch.cuda.synchronize()              # `bad` was written on torch's default stream, the lanes have their own
+    if one(bad) != 0:
+        raise RuntimeError("tampered instance accepted (%s)" % label)
+    del bad
+
+    pipelined = L > 1
+    # warm-up: W steps one at a time with the stage timers on -- these give each kernel's duration when it has the machine
+    # to itself ("exclusive"); then, if overlapping, L untimed overlapped steps to prime the other contexts' workspaces
+    lib.bgls_profile_enable(1)
+    seq = []
+    for _ in range(max(1, warmup)):
+        sync()
+        t0 = time.perf_counter()
+        if one() != 1:
+            raise RuntimeError("verification failed during warm-up")
+        torch.cuda.synchronize()
+        seq.append((time.perf_counter() - t0) * 1e3)
+    sync()
+    stages_excl = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
+    use_tp = pipelined and cid == 0 and throughput
+    if use_tp:
+        # launches overlap from here on: alt-bn128 Miller launches may take the shape that is fastest in that regime
+        # (bgls_set_throughput_mode: 60 pairings per block, see k_miller_s60); verdicts are identical in both modes
+        check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
+    if pipelined:
+        lanes.run(L, lambda k: submit(k), True)
+    regions = []
+    for _ in range(reps):
+        lib.bgls_profile_enable(1)
+        sync()
+        t0 = time.perf_counter()
+        lanes.run(steps, lambda k: submit(k), pipelined)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append(elapsed)
+    stages = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
+    h2d_elapsed = None
+    if with_h2d and world == 1:
+        sync()
+        t0 = time.perf_counter()
+        lanes.run(steps, lambda k: submit(k, h2d=True), pipelined)
+        sync()
+        h2d_elapsed = time.perf_counter() - t0
+    check(lib.bgls_set_throughput_mode(0), "set_throughput_mode")
+    lib.bgls_profile_enable(0)
+    if rank != 0:
+        return None
+
+    peak = pinned_peak(lib)
+    per_step = sorted(r / steps for r in regions)
+    med = statistics.median(per_step)
+    value = n_total / med
+    launches_per_step = (n + LAUNCH_PAIRS - 1) // LAUNCH_PAIRS
+    pairs_per_launch = min(n, LAUNCH_PAIRS)
+    macs_per_launch = (pairs_per_launch + 1) * MILLER_FPMUL[cid] * MAC_PER_FPMUL[cid]
+    ex_ms, ex_cnt = stages_excl["miller"]
+    excl_launch_s = ex_ms / max(ex_cnt, 1) / launches_per_step * 1e-3         # HIP events around the Miller stage, one verification in flight
+    # With several verifications in flight the launches of the dominant kernel share the machine with each other and with
+    # the other stages: what one launch costs the machine over the timed region is the region divided by the launches in it
+    # (every other stage's time included -- the conservative reading); the exclusive figure is the kernel by itself.
+    shared_launch_s = med / launches_per_step
+    cname = "BN254" if cid == 0 else "BLS381"
+    forced_tp = cid == 0 and os.environ.get("BGLS_THROUGHPUT") == "1"      # profiling runs: the 60-pairing shape from the first call on
+    kernel_excl = "k_miller_s60<BN254>" if forced_tp else "k_miller_ab64<%s>" % cname
+    kernel_timed = "k_miller_s60<BN254>" if (use_tp or forced_tp) else kernel_excl
+    traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])
+    rec = {
+        "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
+        "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3, "ms_per_step_all": [p * 1e3 for p in per_step],
+        "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": world, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s VerifyAggregateSignature, one %d-signer batch, %d signers per GPU, distinct 64-byte messages, keys and "
+                               "messages resident in HBM" % (CNAME[cid], n_total, n),
+                   "curve": CNAME[cid], "signers": n_total, "signers_per_gpu": n, "in_flight": L,
+                   "parallelism": "contiguous signer ranges x%d + one all-gather of GT partials and status words" % world},
+        "roofline": {"bound": "valu-int32-mac", "kernel": kernel_timed, "peak": peak / 1e12, "unit": "TMAC/s",
+                     "achieved": macs_per_launch / shared_launch_s / 1e12, "frac": macs_per_launch / shared_launch_s / peak,
+                     "launch_ms": shared_launch_s * 1e3, "launches_per_step": launches_per_step, "macs_per_launch": macs_per_launch,
+                     "traffic": traffic, "traffic_detail": tdet,
+                     "exclusive": {"kernel": kernel_excl, "launch_ms": excl_launch_s * 1e3, "achieved": macs_per_launch / excl_launch_s / 1e12 if excl_launch_s else None,
+                                   "frac": macs_per_launch / excl_launch_s / peak if excl_launch_s else None,
+                                   "note": "HIP events around the Miller stage of the %d one-at-a-time warm-up steps, divided by its launches" % ex_cnt},
+                     "hbm_side": {"achieved": pairs_per_launch * ALGO_BYTES_PER_PAIR[cid] / shared_launch_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "note": "algorithmic bytes of one Miller launch (key + message per pair) / launch_ms"},
+                     "whole_path_frac": value / world * PAIR_FPMUL[cid] * MAC_PER_FPMUL[cid] / peak,
+                     "note": "integer bignum path bounded by v_mad_u64_u32 issue, not HBM or MFMA (SURVEY 8d); achieved = algorithmic MACs of one "
+                             "launch ((pairs + 1) x %d Fp multiplications x %d MAC) / launch_ms; launch_ms = median timed region / launches in it"
+                             % (MILLER_FPMUL[cid], MAC_PER_FPMUL[cid])},
+        "sequential": {"ms_per_step_median": statistics.median(seq), "ms_per_step_min": min(seq), "value": n_total / (statistics.median(seq) * 1e-3),
+                       "note": "one verification at a time (the %d warm-up steps), end to end" % len(seq)},
+        "stage_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items()},
+        "stage_ms_exclusive": {k: (v[0] / max(v[1], 1)) for k, v in stages_excl.items()},
+    }
+    if h2d_elapsed is not None:
+        rec["with_message_h2d"] = {"value": n_total * steps / h2d_elapsed, "ms_per_step": h2d_elapsed / steps * 1e3,
+                                   "note": "the same steps with the %d MiB of messages copied from pinned host memory inside every step "
+                                           "(keys stay resident, SURVEY 8d timing protocol)" % (n * 64 >> 20)}
+    return rec
+
+
+def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
+    """BASELINE config 4: n signers on ONE message -- G2 key sum (AggregatePoints, curves/curve.go:73-121) + hash + 2
+    pairings (bgls/bgls.go:59-70,89-92; KoskVerifyMultiSignature's 0x01 prefix, bgls/blsKosk.go:117-120).  Single GPU."""
+    cid, fp = inst["cid"], inst["fp"]
     rnd = random.Random(0xB6150000 + 4)
-    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
-    kb = b"".join(s.to_bytes(32, "big") for s in sks)
-    g2 = (ctypes.c_uint8 * (4 * fp))()
-    check(lib.bgls_generator(cid, 2, g2), "generator")
-    keys = (ctypes.c_uint8 * (n * 4 * fp))()
-    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(kb), None, n, keys), "scale_points(G2)")
     msg = b"\x01" + rnd.randbytes(64)
     off = (ctypes.c_uint64 * 2)(0, len(msg))
     h = (ctypes.c_uint8 * (2 * fp))()
     check(lib.bgls_hash_to_g1(cid, B(msg), off, 1, h), "hash_to_g1")
     sig = (ctypes.c_uint8 * (2 * fp))()
-    check(lib.bgls_scale_points(cid, 1, h, B((sum(sks) % ORDER[cid]).to_bytes(32, "big")), None, 1, sig), "scale_points(sig)")
-    t_keys = torch.frombuffer(bytearray(bytes(keys)), dtype=torch.uint8).to(dev)
+    check(lib.bgls_scale_points(cid, 1, h, B((sum(inst["sks"][:n]) % ORDER[cid]).to_bytes(32, "big")), None, 1, sig), "scale_points(sig)")
+    t_keys = torch.frombuffer(bytearray(inst["keys"][:n * 4 * fp]), dtype=torch.uint8).to(dev)
     t_sig = torch.frombuffer(bytearray(bytes(sig)), dtype=torch.uint8).to(dev)
     t_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(nn=n):
+    def one(nn=n):
         return check(lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), nn, t_msg.data_ptr(), len(msg), stream), "verify_multi_dev")
 
-    if step() != 1 or step(n - 1) != 0:
+    if one() != 1 or one(n - 1) != 0:
         raise RuntimeError("multisig correctness gate failed")
-    # L verifications in flight (own context and stream each): the key sum of one overlaps the serial hash / pairing /
-    # final-exponentiation tail of the others; every step is a complete verification whose verdict is checked
-    L = max(1, min(16, args.in_flight))
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(L)]
+    L = max(1, min(16, in_flight))
+    lanes = Lanes(lib, dev, cid, L, 12 * fp)
     torch.cuda.synchronize()
 
     def submit(k):
         check(lib.bgls_select_context(k), "select_context")
-        check(lib.bgls_verify_multi_submit_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_msg.data_ptr(), len(msg), lanes[k].cuda_stream),
+        check(lib.bgls_verify_multi_submit_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_msg.data_ptr(), len(msg), lanes.lanes[k]["stream"].cuda_stream),
               "verify_multi_submit_dev")
 
-    def collect(k):
-        check(lib.bgls_select_context(k), "select_context")
-        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
-
-    def run(count):
-        for i in range(count):
-            submit(i % L)
-            if i >= L - 1 and collect((i - L + 1) % L) != 1:
-                raise RuntimeError("verification failed inside the timed region")
-        for i in range(max(0, count - L + 1), count):
-            if collect(i % L) != 1:
-                raise RuntimeError("verification failed inside the timed region")
-        check(lib.bgls_select_context(0), "select_context")
-
     lib.bgls_profile_enable(1)
-    for _ in range(args.warmup):
-        step()
+    seq = []
+    for _ in range(max(1, warmup)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one()
+        torch.cuda.synchronize()
+        seq.append((time.perf_counter() - t0) * 1e3)
     stages_excl = {s_: stage(lib, s_) for s_ in ("sum_points", "h2c", "miller", "reduce", "final_exp")}
-    run(L)
-    lib.bgls_profile_enable(1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sum_ms, sum_cnt = stage(lib, "sum_points")
+    lanes.run(L, submit, L > 1)
+    regions = []
+    for _ in range(reps):
+        lib.bgls_profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lanes.run(steps, submit, L > 1)
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
     lib.bgls_profile_enable(0)
-    peak = ctypes.c_double()
-    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
-    avg_s = sum_ms / max(sum_cnt, 1) * 1e-3
-    macs = n * MULTISIG_FPMUL[cid] * 3 * MAC_PER_FPMUL[cid]          # one G2 mixed addition = 29 Fp2-level products ~ 3 Fp mults each
-    bytes_per_launch = n * 4 * fp
-    print(json.dumps({
-        "metric": "multisig-verify signers/sec", "value": n * args.steps / elapsed, "unit": "signers/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM" % (args.curve, n)},
-        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sum_first+k_sum_next", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
-                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3,
-                     "hbm_algorithmic_GBps": bytes_per_launch / avg_s / 1e9},
-        "in_flight": L,
+    peak = pinned_peak(lib)
+    per_step = sorted(r / steps for r in regions)
+    med = statistics.median(per_step)
+    ex_ms, ex_cnt = stages_excl["sum_points"]
+    sum_s = ex_ms / max(ex_cnt, 1) * 1e-3
+    macs = n * MULTISIG_FPMUL * MAC_PER_FPMUL[cid]              # SURVEY 8d: one G2 mixed addition ~ 29 m per signer
+    traffic, tdet = traffic_for("k_sum_main_" + CNAME[cid])
+    return {
+        "metric": "multisig-verify signers/sec", "value": n / med, "unit": "signers/s", "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3,
+        "ms_per_step_all": [p * 1e3 for p in per_step], "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM" % (CNAME[cid], n), "in_flight": L},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sum_main + k_sum_pair / k_sum_wave (the whole key-sum stage)", "peak": peak / 1e12, "unit": "TMAC/s",
+                     "achieved": macs / sum_s / 1e12, "frac": macs / sum_s / peak, "launch_ms": sum_s * 1e3, "traffic": traffic, "traffic_detail": tdet,
+                     "hbm_side": {"achieved": n * 4 * fp / sum_s / 1e9, "peak": 8000.0, "unit": "GB/s", "note": "key bytes read once / stage time"},
+                     "note": "achieved = n x 29 Fp multiplications x %d MAC / the key-sum stage's time with one verification in flight (HIP events)" % MAC_PER_FPMUL[cid]},
+        "sequential": {"ms_per_step_median": statistics.median(seq), "ms_per_step_min": min(seq), "value": n / (statistics.median(seq) * 1e-3)},
         "stage_ms_exclusive": {k: (v[0] / max(v[1], 1)) for k, v in stages_excl.items()},
-    }), flush=True)
+    }
 
 
-def bench_multisig_hae(args, lib, cid, fp, n, rank, world):
-    """VerifyMultiSignatureWithHAE (bgls/blsHAE.go:56-58) -- exponents from BLAKE2Xb over all keys (root
-    digest on the host while the keys upload, expansion on the device), apk = sum t_i pk_i as one fused weighted sum, then
-    a single-signature check.  Host-buffer entry point: the hash needs the key bytes on the host, so this figure is
-    PCIe- and host-hash-inclusive by construction."""
-    if world != 1:
-        raise SystemExit("multisig-hae workload is single-GPU in this round")
-    rnd = random.Random(0xB6150000 + 6)
-    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
-    g2 = (ctypes.c_uint8 * (4 * fp))()
-    check(lib.bgls_generator(cid, 2, g2), "generator")
-    keys = (ctypes.c_uint8 * (n * 4 * fp))()
-    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(b"".join(s.to_bytes(32, "big") for s in sks)), None, n, keys), "scale_points(G2)")
-    t_raw = (ctypes.c_uint8 * (16 * n))()
-    t0 = time.perf_counter()
-    check(lib.bgls_hae_exponents(cid, keys, n, t_raw), "hae_exponents")
-    t_hash = time.perf_counter() - t0
-    tb = bytes(t_raw)
-    e = sum(sk * int.from_bytes(tb[16 * i:16 * i + 16], "big") for i, sk in enumerate(sks)) % ORDER[cid]
-    msg = rnd.randbytes(64)
-    off = (ctypes.c_uint64 * 2)(0, len(msg))
-    h = (ctypes.c_uint8 * (2 * fp))()
-    check(lib.bgls_hash_to_g1(cid, B(msg), off, 1, h), "hash_to_g1")
-    sig = (ctypes.c_uint8 * (2 * fp))()
-    check(lib.bgls_scale_points(cid, 1, h, B(e.to_bytes(32, "big")), None, 1, sig), "scale_points(sig)")
-    mb = B(msg)
+def bench_small(lib, dev, inst, n, reps):
+    """BASELINE config 1: the reference's own benchmark shape, alt-bn128 n = 64 (bgls/bgls_test.go:186-202
+    BenchmarkAggregateVerification) -- one verification at a time, latency-bound."""
+    cid, fp = inst["cid"], inst["fp"]
+    t_keys = torch.frombuffer(bytearray(inst["keys"][:n * 4 * fp]), dtype=torch.uint8).to(dev)
+    t_msgs = torch.frombuffer(bytearray(inst["msgs"][:n * 64]), dtype=torch.uint8).to(dev)
+    t_sig = torch.frombuffer(bytearray(aggregate_sig(lib, inst, 0, n)), dtype=torch.uint8).to(dev)
+    part = torch.zeros(12 * fp, dtype=torch.uint8, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
 
-    def step(nn=n):
-        return check(lib.bgls_verify_multi_hae(cid, sig, keys, nn, mb, len(msg)), "verify_multi_hae")
+    def one():
+        flags.zero_()
+        check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), t_msgs.data_ptr(), 64, 64, n, 1, part.data_ptr(), flags.data_ptr(), stream), "miller_product_dev")
+        return check(lib.bgls_final_verify_dev(cid, part.data_ptr(), 1, flags.data_ptr(), stream), "final_verify_dev")
 
-    if step() != 1 or step(n - 1) != 0:
-        raise RuntimeError("multisig-hae correctness gate failed")
-    for _ in range(args.warmup):
-        step()
-    lib.bgls_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if step() != 1:
-            raise RuntimeError("verification failed inside the timed region")
-    elapsed = time.perf_counter() - t0
-    sum_ms, sum_cnt = stage(lib, "sum_points")
-    lib.bgls_profile_enable(0)
-    peak = ctypes.c_double()
-    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
-    avg_s = sum_ms / args.steps * 1e-3
-    fpmul_per_signer = 127 * 18 + 64 * 29                 # 128-bit double-and-add on G2: doubling ~ 18 m, mixed addition ~ 29 m
-    macs = n * fpmul_per_signer * MAC_PER_FPMUL[cid]
-    print(json.dumps({
-        "metric": "multisig-hae-verify signers/sec", "value": n * args.steps / elapsed, "unit": "signers/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%s VerifyMultiSignatureWithHAE, %d signers on one message, host buffers (keys cross PCIe and are "
-                               "hashed on the host inside the call)" % (args.curve, n)},
-        "roofline": {"bound": "valu-int32-mac", "kernel": "k_wsum_first (+k_sum_next)", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
-                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3},
-        "host_side": {"blake2xb_root_plus_expansion_ms": t_hash * 1e3, "key_bytes": n * 4 * fp,
-                      "note": "the BLAKE2Xb root is one sequential compression chain over all key bytes (blsHAE.go:81-84)"},
-    }), flush=True)
-
-
-def bench_decompress(args, lib, cid, fp, n, rank, world):
-    """UnmarshalG2 of n compressed alt-bn128 keys (curves/altbn128.go:329-376) -- the step in front of the
-    hot path when keys arrive over the wire.  Host buffers in and out (64 B -> 128 B per key)."""
-    if world != 1 or cid != 0:
-        raise SystemExit("decompress workload: alt-bn128, single GPU")
-    rnd = random.Random(0xB6150000 + 7)
-    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
-    g2 = (ctypes.c_uint8 * 128)()
-    check(lib.bgls_generator(cid, 2, g2), "generator")
-    keys = (ctypes.c_uint8 * (n * 128))()
-    check(lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(b"".join(s.to_bytes(32, "big") for s in sks)), None, n, keys), "scale_points(G2)")
-    comp = (ctypes.c_uint8 * (n * 64))()
-    check(lib.bgls_compress_points(cid, 2, keys, n, comp), "compress_points")
-    out = (ctypes.c_uint8 * (n * 128))()
-    ok = (ctypes.c_uint8 * n)()
-
-    def step():
-        check(lib.bgls_decompress_points(cid, 2, comp, n, out, ok), "decompress_points")
-
-    step()
-    if bytes(out) != bytes(keys) or bytes(ok) != b"\x01" * n:
-        raise RuntimeError("decompress round trip failed")
-    for _ in range(args.warmup):
-        step()
-    lib.bgls_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_cnt = stage(lib, "sum_points")
-    lib.bgls_profile_enable(0)
-    peak = ctypes.c_double()
-    check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
-    avg_s = k_ms / max(k_cnt, 1) * 1e-3
-    fpmul_per_key = 3 * 320 + 40          # reference algorithm: two square roots and one residuosity test by exponentiation, plus x^3 etc.
-    macs = n * fpmul_per_key * MAC_PER_FPMUL[cid]
-    print(json.dumps({
-        "metric": "G2 key decompression keys/sec", "value": n * args.steps / elapsed, "unit": "keys/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "altbn128 UnmarshalG2 (compressed), %d keys, host buffers in and out" % n},
-        "roofline": {"bound": "valu-int32-mac", "kernel": "k_decompress_bn<2>", "achieved": macs / avg_s / 1e12, "peak": peak.value / 1e12,
-                     "unit": "TMAC/s", "frac": macs / avg_s / peak.value, "traffic": None, "launch_ms": avg_s * 1e3,
-                     "hbm_algorithmic_GBps": n * 192 / avg_s / 1e9},
-    }), flush=True)
+    if one() != 1:
+        raise RuntimeError("n = %d instance rejected" % n)
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if one() != 1:
+            raise RuntimeError("verification failed")
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    med = statistics.median(ts)
+    return {"metric": "aggregate-verify signer-pairs/sec", "value": n / (med * 1e-3), "unit": "signer-pairs/s", "ms_per_step": med, "ms_per_step_min": min(ts),
+            "steps": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s VerifyAggregateSignature, %d signers (the reference's BenchmarkAggregateVerification shape), one call at a time" % (CNAME[cid], n)},
+            "roofline": None, "note": "latency-bound: one block per stage; reference's published figure for this shape: 23.1 ms on 8 laptop threads (README.md:45)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
+    ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 20, help="signers of the headline batch (whole job)")
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
-    ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 16, help="signers per GPU")
+    ap.add_argument("--in-flight", type=int, default=4, help="verifications kept in flight (1 = strictly sequential, max 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="keep the 64-pairing Miller kernel also when launches overlap")
-    ap.add_argument("--in-flight", type=int, default=None,
-                    help="verifications kept in flight (1 = strictly sequential, max 16); default 4, multisig workload 8")
-    ap.add_argument("--workload", default="aggregate", choices=["aggregate", "multisig", "multisig-hae", "decompress"],
-                    help="aggregate = VerifyAggregateSignature (headline); multisig = KoskVerifyMultiSignature (BASELINE config 4)")
+    ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "small"], help="run ONE record (profiling runs): --curve, --n apply")
+    ap.add_argument("--no-records", action="store_true", help="headline only")
     args = ap.parse_args()
-    if args.in_flight is None:
-        args.in_flight = 8 if args.workload == "multisig" else 4
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,184 +486,55 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     check(lib.bgls_init(local_rank), "bgls_init")
-    cid = 0 if args.curve == "altbn128" else 1
-    fp = 32 if cid == 0 else 48
-    n = args.n
-    gtb = 12 * fp
+    tp = not args.no_throughput_mode
 
-    if args.workload == "multisig":
-        return bench_multisig(args, lib, cid, fp, n, dev, rank, world)
-    if args.workload == "multisig-hae":
-        return bench_multisig_hae(args, lib, cid, fp, n, rank, world)
-    if args.workload == "decompress":
-        return bench_decompress(args, lib, cid, fp, n, rank, world)
+    def shard_instance(cid, n_total, seed):
+        """this rank's contiguous range of an n_total-signer batch (every rank generates only its own signers)"""
+        lo, hi = shard_range(n_total, rank, world)
+        return make_instance(lib, cid, hi - lo, seed + 1000 * rank)
 
-    # ---- setup (untimed): resident shard + the global aggregate signature on rank 0
-    keys, msgs, part_sig, sigs = make_shard(lib, cid, n, 0xB6150000 + 1 + 1000 * rank)
-    t_keys = torch.frombuffer(bytearray(keys), dtype=torch.uint8).to(dev)
-    t_msgs = torch.frombuffer(bytearray(msgs), dtype=torch.uint8).to(dev)
-    t_psig = torch.frombuffer(bytearray(part_sig), dtype=torch.uint8).to(dev)
-    all_sigs = all_gather_bytes(t_psig, world)
-    agg = (ctypes.c_uint8 * (2 * fp))()
-    check(lib.bgls_aggregate_points(cid, 1, B(bytes(all_sigs.cpu().numpy().tobytes())), world, agg), "aggregate_points(global)")
-    t_sig = torch.frombuffer(bytearray(bytes(agg)), dtype=torch.uint8).to(dev)
-    # L verifications in flight on L library contexts / streams (default 4): every step is still one complete pass (duplicate
-    # scan, hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound
-    # stages of one step overlap the Miller launch of its neighbours.  --in-flight 1 runs them strictly one after the other.
-    L = max(1, min(16, args.in_flight))
-    lanes = [{"stream": torch.cuda.Stream(device=dev), "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
-              "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for _ in range(L)]
-    torch.cuda.synchronize()
+    if args.only == "multisig":
+        inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000 + 4)
+        print(json.dumps(bench_multisig(lib, dev, inst, args.n, args.steps, args.warmup, args.reps, args.in_flight)), flush=True)
+        return
+    if args.only == "small":
+        inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000)
+        print(json.dumps(bench_small(lib, dev, inst, args.n, max(args.steps, 20))), flush=True)
+        return
 
-    def submit(k, msgs_t=t_msgs):
-        """Enqueue one complete verification on lane k (its own library context and stream); nothing here waits for the GPU."""
-        ln = lanes[k]
-        h = ln["stream"].cuda_stream
-        check(lib.bgls_select_context(k), "select_context")
-        with torch.cuda.stream(ln["stream"]):
-            ln["flags"].zero_()
-            if world > 1:                 # duplicates may straddle shards: exact scan over every rank's messages
-                global_duplicate_scan(lambda buf, count: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, ln["flags"].data_ptr(), h),
-                                                               "duplicate_scan_dev"), msgs_t, n, world)
-            check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
-                                              64, 64, n, 1 if world == 1 else 0, ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
-            if world == 1:
-                check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
-            else:
-                parts, merged = gather_partials_and_flags(ln["part"], ln["flags"], world)
-                check(lib.bgls_final_verify_submit_dev(cid, parts.data_ptr(), world, merged.data_ptr(), h), "final_verify_submit_dev")
-
-    def collect(k):
-        check(lib.bgls_select_context(k), "select_context")
-        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
-
-    def step(msgs_t=t_msgs):
-        submit(0, msgs_t)
-        return collect(0)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # correctness gate: the valid instance verifies, one flipped message bit rejects
-    if step() != 1:
-        raise RuntimeError("valid instance rejected")
-    bad = t_msgs.clone()
-    if rank == world - 1:
-        bad[64 * (n // 2) + 3] ^= 0x20
-    torch.cuda.synchronize()              # `bad` was written on torch's default stream, the lanes have their own
-    if step(bad) != 0:
-        raise RuntimeError("tampered instance accepted")
-
-    pipelined = L > 1
-
-    def run(count, overlap):
-        if not overlap:
-            for _ in range(count):
-                if step() != 1:
-                    raise RuntimeError("verification failed inside the timed region")
-            return
-        for i in range(count):
-            submit(i % L)
-            if i >= L - 1 and collect((i - L + 1) % L) != 1:
-                raise RuntimeError("verification failed inside the timed region")
-        for i in range(max(0, count - L + 1), count):
-            if collect(i % L) != 1:
-                raise RuntimeError("verification failed inside the timed region")
-        check(lib.bgls_select_context(0), "select_context")
-
-    # warm-up: W steps one at a time with the stage timers on -- these give each kernel's duration when it has the machine
-    # to itself ("exclusive"); then, if overlapping, L untimed overlapped steps to prime the other contexts' workspaces
-    lib.bgls_profile_enable(1)
-    run(args.warmup, False)
-    sync()
-    stages_excl = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
-    if pipelined:
-        # launches overlap from here on: alt-bn128 Miller launches may take the shape that is fastest in that regime
-        # (bgls_set_throughput_mode: 60 pairings per block, see k_miller_s60); verdicts are identical in both modes
-        if cid == 0 and not args.no_throughput_mode:
-            check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
-        run(L, True)
-    lib.bgls_profile_enable(1)
-    sync()
-    t0 = time.perf_counter()
-    run(args.steps, pipelined)
-    sync()
-    elapsed = time.perf_counter() - t0
-    check(lib.bgls_set_throughput_mode(0), "set_throughput_mode")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stages = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
-    lib.bgls_profile_enable(0)
-
-    if rank == 0:
-        peak = ctypes.c_double()
-        check(lib.bgls_probe_mad_peak(ctypes.byref(peak)), "probe_mad_peak")
-        mil_ms, mil_cnt = stages["miller"]
-        mil_events_s = mil_ms / max(mil_cnt, 1) * 1e-3        # HIP events around the launch on its own stream
-        macs_per_launch = (n + 1) * MILLER_FPMUL[cid] * MAC_PER_FPMUL[cid]
-        # With several verifications in flight the launches of the dominant kernel share the machine: the events around ONE
-        # launch then also span the time it waits for and shares SIMDs with its neighbours.  The time one launch costs
-        # the machine over the timed region is the region divided by the launches in it (= ms_per_step, every other
-        # stage's time included, so this is the conservative reading); strictly sequential runs use the events.
-        mil_avg_s = mil_events_s if L == 1 else elapsed / args.steps
-        achieved = macs_per_launch / mil_avg_s / 1e12 if mil_avg_s > 0 else 0.0
-        value = world * n * args.steps / elapsed
-        ex_ms, ex_cnt = stages_excl["miller"]
-        excl = None
-        if ex_cnt:
-            ex_s = ex_ms / ex_cnt * 1e-3
-            excl = {"launch_ms": ex_s * 1e3, "achieved": macs_per_launch / ex_s / 1e12, "frac": macs_per_launch / ex_s / peak.value if peak.value else None,
-                    "note": "the Miller launch with one verification in flight (the %d warm-up steps; k_miller_ab64, the shape the library "
-                            "uses when launches do not overlap): its duration with the machine to itself.  With %d in flight consecutive "
-                            "launches share the machine: launch_ms_events (HIP events around one launch) stretches, launch_ms = timed "
-                            "region / launches is what a launch costs the machine." % (ex_cnt, L)}
-        cname = "BN254" if cid == 0 else "BLS381"
-        # the library's dispatch rule (Engine::miller_coop): 64 pairings per block, consecutive launches of 1024 blocks
-        miller_kernel = "k_miller_ab64<%s>%s" % (cname, "" if (n + 63) // 64 <= 1024 else " x%d launches" % (((n + 63) // 64 + 1023) // 1024))
-        if pipelined and cid == 0 and not args.no_throughput_mode:
-            miller_kernel = "k_miller_s60<BN254> (timed region; the exclusive figures are k_miller_ab64<BN254>, the shape used when launches do not overlap)"
-        out = {
-            "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s VerifyAggregateSignature, %d signers per GPU (%d total), distinct 64-byte messages, "
-                                   "keys and messages resident in HBM" % (args.curve, n, world * n),
-                       "curve": args.curve, "signers_per_gpu": n, "in_flight": L, "parallelism": "signer-shards x%d + all-gather of GT partials" % world},
-            "roofline": {"bound": "valu-int32-mac", "kernel": miller_kernel, "achieved": achieved, "peak": peak.value / 1e12,
-                         "unit": "TMAC/s", "frac": achieved / (peak.value / 1e12) if peak.value else None, "traffic": None,
-                         "launch_ms": mil_avg_s * 1e3, "launch_ms_events": mil_events_s * 1e3, "macs_per_launch": macs_per_launch,
-                         "exclusive": excl,
-                         "hbm_side": {"achieved": n * ALGO_BYTES_PER_PAIR[cid] / mil_avg_s / 1e9 if mil_avg_s > 0 else None, "peak": 8000.0,
-                                      "unit": "GB/s", "note": "algorithmic bytes of one Miller launch / its duration"},
-                         "note": "integer bignum path: bounded by v_mad_u64_u32 issue, not HBM or MFMA (SURVEY 8d); peak measured "
-                                 "live by bgls_probe_mad_peak; HBM side: %.3f GB/s algorithmic of 8000 peak"
-                                 % (value * ALGO_BYTES_PER_PAIR[cid] / world / 1e9),
-                         "whole_path_frac": value / world * PAIR_FPMUL[cid] * MAC_PER_FPMUL[cid] / peak.value if peak.value else None},
-            "stage_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items()},
-            "stage_ms_exclusive": {k: (v[0] / max(v[1], 1)) for k, v in stages_excl.items()},
-        }
+    cid = CURVE[args.curve]
+    inst = shard_instance(cid, args.n, 0xB6150000 + 1 + cid)
+    head = bench_aggregate(lib, dev, inst, args.n, rank, world, args.steps, args.warmup, args.reps, args.in_flight, tp, "headline")
+    records = {}
+    if args.only is None and not args.no_records:
+        other = 1 - cid
+        oinst = shard_instance(other, args.n, 0xB6150000 + 1 + other)
+        r = bench_aggregate(lib, dev, oinst, args.n, rank, world, max(2, args.steps // 2), 1, args.reps, args.in_flight, tp, CNAME[other], with_h2d=False)
+        if rank == 0:
+            records["%s_%d" % (CNAME[other], args.n)] = r
         if world == 1:
-            # the same verification through the host-buffer entry point (keys + messages cross PCIe inside the call)
-            off = (ctypes.c_uint64 * (n + 1))(*[64 * i for i in range(n + 1)])
-            kb_, mb_, sb_ = B(keys), B(msgs), B(bytes(agg))
-            check(lib.bgls_verify_aggregate(cid, sb_, kb_, mb_, off, n, 0), "verify_aggregate(host)")
-            t1 = time.perf_counter()
-            ok = check(lib.bgls_verify_aggregate(cid, sb_, kb_, mb_, off, n, 0), "verify_aggregate(host)")
-            dt = time.perf_counter() - t1
-            out["pcie_inclusive"] = {"value": n / dt, "unit": "signer-pairs/s", "ms_per_call": dt * 1e3, "verdict": ok,
-                                     "note": "bgls_verify_aggregate with host buffers (pageable memory), never the headline value"}
-            pmc = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
-            if os.path.exists(pmc) and args.curve == "altbn128" and n == 1 << 16:
-                det = json.load(open(pmc))          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the evidence run (profiles/r1)
-                shape = det.get("throughput_shape") if (pipelined and cid == 0 and not args.no_throughput_mode) else None
-                out["roofline"]["traffic"] = (shape or det).get("bytes_per_launch_fetch_x2")     # bytes per launch, gfx950 FETCH_SIZE correction applied
-                out["roofline"]["traffic_detail"] = det
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cid, keys, msgs, sigs, n, fp, lib)
+            small_n = min(1 << 16, args.n)
+            for c_, i_ in ((cid, inst), (other, oinst)):
+                i_["n_local"] = small_n
+                records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 20, 3, args.reps, args.in_flight, tp, CNAME[c_] + " 2^16")
+                i_["n_local"] = i_["n"]
+            bn = inst if cid == 0 else oinst
+            records["altbn128_multisig_%d" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16)
+            records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)
+            if not args.no_cpu_baseline:
+                for c_, i_ in ((cid, inst), (other, oinst)):
+                    cb = cpu_baseline(c_, i_, lib)
+                    for key in ("%s_%d" % (CNAME[c_], args.n), "%s_%d" % (CNAME[c_], small_n)):
+                        if key in records:
+                            records[key]["cpu_baseline"] = cb
+                    if c_ == cid:
+                        head["cpu_baseline"] = cb
+    elif world == 1 and not args.no_cpu_baseline and args.only is None:
+        head["cpu_baseline"] = cpu_baseline(cid, inst, lib)
+    if rank == 0:
+        out = dict(head)
+        out.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None})
+        out["records"] = records
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -411,11 +411,13 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ); env["BGLS_BENCH_SHARE_GPU"] = "1"
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--signers", "4096", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                          "--signers", "8192", "--no-cpu-baseline", "--reps", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-800:], out.stderr[-1500:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["signers_per_gpu"] == 4096
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["signers_per_gpu"] == 4096
+    other = d["records"]["bls12_8192"]                     # the BLS12-381 record rides on the same line for every N
+    assert other["n_gpus"] == 2 and other["value"] > 0 and other["config"]["signers_per_gpu"] == 4096
 
 
 def test_two_contexts_in_flight(gpu_lib, curve):
