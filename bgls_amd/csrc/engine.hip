@@ -58,7 +58,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 constexpr size_t MAX_BATCH = (size_t)1 << 30;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -353,6 +353,8 @@ struct Engine {
       if (throughput_mode() && npairs >= 1) {
         // 60 pairings per block, 28-bit-limb consumer; the signature pair goes to the epilogue kernel
         const size_t nb60 = (npairs + 59) / 60, groups = nb60 * 10;
+        void* qp;
+        if ((rc = c.get(WS_QP, kl::miller_qp_bytes<C>(nb60 < 8192 ? nb60 : 8192), &qp))) return rc;
         if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
         if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
         {
@@ -360,7 +362,7 @@ struct Engine {
           for (size_t blk0 = 0; blk0 < nb60; blk0 += 8192) {
             const size_t nblocks = nb60 - blk0 < 8192 ? nb60 - blk0 : 8192;
             const size_t p0 = blk0 * 60;
-            kl::miller_s60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, miller_dbg());
+            kl::miller_s60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, miller_dbg(), (uint32_t*)qp);
           }
           HIPCHK(hipGetLastError());
         }
@@ -373,6 +375,8 @@ struct Engine {
     // consecutive launches of 1024 blocks.  Block 0 of the first launch also scales the generator lines for the
     // signature pair (unless the epilogue kernel does: cofactor path).
     const size_t nb64 = npairs ? (npairs + 63) / 64 : 1, groups = nb64 * 10;
+    void* qp;
+    if ((rc = c.get(WS_QP, kl::miller_qp_bytes<C>(nb64 < 1024 ? nb64 : 1024), &qp))) return rc;
     if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
     if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
@@ -382,7 +386,7 @@ struct Engine {
         const size_t p0 = blk0 * 64;
         const size_t np = npairs - p0 < nblocks * 64 ? npairs - p0 : nblocks * 64;
         const long long sig_at = (blk0 == 0 && sig && !cofactor) ? (long long)(sig - (g1s + p0)) : -1LL;
-        kl::miller_ab64<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, np, sig_at, gl, (Fp2<C>*)pa + blk0 * 10 * 6, d_flags, miller_dbg());
+        kl::miller_ab64<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, np, sig_at, gl, (Fp2<C>*)pa + blk0 * 10 * 6, d_flags, miller_dbg(), (uint32_t*)qp);
       }
       HIPCHK(hipGetLastError());
     }

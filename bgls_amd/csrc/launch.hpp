@@ -36,10 +36,11 @@ template <class C> size_t jac_bytes(int group) { return (size_t)3 * (group == 1 
 // ---- k_miller_bn.hip / k_miller_bls.hip   (dbg != 0 only in -DBGLS_DEV builds: timing variants, wrong results)
 template <class C>
 void miller_ab64(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
-                 const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, int dbg);
+                 const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, int dbg, uint32_t* qp);
+template <class C> constexpr size_t miller_qp_bytes(size_t nblocks) { return nblocks * 64 * 6 * C::L * 4; }    // parked Q, P of every producer lane
 template <class C>
 void miller_s60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags,
-                int dbg);
+                int dbg, uint32_t* qp);
 
 template <class C> size_t lines_bytes(int variant, size_t n_pad);
 template <class C>

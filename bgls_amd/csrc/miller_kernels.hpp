@@ -28,6 +28,40 @@ struct CoopLane {
   }
 };
 
+
+// ---- the producer's fixed operands, parked in HBM ----------------------------------------------------------------------
+// A producer lane needs its key Q (Fp2 x, y) only in the addition steps and its hash point P (x, y) only to scale the line
+// coefficients, but as loop-invariant values they sit in registers through every Fp2 product and push the point-step
+// temporaries out to the private stack (BLS12-381: 72 of 256 registers; 14.6 GB of spill traffic per launch, 870x the
+// algorithmic bytes, profiles/r2 interim).  They are parked in a lane-interleaved workspace instead (element k of lane l
+// of block b at ((b * QP_DW + k) * 64 + l)) and re-read through a laundered pointer where they are used: 96-288 bytes per
+// step and lane from L2 instead of spills around every product.
+template <class C>
+struct QP {
+  static constexpr int L = C::L;
+  static constexpr int QX = 0, QY = 2 * L, PX = 4 * L, PY = 5 * L, DW = 6 * L;
+  static __device__ __forceinline__ void st_fp(u32* base, int off, const Fp<C>& a) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) base[(size_t)(off + k) * 64] = a.v[k];
+  }
+  static __device__ __forceinline__ Fp<C> ld_fp(const u32* base, int off) {
+    Fp<C> r;
+#pragma unroll
+    for (int k = 0; k < L; ++k) r.v[k] = base[(size_t)(off + k) * 64];
+    return r;
+  }
+  static __device__ __forceinline__ void park(u32* base, const Aff<F2<C>>& Q, const Aff<F1<C>>& P) {
+    st_fp(base, QX, Q.x.c0); st_fp(base, QX + L, Q.x.c1);
+    st_fp(base, QY, Q.y.c0); st_fp(base, QY + L, Q.y.c1);
+    st_fp(base, PX, P.x); st_fp(base, PY, P.y);
+  }
+  static __device__ __forceinline__ const u32* launder(const u32* p) {       // opaque to the optimiser: no hoisting out of the step loop
+    asm volatile("" : "+v"(p));
+    return p;
+  }
+  static __device__ __forceinline__ Fp2<C> ld_f2(const u32* base, int off) { return {ld_fp(base, off), ld_fp(base, off + L)}; }
+};
+
 // ---- 64 pairings per block, 256 VGPRs (two waves per SIMD, 1024 blocks = exactly one 2^16 batch) ----------
 // Same producer/consumer scheme as k_miller_ab, but the producer wave uses all 64 lanes (lane l feeds line
 // slot l/10 of group l%10, so groups 0..3 fold seven lines and the others six plus a constant 1), the
@@ -55,7 +89,7 @@ struct Coop64 {
 // R28 (alt-bn128): the consumer works on 28-bit limbs (coop_r28.hpp); the producer converts what it stores.
 template <class C, int DBG = 0, bool R28 = false>
 __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
-                                                        const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, unsigned swap_mask) {
+                                                        const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, unsigned swap_mask, u32* qp) {
   typedef Coop64<C, R28> K;
   // The two waves of a block land on different SIMDs and every CU hosts four blocks: if wave 0 were the producer
   // everywhere, two SIMDs of a CU would carry two producers and the other two would carry two consumers, and the kernel
@@ -103,6 +137,8 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
       }
     }
     G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+    u32* const myqp = qp + (size_t)blockIdx.x * QP<C>::DW * 64 + lane;
+    QP<C>::park(myqp, Q, P);
     int buf = 0, step = 0;
     auto publish = [&](LineCapture<C>& cap) {
       if constexpr (DBG == 2) { ++step; __syncthreads(); buf ^= 1; return; }
@@ -130,29 +166,38 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       {
-        LineCapture<C> cap{{}, P.x, P.y};
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        LineCapture<C> cap{{}, px, py};
         if constexpr (DBG != 2) dbl_step_emit<C>(T, cap);
         publish(cap);
       }
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        LineCapture<C> cap{{}, P.x, P.y};
-        if constexpr (DBG != 2) add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), cap);
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        const Fp2<C> qx = QP<C>::ld_f2(q, QP<C>::QX), qy = QP<C>::ld_f2(q, QP<C>::QY);
+        LineCapture<C> cap{{}, px, py};
+        if constexpr (DBG != 2) add_step_emit<C>(T, qx, d > 0 ? qy : f2_neg<C>(qy), cap);
         publish(cap);
       }
     }
     if constexpr (C::CURVE_ID == 0) {
       {
-        Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
-        Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-        LineCapture<C> cap{{}, P.x, P.y};
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        Fp2<C> x1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QX)), gamma_const<C>(1, 2));
+        Fp2<C> y1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QY)), gamma_const<C>(1, 3));
+        LineCapture<C> cap{{}, px, py};
         if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, cap);
         publish(cap);
       }
       {
-        Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
-        Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-        LineCapture<C> cap{{}, P.x, P.y};
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        Fp2<C> x2 = f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QX), gamma_const<C>(2, 2));
+        Fp2<C> y2 = f2_neg<C>(f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QY), gamma_const<C>(2, 3)));
+        LineCapture<C> cap{{}, px, py};
         if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, cap);
         publish(cap);
       }
@@ -258,7 +303,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
 // more than fit at once, which is irrelevant while launches overlap and a second, nearly empty round when they do not --
 // hence only in throughput mode (bgls_set_throughput_mode).
 template <class C, int DBG = 0>    // DBG 1 / 2: producer / consumer work only (timing, wrong results)
-__global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags) {
+__global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* qp) {
   static_assert(C::CURVE_ID == 0 && C::TWIST_D, "alt-bn128 only");
   typedef Coop64<C, true> K;
   const int wave = threadIdx.x >> 6;
@@ -287,6 +332,8 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
       P.y = fp_load<C>(C::G1Y);
     }
     G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
+    u32* const myqp = qp + (size_t)blockIdx.x * QP<C>::DW * 64 + lane;
+    QP<C>::park(myqp, Q, P);
     int buf = 0;
     auto done = [&]() {
       wave_sync();
@@ -295,22 +342,35 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      if constexpr (DBG != 2) dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
-      done();
+      {
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        if constexpr (DBG != 2) dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
+        done();
+      }
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        if constexpr (DBG != 2) add_step_emit<C>(T, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+        const u32* q = QP<C>::launder(myqp);
+        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+        const Fp2<C> qx = QP<C>::ld_f2(q, QP<C>::QX), qy = QP<C>::ld_f2(q, QP<C>::QY);
+        if constexpr (DBG != 2) add_step_emit<C>(T, qx, d > 0 ? qy : f2_neg<C>(qy), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
         done();
       }
     }
     {
-      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
-      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-      if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+      const u32* q = QP<C>::launder(myqp);
+      const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QX)), gamma_const<C>(1, 2));
+      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QY)), gamma_const<C>(1, 3));
+      if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
       done();
-      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
-      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-      if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, P.x, P.y, valid, owner});
+    }
+    {
+      const u32* q = QP<C>::launder(myqp);
+      const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
+      Fp2<C> x2 = f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QX), gamma_const<C>(2, 2));
+      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QY), gamma_const<C>(2, 3)));
+      if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
       done();
     }
   } else {
