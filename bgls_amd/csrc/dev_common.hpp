@@ -18,7 +18,7 @@ struct MsgView {
 };
 
 // status word of a verification (device u32, OR-ed by the kernels; mapped to BGLS_ERR_* / verdict 0 by the engine)
-enum : uint32_t { FLAG_DUP = 1u, FLAG_ENC = 2u, FLAG_HASH = 4u, FLAG_SUBGROUP = 8u };
+enum : uint32_t { FLAG_DUP = 1u, FLAG_ENC = 2u, FLAG_HASH = 4u, FLAG_SUBGROUP = 8u, FLAG_DEGENERATE = 16u };
 
 inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 

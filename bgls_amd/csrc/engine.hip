@@ -237,6 +237,45 @@ struct Engine {
     return miller(c, st, (const Aff<G1F>*)g1s, d_keys, n, d_sig ? (const Aff<G1F>*)g1s + n : nullptr, d_partial, d_flags, raw);
   }
 
+  // The same product against a PREPARED key range (prepared.hpp): no point steps, the hash points only scale the resident
+  // line ratios.  BLS12-381 hash points stay uncleared as on the unprepared path: the cofactor is applied once in GT.
+  static int miller_product_prepared(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint32_t* d_prep, const uint8_t* d_kinf, size_t n_pad,
+                                     MsgView mv, size_t n, uint8_t* d_partial, uint32_t* d_flags) {
+    if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+    void *g1s, *ptab, *pa, *pb;
+    int rc;
+    if ((rc = c.get(WS_G1S, (n + 2) * sizeof(Aff<G1F>), &g1s))) return rc;
+    const bool raw = C::CURVE_ID == 1 && n > 0;
+    if (n) {
+      Scope sc(c, st, ST_H2C);
+      if ((rc = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags, raw))) return rc;
+    }
+    const Aff<G1F>* sig = nullptr;
+    const LineCoeffs<C>* gl = nullptr;
+    if (d_sig) {
+      kl::g1_parse<C>(st, d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
+      sig = (const Aff<G1F>*)g1s + n;
+      if ((rc = gen_lines(c, &gl))) return rc;
+    }
+    if (n == 0) return miller(c, st, (const Aff<G1F>*)g1s, nullptr, 0, sig, d_partial, d_flags, false);
+    // pairings per squaring: as many as still leave about two waves per SIMD
+    const int ng = n_pad >= ((size_t)1 << 19) ? 24 : n_pad >= ((size_t)1 << 18) ? 12 : 6;
+    const kl::PrepSizes ps = kl::prep_sizes<C>();
+    const size_t groups = n_pad / ng;
+    if ((rc = c.get(WS_LINES, n_pad * ps.point_bytes, &ptab))) return rc;
+    if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    {
+      Scope sc(c, st, ST_MILLER);
+      kl::prep_points<C>(st, (const Aff<G1F>*)g1s, d_kinf, n, n_pad, (uint32_t*)ptab);
+      kl::fold_prep<C>(st, d_prep, (const uint32_t*)ptab, n_pad, ng, (Fp2<C>*)pa);
+      HIPCHK(hipGetLastError());
+    }
+    Fp2<C>* red = nullptr;
+    if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, groups, &red))) return rc;
+    return emit_partial(c, st, red, raw || sig != nullptr, sig, gl, d_partial);
+  }
+
   // H(m_i) as affine Montgomery points.  raw (BLS12-381 only): points before cofactor clearing, for the cofactor-in-GT
   // verification path.
   static int hash_to_g1(Ctx& c, hipStream_t st, MsgView mv, size_t n, Aff<G1F>* out, uint32_t* d_flags, bool raw = false) {
@@ -1256,18 +1295,23 @@ struct KeyShard {
   void* d_mont = nullptr;    // the same keys as Aff<F2<C>> (Montgomery form), for the key sums
   void* d_rec = nullptr;     // this shard's exchange record: GT partial + status word (send buffer)
   void* d_all = nullptr;     // every shard's record (receive buffer)
+  // prepared sets (BGLS_KEYS_PREPARE, prepared.hpp): normalised line ratios of every key and step, [step][n_pad] rows
+  void* d_prep = nullptr;
+  void* d_kinf = nullptr;    // n_pad bytes: 1 = key at infinity / padding
+  size_t n_pad = 0;          // hi - lo rounded up to whole fold groups for every NG in use
 };
 struct KeySet {
   int curve = 0;
   size_t n = 0;
   std::vector<KeyShard> shards;
+  bool prepared = false;
   std::vector<ncclComm_t> comms;     // one per shard when the RCCL exchange is usable, else empty
   std::mutex mu;                     // one verification at a time per key set (the shards' buffers are part of it)
   ~KeySet() {
     for (auto cm : comms) if (cm) (void)rccl().CommDestroy(cm);
     for (auto& sh : shards) {
       if (hipSetDevice(sh.device) != hipSuccess) continue;
-      for (void* q : {sh.d_wire, sh.d_mont, sh.d_rec, sh.d_all}) if (q) (void)hipFree(q);
+      for (void* q : {sh.d_wire, sh.d_mont, sh.d_rec, sh.d_all, sh.d_prep, sh.d_kinf}) if (q) (void)hipFree(q);
     }
   }
 };
@@ -1283,6 +1327,7 @@ std::shared_ptr<KeySet> keyset(bgls_keys_t h) {
 }
 
 constexpr size_t REC_PAD = 16;     // status word + padding behind the GT bytes of an exchange record
+constexpr size_t PREP_PAD = 240;   // prepared sets are padded to whole waves of 10 groups for NG = 6, 12 and 24
 
 template <class C>
 int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* out) {
@@ -1291,6 +1336,7 @@ int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devic
   auto ks = std::make_shared<KeySet>();
   ks->curve = C::CURVE_ID;
   ks->n = n;
+  ks->prepared = (flags & BGLS_KEYS_PREPARE) != 0;
   const size_t REC = E::GTB + REC_PAD;
   bool distinct = true;
   for (int s = 0; s < n_devices; ++s) {
@@ -1331,6 +1377,28 @@ int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devic
       HIPCHK(hipStreamSynchronize(c.stream));
       if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "key set: non-canonical coordinate or key not on the twist");
       if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "key set: key outside the order-r subgroup");
+      if (flags & BGLS_KEYS_PREPARE) {
+        // line ratios of every key (k_prepare), in chunks so that the scratch stays a few GB
+        const kl::PrepSizes ps = kl::prep_sizes<C>();
+        sh.n_pad = (cnt + PREP_PAD - 1) / PREP_PAD * PREP_PAD;
+        if (sh.n_pad == 0) sh.n_pad = PREP_PAD;
+        HIPCHK(hipMalloc(&sh.d_prep, sh.n_pad * ps.line_bytes_per_key));
+        HIPCHK(hipMalloc(&sh.d_kinf, sh.n_pad));
+        const size_t chunk = (size_t)1 << 17;
+        void* tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, (sh.n_pad < chunk ? sh.n_pad : chunk) * ps.tmp_bytes_per_key));
+        HIPCHK(hipMemsetAsync(d_flags, 0, 4, c.stream));
+        for (size_t i0 = 0; i0 < sh.n_pad; i0 += chunk) {
+          const size_t count = sh.n_pad - i0 < chunk ? sh.n_pad - i0 : chunk;
+          kl::prepare_keys<C>(c.stream, sh.d_mont, cnt, sh.n_pad, i0, count, (uint32_t*)sh.d_prep, (uint8_t*)sh.d_kinf, (uint32_t*)tmp, (uint32_t*)d_flags);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, c.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(BGLS_ERR_HIP, "preparing the key set", e);
+        if (f & FLAG_DEGENERATE) return fail(BGLS_ERR_ENCODING, "key set: a key has a degenerate Miller step and cannot be prepared (upload it without BGLS_KEYS_PREPARE)");
+      }
       return 0;
     }();
   }
@@ -1452,8 +1520,12 @@ int verify_aggregate_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* blob, co
     if (s == 0 && !allow_dups && (r = E::dup_scan(c, st, all, n, (uint32_t*)d_flags))) return r;
     MsgView mine = all;
     if (s == 0) mine.off = (const uint64_t*)d_off + sh.lo;      // sh.lo == 0; kept for clarity
-    if ((r = E::miller_product(c, st, s == 0 ? (const uint8_t*)d_sig : nullptr, (const uint8_t*)sh.d_wire, mine, cnt, 0,
-                               (uint8_t*)sh.d_rec, (uint32_t*)d_flags)))
+    if (ks.prepared) {
+      if ((r = E::miller_product_prepared(c, st, s == 0 ? (const uint8_t*)d_sig : nullptr, (const uint32_t*)sh.d_prep, (const uint8_t*)sh.d_kinf, sh.n_pad,
+                                          mine, cnt, (uint8_t*)sh.d_rec, (uint32_t*)d_flags)))
+        return r;
+    } else if ((r = E::miller_product(c, st, s == 0 ? (const uint8_t*)d_sig : nullptr, (const uint8_t*)sh.d_wire, mine, cnt, 0,
+                                      (uint8_t*)sh.d_rec, (uint32_t*)d_flags)))
       return r;
     HIPCHK(hipMemcpyAsync((uint8_t*)sh.d_rec + E::GTB, d_flags, 4, hipMemcpyDeviceToDevice, st));
     if (s) HIPCHK(hipStreamSynchronize(st));       // record complete before the exchange reads it (shard 0: stream order)

@@ -47,6 +47,15 @@ template <class C>
 void miller_lines(hipStream_t st, int variant, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, size_t n_pad, uint32_t* table, uint32_t* flags);
 template <class C> void miller_fold(hipStream_t st, int variant, const uint32_t* table, size_t n_pad, int ng, Fp2<C>* out);
 
+// prepared key sets (prepared.hpp): bytes per key of the line table, per pairing of the point table, per key of k_prepare's scratch
+struct PrepSizes { size_t line_bytes_per_key, point_bytes, tmp_bytes_per_key; };
+template <class C> PrepSizes prep_sizes();
+template <class C>
+void prepare_keys(hipStream_t st, const void* keys_mont, size_t n, size_t n_pad, size_t i0, size_t count, uint32_t* table, uint8_t* kinf,
+                  uint32_t* tmp, uint32_t* flags);
+template <class C> void prep_points(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* kinf, size_t n, size_t n_pad, uint32_t* ptab);
+template <class C> void fold_prep(hipStream_t st, const uint32_t* table, const uint32_t* ptab, size_t n_pad, int ng, Fp2<C>* out);
+
 // ---- k_tail_bn.hip / k_tail_bls.hip
 template <class C> void gen_lines(hipStream_t st, LineCoeffs<C>* table, int* nsteps);
 template <class C> void reduce_coop(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out);

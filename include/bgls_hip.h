@@ -235,9 +235,14 @@ int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_key
  * altbn128Point2 / bls12Point2 slices become (curves/altbn128.go:19-29, curves/bls12_381.go:18-28): the shim uploads a
  * []Point once, keeps the handle (runtime.SetFinalizer -> bgls_keys_free) and passes it to every Verify*.
  * flags: BGLS_KEYS_CHECK also requires every key to lie in the order-r subgroup (the reference's construction-time
- * check); any invalid key fails the upload with BGLS_ERR_ENCODING. */
+ * check); any invalid key fails the upload with BGLS_ERR_ENCODING.
+ * BGLS_KEYS_PREPARE additionally walks the G2 point steps of the Miller loop once per key and keeps every step's line
+ * function in HBM (13-17 KB per key: a 2^20-key set is 14-18 GB of the 288), so that verifications against the set only
+ * scale and fold those lines (prepared.hpp): the fixed-argument precomputation pairing libraries offer as "prepared G2".
+ * Verdicts and the final GT element are identical to the unprepared path. */
 typedef uint64_t bgls_keys_t;
 #define BGLS_KEYS_CHECK 1u
+#define BGLS_KEYS_PREPARE 2u
 int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out);
 int bgls_keys_free(bgls_keys_t handle);
 int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices);

@@ -192,3 +192,45 @@ def test_key_set_multisig_any_sharding(gpu_lib, curve):
 def test_rccl_is_loadable(gpu_lib):
     """The exchange uses RCCL when the devices of a key set are distinct; on a one-GPU box only its loading can be checked."""
     assert gpu_lib.bgls_rccl_available() == 1
+
+
+def test_prepared_key_set_gives_the_same_gt(gpu_lib, curve):
+    """BGLS_KEYS_PREPARE: the Miller stage runs on the resident, normalised line functions of the keys (prepared.hpp).  Same
+    verdicts and -- after the final exponentiation -- the same GT bytes as the unprepared set and the oracle, on one and on
+    several shards; keys at infinity and ragged sizes (padding up to whole fold groups) included."""
+    lib, cid, fp = gpu_lib, curve["id"], curve["fp"]
+    for n, seed in ((5, 1), (333, 2), (1000, 3)):
+        sks, keys, msgs, sigs, agg = make_instance(lib, cid, fp, n, 8800 + 10 * cid + seed)
+        blob, off = b"".join(msgs), offsets(msgs)
+        wrong_sig = sigs[:2 * fp]
+        bad = list(msgs); bad[n // 2] = bytes([bad[n // 2][0] ^ 1]) + bad[n // 2][1:]
+        ref_gt = None
+        for flags, shards in ((1, 1), (3, 1), (3, 3)):
+            h = ctypes.c_uint64()
+            assert lib.bgls_keys_upload(cid, B(keys), n, devs(shards), shards, flags, ctypes.byref(h)) == 0, _err(lib)
+            assert lib.bgls_verify_aggregate_h(h, B(agg), B(blob), off, n, 0) == 1, (n, flags, shards)
+            assert lib.bgls_verify_aggregate_h(h, B(agg), B(b"".join(bad)), offsets(bad), n, 0) == 0
+            gt = out(12 * fp)
+            assert lib.bgls_verify_aggregate_h_gt(h, B(wrong_sig), B(blob), off, n, 0, gt) == 0
+            if ref_gt is None:
+                ref_gt = bytes(gt)
+            assert bytes(gt) == ref_gt, (n, flags, shards)
+            assert lib.bgls_keys_free(h) == 0
+    # a key at infinity contributes e(H, inf) = 1 on both paths
+    n = 40
+    sks, keys, msgs, sigs, agg = make_instance(lib, cid, fp, n, 8899 + cid)
+    kk = bytearray(keys); kk[4 * fp * 7:4 * fp * 8] = bytes(4 * fp)
+    agg2 = out(2 * fp)
+    assert lib.bgls_aggregate_points(cid, 1, B(sigs[:2 * fp * 7] + sigs[2 * fp * 8:]), n - 1, agg2) == 0
+    blob, off = b"".join(msgs), offsets(msgs)
+    for flags in (0, 2):
+        h = ctypes.c_uint64()
+        assert lib.bgls_keys_upload(cid, B(bytes(kk)), n, devs(1), 1, flags, ctypes.byref(h)) == 0
+        assert lib.bgls_verify_aggregate_h(h, agg2, B(blob), off, n, 0) == 1, flags
+        assert lib.bgls_verify_aggregate_h(h, B(agg), B(blob), off, n, 0) == 0
+        assert lib.bgls_keys_free(h) == 0
+
+
+def _err(lib):
+    from bgls_amd import _lib
+    return _lib.last_error()
