@@ -16,7 +16,12 @@ signers (config 4) and the reference's own CPU-runnable shape, alt-bn128 n = 64 
 schema: value, ms_per_step (median / min over the repetitions), roofline {frac, kernel, launch_ms, traffic}, and
 cpu_baseline where one was taken.
 
-`python bench.py --only aggregate --curve bls12 --n 65536 --in-flight 1` etc. run a single record (profiling runs).
+Two further records, "<curve>_<n>_prepared_keys", time the same batches against PREPARED key sets (bgls_keys_upload with
+BGLS_KEYS_PREPARE: the keys' Miller line functions are computed once at upload and stay in HBM); they are secondary,
+labelled figures -- the headline and the BASELINE records always include the G2 point steps in the timed region.
+
+`python bench.py --only aggregate --curve bls12 --n 65536 --in-flight 1` etc. run a single record (profiling runs;
+`--prepared` for the prepared-key-set path).
 """
 import argparse
 import ctypes
@@ -195,7 +200,10 @@ class Lanes:
             check(lib.bgls_select_context(0), "select_context")
 
 
-def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, in_flight, throughput, label, with_h2d=True):
+PREPARED_FPMUL = {0: 88 * 40 + 64 * 72 // 24, 1: 69 * 40 + 64 * 72 // 24}    # per pair: lines x (2 Fp2 products on 6 lanes + 4 scalings) + squarings / 24
+
+
+def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, in_flight, throughput, label, with_h2d=True, prepared=False):
     """VerifyAggregateSignature over an n_total-signer batch of which this rank holds inst['n_local'] signers (the first
     n_local of `inst`).  Returns the record dict on rank 0 (None elsewhere)."""
     cid, fp = inst["cid"], inst["fp"]
@@ -211,6 +219,14 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     t_sig = torch.frombuffer(bytearray(bytes(agg)), dtype=torch.uint8).to(dev)
     L = max(1, min(16, in_flight))
     lanes = Lanes(lib, dev, cid, L, gtb)
+    handle = None
+    if prepared:                          # keys uploaded once: parsed, validated, line functions of every Miller step resident (BGLS_KEYS_PREPARE)
+        assert world == 1
+        hh = ctypes.c_uint64()
+        t0 = time.perf_counter()
+        check(lib.bgls_keys_upload(cid, B(inst["keys"][:n * 4 * fp]), n, None, 1, 2, ctypes.byref(hh)), "keys_upload(prepare)")
+        upload_s = time.perf_counter() - t0
+        handle = hh.value
     h_msgs = torch.frombuffer(bytearray(inst["msgs"][:n * 64]), dtype=torch.uint8).pin_memory() if with_h2d else None
     torch.cuda.synchronize()
 
@@ -225,8 +241,12 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
             if world > 1:                 # duplicates may straddle shards: exact scan over every rank's messages
                 global_duplicate_scan(lambda buf, count: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, ln["flags"].data_ptr(), h),
                                                                "duplicate_scan_dev"), msgs_t, n, world)
-            check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
-                                              64, 64, n, 1 if world == 1 else 0, ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
+            if handle is not None:
+                check(lib.bgls_miller_product_keys_dev(handle, t_sig.data_ptr(), msgs_t.data_ptr(), 64, 64, n, 1, ln["part"].data_ptr(), ln["flags"].data_ptr(), h),
+                      "miller_product_keys_dev")
+            else:
+                check(lib.bgls_miller_product_dev(cid, t_sig.data_ptr() if rank == 0 else None, t_keys.data_ptr(), msgs_t.data_ptr(),
+                                                  64, 64, n, 1 if world == 1 else 0, ln["part"].data_ptr(), ln["flags"].data_ptr(), h), "miller_product_dev")
             if world == 1:
                 check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
             else:
@@ -268,7 +288,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         seq.append((time.perf_counter() - t0) * 1e3)
     sync()
     stages_excl = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
-    use_tp = pipelined and cid == 0 and throughput
+    use_tp = pipelined and cid == 0 and throughput and not prepared
     if use_tp:
         # launches overlap from here on: alt-bn128 Miller launches may take the shape that is fastest in that regime
         # (bgls_set_throughput_mode: 60 pairings per block, see k_miller_s60); verdicts are identical in both modes
@@ -298,6 +318,8 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         h2d_elapsed = time.perf_counter() - t0
     check(lib.bgls_set_throughput_mode(0), "set_throughput_mode")
     lib.bgls_profile_enable(0)
+    if handle is not None:
+        check(lib.bgls_keys_free(handle), "keys_free")
     if rank != 0:
         return None
 
@@ -305,9 +327,9 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     per_step = sorted(r / steps for r in regions)
     med = statistics.median(per_step)
     value = n_total / med
-    launches_per_step = (n + LAUNCH_PAIRS - 1) // LAUNCH_PAIRS
-    pairs_per_launch = min(n, LAUNCH_PAIRS)
-    macs_per_launch = (pairs_per_launch + 1) * MILLER_FPMUL[cid] * MAC_PER_FPMUL[cid]
+    launches_per_step = 1 if prepared else (n + LAUNCH_PAIRS - 1) // LAUNCH_PAIRS
+    pairs_per_launch = n if prepared else min(n, LAUNCH_PAIRS)
+    macs_per_launch = (pairs_per_launch + 1) * (PREPARED_FPMUL if prepared else MILLER_FPMUL)[cid] * MAC_PER_FPMUL[cid]
     ex_ms, ex_cnt = stages_excl["miller"]
     excl_launch_s = ex_ms / max(ex_cnt, 1) / launches_per_step * 1e-3         # HIP events around the Miller stage, one verification in flight
     # With several verifications in flight the launches of the dominant kernel share the machine with each other and with
@@ -318,6 +340,8 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     forced_tp = cid == 0 and os.environ.get("BGLS_THROUGHPUT") == "1"      # profiling runs: the 60-pairing shape from the first call on
     kernel_excl = "k_miller_s60<BN254>" if forced_tp else "k_miller_ab64<%s>" % cname
     kernel_timed = "k_miller_s60<BN254>" if (use_tp or forced_tp) else kernel_excl
+    if prepared:
+        kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])
     rec = {
         "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",
@@ -345,6 +369,13 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         "stage_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items()},
         "stage_ms_exclusive": {k: (v[0] / max(v[1], 1)) for k, v in stages_excl.items()},
     }
+    if prepared:
+        rec["config"]["workload"] = ("%s VerifyAggregateSignature against a PREPARED resident key set (bgls_keys_upload with BGLS_KEYS_PREPARE: the line "
+                                     "functions of every key and Miller step computed at upload, %.0f ms, untimed), one %d-signer batch, distinct 64-byte "
+                                     "messages resident in HBM" % (CNAME[cid], upload_s * 1e3, n_total))
+        rec["roofline"]["note"] = ("prepared path: no point steps inside the timed region; achieved = (pairs + 1) x %d Fp multiplications (per pair: 88 / 69 lines x "
+                                   "(2 Fp2 products on 6 lanes + 4 scalings) + the shared squarings) x %d MAC / launch_ms" % (PREPARED_FPMUL[cid], MAC_PER_FPMUL[cid]))
+        rec["prepared_upload_ms"] = upload_s * 1e3
     if h2d_elapsed is not None:
         rec["with_message_h2d"] = {"value": n_total * steps / h2d_elapsed, "ms_per_step": h2d_elapsed / steps * 1e3,
                                    "note": "the same steps with the %d MiB of messages copied from pinned host memory inside every step "
@@ -467,6 +498,7 @@ def main():
     ap.add_argument("--no-throughput-mode", action="store_true", help="keep the 64-pairing Miller kernel also when launches overlap")
     ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "small"], help="run ONE record (profiling runs): --curve, --n apply")
     ap.add_argument("--no-records", action="store_true", help="headline only")
+    ap.add_argument("--prepared", action="store_true", help="with --only aggregate: verify against a prepared key set")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -504,7 +536,8 @@ def main():
 
     cid = CURVE[args.curve]
     inst = shard_instance(cid, args.n, 0xB6150000 + 1 + cid)
-    head = bench_aggregate(lib, dev, inst, args.n, rank, world, args.steps, args.warmup, args.reps, args.in_flight, tp, "headline")
+    head = bench_aggregate(lib, dev, inst, args.n, rank, world, args.steps, args.warmup, args.reps, args.in_flight, tp, "headline",
+                           prepared=args.prepared and args.only == "aggregate")
     records = {}
     if args.only is None and not args.no_records:
         other = 1 - cid
@@ -518,6 +551,9 @@ def main():
                 i_["n_local"] = small_n
                 records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 20, 3, args.reps, args.in_flight, tp, CNAME[c_] + " 2^16")
                 i_["n_local"] = i_["n"]
+            for c_, i_ in ((cid, inst), (other, oinst)):      # the same batches against prepared key sets (secondary records, labelled)
+                records["%s_%d_prepared_keys" % (CNAME[c_], args.n)] = bench_aggregate(lib, dev, i_, args.n, 0, 1, max(2, args.steps // 2), 1, args.reps, args.in_flight,
+                                                                                        tp, CNAME[c_] + " prepared", with_h2d=False, prepared=True)
             bn = inst if cid == 0 else oinst
             records["altbn128_multisig_%d" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16)
             records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)

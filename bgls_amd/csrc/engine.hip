@@ -1756,6 +1756,43 @@ int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uin
 
 int bgls_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
+// device-resident messages against a one-device key set, on the calling thread's context (several verifications in flight
+// on several contexts: the handle's resident arrays are read-only)
+int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
+                                 int check_duplicates, void* d_partial_out, void* d_flags, void* stream) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (ks->shards.size() != 1) return fail(BGLS_ERR_ARG, "device entry point: the key set must live on one device");
+  if (n != ks->n) return fail(BGLS_ERR_ARG, "message count differs from the key set's size");
+  if (!d_partial_out || !d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
+  const int pd = g_dev;
+  g_dev = ks->shards[0].device;
+  Ctx& c = ctx();
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = [&]() -> int {
+      int r;
+      if ((r = c.enter())) return r;
+      hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+      const KeyShard& sh = ks->shards[0];
+      MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+      if (ks->curve == BGLS_CURVE_ALTBN128) {
+        typedef Engine<BN254> E;
+        if (check_duplicates && (r = E::dup_scan(c, st, mv, n, (uint32_t*)d_flags))) return r;
+        if (ks->prepared) return E::miller_product_prepared(c, st, (const uint8_t*)d_sig, (const uint32_t*)sh.d_prep, (const uint8_t*)sh.d_kinf, sh.n_pad, mv, n, (uint8_t*)d_partial_out, (uint32_t*)d_flags);
+        return E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)sh.d_wire, mv, n, 0, (uint8_t*)d_partial_out, (uint32_t*)d_flags);
+      }
+      typedef Engine<BLS381> E;
+      if (check_duplicates && (r = E::dup_scan(c, st, mv, n, (uint32_t*)d_flags))) return r;
+      if (ks->prepared) return E::miller_product_prepared(c, st, (const uint8_t*)d_sig, (const uint32_t*)sh.d_prep, (const uint8_t*)sh.d_kinf, sh.n_pad, mv, n, (uint8_t*)d_partial_out, (uint32_t*)d_flags);
+      return E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)sh.d_wire, mv, n, 0, (uint8_t*)d_partial_out, (uint32_t*)d_flags);
+    }();
+  }
+  g_dev = pd;
+  return rc;
+}
+
 int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len) {
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");

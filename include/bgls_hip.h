@@ -257,6 +257,10 @@ int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_
  * bgls/bgls.go:113-114; the identity iff the verdict is 1): canonical bytes, identical for any number of devices. */
 int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
                                int allow_duplicates, uint8_t* gt_out);
+/* bgls_miller_product_dev against a ONE-device key set (prepared or not) with device-resident fixed-stride messages, on
+ * the calling thread's context and the given stream; finish with bgls_final_verify_(submit_)dev. */
+int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
+                                 int check_duplicates, void* d_partial_out, void* d_flags, void* stream);
 /* verifyMultiSignature (bgls/bgls.go:89-92) against a resident key set: per-device partial key sums (projective G2
  * points) are gathered on the first device, added, and the two-pairing check runs there. */
 int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len);
