@@ -22,11 +22,14 @@ BGLS_THROUGHPUT=1 prof bn_s60_61440 $SEQ --n 61440
 prof bls_ab64_65536 $SEQ --n 65536 --curve bls12
 prof multisig_1048576 --only multisig --n 1048576 --in-flight 1 --reps 1 --steps 5 --warmup 2
 prof default_overlapped --no-cpu-baseline --no-records --reps 1 --steps 5 --warmup 2
+prof bn_prepared_1048576 $SEQ --n 1048576 --prepared --steps 3 --warmup 1
+prof bls_prepared_1048576 $SEQ --n 1048576 --prepared --curve bls12 --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc bn_ab64 $c $SEQ --n 65536 --steps 2 --warmup 1
   BGLS_THROUGHPUT=1 pmc bn_s60 $c $SEQ --n 61440 --steps 2 --warmup 1
   pmc bls_ab64 $c $SEQ --n 65536 --curve bls12 --steps 2 --warmup 1
   pmc multisig $c --only multisig --n 1048576 --in-flight 1 --reps 1 --steps 2 --warmup 1
+  pmc bn_prepared $c $SEQ --n 1048576 --prepared --steps 2 --warmup 1
 done
 pmc bn_s60 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" $SEQ --n 61440 --steps 2 --warmup 1 2>/dev/null
 find $O -name "*.csv" | wc -l; du -sh $O

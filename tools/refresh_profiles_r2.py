@@ -46,7 +46,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (prof
 for key, name, kern, algo in (("k_miller_ab64_altbn128", "bn_ab64", "k_miller_ab64<bgls::BN254", 65536 * 192 + 64),
                               ("k_miller_s60_altbn128", "bn_s60", "k_miller_s60", 61440 * 192),
                               ("k_miller_ab64_bls12", "bls_ab64", "k_miller_ab64<bgls::BLS381", 65536 * 256),
-                              ("k_sum_main_altbn128", "multisig", "k_sum_main", 1048576 * 128)):
+                              ("k_sum_main_altbn128", "multisig", "k_sum_main", 1048576 * 128),
+                              ("k_fold_prep_altbn128", "bn_prepared", "k_fold_prep", 1048576 * (88 * 192 + 128))):
     t = traffic(name, kern, algo)
     if t:
         out[key] = t
