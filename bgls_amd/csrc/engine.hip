@@ -1652,32 +1652,38 @@ size_t bgls_gt_size(int curve) { return 12 * bgls_fp_size(curve); }
 
 int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
                           size_t n, int allow_duplicates) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_aggregate_t<CV>(sig, keys, msg_blob, msg_off, n, allow_duplicates));
 }
 
 int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
 }
 
 int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!gt_out || (n && (!g1s || !g2s))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, pairing_product_t<CV>(g1s, g2s, n, gt_out));
 }
 
 int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n && (!msg_off || !g1_out)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, hash_to_g1_t<CV>(msg_blob, msg_off, n, g1_out));
 }
 
 int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || !out || (n && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, aggregate_points_t<CV>(group, pts, n, out));
 }
 
 int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
                       uint8_t* out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, scale_points_t<CV>(group, pts, scalars, signs, n, out));
 }
@@ -1698,6 +1704,7 @@ int bgls_point_check(int curve, int group, const uint8_t* a) {
 }
 
 int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !ok_out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, check_points_t<CV>(group, pts, n, ok_out));
 }
@@ -1709,6 +1716,7 @@ int bgls_select_device(int device) {
 }
 
 int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!handle_out || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n_devices < 1 || n_devices > NCTX) return fail(BGLS_ERR_ARG, "n_devices out of range (1..16)");
   int dflt = cur_device();
@@ -1740,6 +1748,7 @@ int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices) {
 
 int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
                             int allow_duplicates) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (!sig || !msg_off) return fail(BGLS_ERR_ARG, "NULL argument");
@@ -1748,6 +1757,7 @@ int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_
 
 int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
                                int allow_duplicates, uint8_t* gt_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (!sig || !msg_off || !gt_out) return fail(BGLS_ERR_ARG, "NULL argument");
@@ -1760,6 +1770,7 @@ int bgls_rccl_available(void) { return rccl().ok ? 1 : 0; }
 // on several contexts: the handle's resident arrays are read-only)
 int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
                                  int check_duplicates, void* d_partial_out, void* d_flags, void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (ks->shards.size() != 1) return fail(BGLS_ERR_ARG, "device entry point: the key set must live on one device");
@@ -1802,6 +1813,7 @@ int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* m
 
 int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
                                 size_t n, int allow_duplicates, const int* devices, int n_devices) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
   int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
   if (rc) return rc;
@@ -1814,6 +1826,7 @@ int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* ke
 
 int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len,
                             const int* devices, int n_devices) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
   int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
   if (rc) return rc;
@@ -1915,6 +1928,7 @@ int bgls_probe_mad_peak(double* mac_per_s) {
 int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len,
                             size_t msg_stride, size_t n, int check_duplicates, void* d_partial_out, void* d_flags,
                             void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
                                            d_flags, stream));
@@ -1950,6 +1964,7 @@ int bgls_final_verify_collect(int curve) {
 }
 
 int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n >= (1ull << 30)) return fail(BGLS_ERR_ARG, "too many messages for one scan");
   return duplicate_scan_dev(d_msgs, msg_len, msg_stride, n, d_flags, stream);
@@ -1961,46 +1976,54 @@ int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const
 }
 
 int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || !d_out || (n && !d_pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, aggregate_points_dev_t<CV>(group, d_pts, n, d_out, stream));
 }
 
 int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
                           void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
 }
 
 int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
                                  void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream, true));
 }
 
 /* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */
 int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n && (!keys || !t_out)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, hae_exponents_t<CV>(keys, n, t_out));
 }
 
 int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!out || (n && (!sigs || !keys))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, aggregate_signatures_hae_t<CV>(sigs, keys, n, out));
 }
 
 int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, nullptr, n, msg, msg_len));
 }
 
 int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
                               size_t n) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_aggregate_hae_t<CV>(sig, keys, msg_blob, msg_off, n));
 }
 
 int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity, size_t n,
                                    const uint8_t* msg, size_t msg_len) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (!multiplicity) DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
   DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, multiplicity, n, msg, msg_len));
@@ -2008,22 +2031,26 @@ int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t*
 
 /* ---- compressed wire formats (alt-bn128; curves/altbn128.go:81-89,203-221,296-376) ---- */
 int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   return wire_points(curve, group, true, pts, n, out, nullptr);
 }
 
 int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!in || !out || !ok))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   return wire_points(curve, group, false, in, n, out, ok);
 }
 
 /* ---- batch key generation / signing (bgls/bgls.go:40-56) ---- */
 int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, scale_generator_t<CV>(group, scalars, n, out));
 }
 
 int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* sigs_out) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!msg_off || (n && (!sks || !sigs_out))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, sign_batch_t<CV>(sks, msg_blob, msg_off, n, sigs_out));
 }

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
     u32* const myqp = qp + (size_t)blockIdx.x * QP<C>::DW * 64 + lane;
     QP<C>::park(myqp, Q, P);
     int buf = 0, step = 0;
-    auto publish = [&](LineCapture<C>& cap) {
+    auto publish = [&](LineCapture<C>& cap) __attribute__((always_inline)) {
       if constexpr (DBG == 2) { ++step; __syncthreads(); buf ^= 1; return; }
       if (!valid) { cap.e[0] = f2_one<C>(); cap.e[1] = f2_zero<C>(); cap.e[2] = f2_zero<C>(); }
       const LReg r = {tgb + (buf ? K::RL2 : K::RL), K::NENT};
