@@ -56,6 +56,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // Largest batch one call accepts: the duplicate table (2n rounded up to a power of two, u32 slots), the hashing work
 // lists (u32 indices) and the grid computations all assume n < 2^30.
 constexpr size_t MAX_BATCH = (size_t)1 << 30;
+// batches up to this many pairings take the latency form of the Miller loop (one block per pairing, k_miller_lat)
+constexpr size_t LAT_MAX = 128;
 
 // workspace slots
 enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_NUM };
@@ -224,7 +226,7 @@ struct Engine {
   static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
                             int check_dups, uint8_t* d_partial, uint32_t* d_flags) {
     if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
-    const bool raw = C::CURVE_ID == 1 && n > 0;     // BLS12-381: uncleared hash points, cofactor applied once in GT
+    const bool raw = C::CURVE_ID == 1 && n > LAT_MAX;     // BLS12-381 batches: uncleared hash points, cofactor applied once in GT
     void* g1s;
     int rc;
     if ((rc = c.get(WS_G1S, (n + 2) * sizeof(Aff<G1F>), &g1s))) return rc;
@@ -360,6 +362,19 @@ struct Engine {
     void *pa, *pb;
     Fp2<C>* red = nullptr;
     bool epilogue = cofactor;
+    if (npairs <= LAT_MAX && !cofactor && g_shape.load() == 0) {
+      // a handful of pairings: one block per pairing (k_miller_lat), the signature pair as one more block
+      const size_t blocks = npairs + (sig ? 1 : 0);
+      if ((rc = c.get(WS_F_A, (blocks + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+      if ((rc = c.get(WS_F_B, (blocks / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      {
+        Scope sc(c, st, ST_MILLER);
+        kl::miller_lat<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
+        HIPCHK(hipGetLastError());
+      }
+      if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;
+      return emit_partial(c, st, red, false, nullptr, gl, d_partial);
+    }
     if (g_shape.load() > 0 && npairs >= 1) {
       // decoupled: line table in HBM, then folds; batches above 2^16 pairings go chunk by chunk through one table
       int variant = g_shape.load() - 1;
