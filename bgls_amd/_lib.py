@@ -64,6 +64,8 @@ SIGNATURES = {
     "bgls_select_context": (ci, [ci]),
     "bgls_set_throughput_mode": (ci, [ci]),
     "bgls_set_miller_shape": (ci, [ci, ci]),
+    "bgls_weighted_sum_dev": (ci, [ci, ci, vp, vp, sz, vp, vp]),
+    "bgls_set_msm_min": (ci, [sz]),
     "bgls_final_verify_dev": (ci, [ci, vp, sz, vp, vp]),
     "bgls_aggregate_points_dev": (ci, [ci, ci, vp, sz, vp, vp]),
     "bgls_verify_multi_dev": (ci, [ci, vp, vp, sz, vp, sz, vp]),

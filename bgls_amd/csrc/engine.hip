@@ -60,7 +60,7 @@ constexpr size_t MAX_BATCH = (size_t)1 << 30;
 constexpr size_t LAT_MAX = 128;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -147,12 +147,14 @@ int cur_device() { return g_dev >= 0 ? g_dev : g_default_device.load(); }
 Ctx& ctx_of(int device, int index) { return ctx_pool()[(size_t)device * NCTX + index]; }
 Ctx& ctx() { return ctx_of(cur_device(), g_sel); }
 
-// Per-device tables built once: the fixed-argument line coefficients of the generator g2 (k_gen_lines), one per curve.
+// Per-device tables built once: the fixed-argument line coefficients of the generator g2 (k_gen_lines), one per curve,
+// and the window multiples d 2^(8j) g of both generators for batch key generation (k_fb_build).
 // Built under the device's lock on a private stream and published only after the build has completed, so every stream
 // of every context of that device may read them without further ordering.
 struct DeviceTables {
   std::mutex mu;
   void* gen_lines[2] = {nullptr, nullptr};
+  void* fixed_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [curve][group - 1]: window multiples of the generator (k_fb_build)
 };
 DeviceTables& tables_of(int device) {
   static DeviceTables t[MAX_DEVICES];
@@ -223,8 +225,9 @@ struct Engine {
 
   // d_flags: device u32 (already zeroed by caller).  Writes the product of the n (+1) Miller values to d_partial (GT
   // bytes, no final exponentiation).
+  // d_w16 != nullptr: pair i is (w_i H(m_i), pk_i) with 16-byte big-endian weights (hashed aggregation exponents).
   static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
-                            int check_dups, uint8_t* d_partial, uint32_t* d_flags) {
+                            int check_dups, uint8_t* d_partial, uint32_t* d_flags, const uint8_t* d_w16 = nullptr) {
     if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
     const bool raw = C::CURVE_ID == 1 && n > LAT_MAX;     // BLS12-381 batches: uncleared hash points, cofactor applied once in GT
     void* g1s;
@@ -234,6 +237,7 @@ struct Engine {
     if (n) {
       Scope sc(c, st, ST_H2C);
       if ((rc = hash_to_g1(c, st, mv, n, (Aff<G1F>*)g1s, d_flags, raw))) return rc;
+      if (d_w16) kl::scale_g1_inplace<C>(st, (Aff<G1F>*)g1s, d_w16, n);
     }
     if (d_sig) kl::g1_parse<C>(st, d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
     return miller(c, st, (const Aff<G1F>*)g1s, d_keys, n, d_sig ? (const Aff<G1F>*)g1s + n : nullptr, d_partial, d_flags, raw);
@@ -1034,18 +1038,16 @@ int hae_exponents_t(const uint8_t* keys, size_t n, uint8_t* t_out) {
   return 0;
 }
 
-// d_out (affine bytes) <- sum_i w_i P_i over device-resident points and 16-byte weights
+// Weighted sums below this many points keep one double-and-add per point (bgls_set_msm_min; tests pin both paths)
+std::atomic<size_t> g_msm_min{32};
+
+// d_out (affine bytes) <- sum_i w_i P_i over device-resident points and 16-byte weights, one scalar multiplication per
+// point (k_wsum_first) followed by the addition tree
 template <class C>
-int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint8_t* d_w16, const uint8_t* d_signs, size_t n,
-                     uint8_t* d_out, uint32_t* d_flags) {
-  const size_t PTB = group == BGLS_G1 ? Engine<C>::G1B : Engine<C>::G2B;
-  if (n == 0) {
-    HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
-    return 0;
-  }
+int weighted_sum_naive(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint8_t* d_w16, const uint8_t* d_signs, size_t n,
+                       uint8_t* d_out, uint32_t* d_flags) {
   void *ja, *jb;
   int rc;
-  Scope sc(c, st, ST_SUM);
   const size_t JB = kl::jac_bytes<C>(group);
   if ((rc = c.get(WS_JAC_A, (n + 1) * JB, &ja))) return rc;
   if ((rc = c.get(WS_JAC_B, (n / 2 + 2) * JB, &jb))) return rc;
@@ -1063,6 +1065,58 @@ int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, co
     cnt = nout;
   }
   kl::jac_to_bytes<C>(st, group, a, 1, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The same sum by the bucket method (k_msm.hip): n W mixed additions instead of n (128 doublings + 64 additions).
+// Bucket populations are only balanced for weights that look random (hashed exponents do); when the largest bucket is
+// far above the mean -- small multiplicities, repeated weights -- the per-point form is the faster one and is used.
+template <class C>
+int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint8_t* d_w16, const uint8_t* d_signs, size_t n,
+                     uint8_t* d_out, uint32_t* d_flags) {
+  const size_t PTB = group == BGLS_G1 ? Engine<C>::G1B : Engine<C>::G2B;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
+    return 0;
+  }
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  Scope sc(c, st, ST_SUM);
+  const kl::MsmPlan p = kl::msm_plan(n);
+  if (n < g_msm_min.load() || (uint64_t)n * (uint64_t)p.W >= (1ull << 32))            // list positions are 32-bit
+    return weighted_sum_naive<C>(c, st, group, d_pts, d_w16, d_signs, n, d_out, d_flags);
+  const size_t JB = kl::jac_bytes<C>(group);
+  void *aff, *cnt, *start, *list, *buckets, *tail;
+  int rc;
+  if ((rc = c.get(WS_MSM_AFF, n * kl::msm_aff_bytes<C>(group), &aff))) return rc;
+  if ((rc = c.get(WS_MSM_CNT, ((size_t)p.NB + 2) * 4, &cnt))) return rc;
+  if ((rc = c.get(WS_MSM_START, ((size_t)p.NB + 1) * 4, &start))) return rc;
+  if ((rc = c.get(WS_MSM_LIST, n * (size_t)p.W * 4, &list))) return rc;
+  if ((rc = c.get(WS_JAC_A, (size_t)p.NB * p.S * JB, &buckets))) return rc;
+  const size_t half = p.S > 1 ? (size_t)p.NB * p.S / 2 : 0;                  // second buffer of the partials' pairwise folds
+  if ((rc = c.get(WS_JAC_B, (half + (size_t)p.NCH + p.W + 1) * JB, &tail))) return rc;
+  uint32_t* d_meta = (uint32_t*)cnt + p.NB;
+  HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)p.NB + 2) * 4, st));
+  kl::msm_parse<C>(st, group, d_pts, d_w16, d_signs, n, p, aff, (uint32_t*)cnt, d_flags);
+  kl::msm_scan(st, (uint32_t*)cnt, p.NB, (uint32_t*)start, d_meta);
+  HIPCHK(hipGetLastError());
+  uint32_t meta[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(meta, d_meta, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const size_t mean = n >> p.c;
+  if (meta[0] > (mean * 8 > 64 ? mean * 8 : 64)) return weighted_sum_naive<C>(c, st, group, d_pts, d_w16, d_signs, n, d_out, d_flags);
+  uint8_t* chunks = (uint8_t*)tail + half * JB;
+  uint8_t* wins = chunks + (size_t)p.NCH * JB;
+  uint8_t* res = wins + (size_t)p.W * JB;
+  kl::msm_scatter<C>(st, group, aff, d_w16, n, p, (uint32_t*)cnt, (uint32_t*)list);
+  kl::msm_buckets<C>(st, group, aff, (const uint32_t*)list, (const uint32_t*)start, p, buckets);
+  void *a = buckets, *b = tail;
+  for (size_t cntp = (size_t)p.NB * p.S; cntp > p.NB; cntp /= 2) {            // S partials per bucket -> one, halving
+    kl::sum_pair<C>(st, group, a, cntp, b);
+    std::swap(a, b);
+  }
+  kl::msm_tail<C>(st, group, a, p, chunks, wins, res);
+  kl::jac_to_bytes<C>(st, group, res, 1, d_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1115,6 +1169,26 @@ int verify_multi_weighted_t(const uint8_t* sig, const uint8_t* keys, const int64
   return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_apk, 1, (const uint8_t*)d_msg, msg_len);
 }
 
+// getAggregatePubKey over device-resident points and weights (blsHAE.go:74-77): d_out <- sum_i w_i P_i as affine bytes
+template <class C>
+int weighted_sum_dev_t(int group, const void* d_pts, const void* d_w16, size_t n, void* d_out, void* stream) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  void* d_flags;
+  if ((rc = c.get(WS_FLAGS2, 16, &d_flags))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if ((rc = weighted_sum_dev<C>(c, st, group, (const uint8_t*)d_pts, (const uint8_t*)d_w16, nullptr, n, (uint8_t*)d_out, (uint32_t*)d_flags)))
+    return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c.collect();
+  return flags_to_rc(f);
+}
+
 // VerifyAggregateSignatureWithHAE (blsHAE.go:49-53): keys scaled by their exponents, then verifyAggSig with duplicates allowed
 template <class C>
 int verify_aggregate_hae_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* blob, const uint64_t* off, size_t n) {
@@ -1127,26 +1201,23 @@ int verify_aggregate_hae_t(const uint8_t* sig, const uint8_t* keys, const uint8_
   for (size_t i = 0; i < n; ++i)
     if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
   const size_t blob_len = n ? off[n] : 0;
-  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part, *d_scaled, *d_t;
+  void *d_sig, *d_keys, *d_blob, *d_off, *d_flags, *d_part, *d_t;
   if ((rc = c.get(WS_IN_A, E::G1B, &d_sig))) return rc;
   if ((rc = c.get(WS_IN_B, n * E::G2B, &d_keys))) return rc;
   if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
   if ((rc = c.get(WS_IN_D, (n + 1) * 8, &d_off))) return rc;
   if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
   if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
-  if ((rc = c.get(WS_HAE_KEYS, n * E::G2B, &d_scaled))) return rc;
   HIPCHK(hipMemcpyAsync(d_sig, sig, E::G1B, hipMemcpyHostToDevice, st));
   if (n) HIPCHK(hipMemcpyAsync(d_keys, keys, n * E::G2B, hipMemcpyHostToDevice, st));
   if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
   if ((rc = hae_exponents_dev<C>(c, st, keys, n, &d_t))) return rc;
-  if (n) {
-    kl::scale<C>(st, BGLS_G2, (const uint8_t*)d_keys, (const uint8_t*)d_t, nullptr, n, (uint8_t*)d_scaled, (uint32_t*)d_flags, 16);
-    HIPCHK(hipGetLastError());
-  }
+  // e(H(m_i), t_i pk_i) = e(t_i H(m_i), pk_i): the exponent goes to the G1 side (a third of the G2 work, same GT value)
   MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
-  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_scaled, mv, n, 0, (uint8_t*)d_part, (uint32_t*)d_flags)))
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, mv, n, 0, (uint8_t*)d_part, (uint32_t*)d_flags,
+                              (const uint8_t*)d_t)))
     return rc;
   return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
 }
@@ -1214,7 +1285,35 @@ int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n
   return flags_to_rc(f);
 }
 
-// LoadPublicKey over a batch (bgls/bgls.go:40-43): out[i] = sk_i * g2 (group = BGLS_G2) or sk_i * g1
+// window multiples of a generator for this device (DeviceTables), built on first use
+template <class C>
+int fixed_base_table(Ctx& c, int group, const void** out) {
+  DeviceTables& t = tables_of(c.device);
+  std::lock_guard<std::mutex> lk(t.mu);
+  void*& slot = t.fixed_base[C::CURVE_ID][group - 1];
+  if (!slot) {
+    void* tab = nullptr;
+    hipStream_t bs = nullptr;
+    HIPCHK(hipMalloc(&tab, kl::fb_table_bytes<C>(group)));
+    hipError_t e = hipStreamCreate(&bs);
+    if (e == hipSuccess) {
+      kl::fb_build<C>(bs, group, tab);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(bs);
+    }
+    if (bs) (void)hipStreamDestroy(bs);
+    if (e != hipSuccess) {
+      (void)hipFree(tab);
+      return fail(BGLS_ERR_HIP, "building the fixed-base table", e);
+    }
+    slot = tab;
+  }
+  *out = slot;
+  return 0;
+}
+
+// LoadPublicKey over a batch (bgls/bgls.go:40-43): out[i] = sk_i * g2 (group = BGLS_G2) or sk_i * g1, one mixed addition
+// per scalar byte from the resident table of window multiples
 template <class C>
 int scale_generator_t(int group, const uint8_t* sks, size_t n, uint8_t* out) {
   typedef Engine<C> E;
@@ -1226,10 +1325,12 @@ int scale_generator_t(int group, const uint8_t* sks, size_t n, uint8_t* out) {
   if (n == 0) return 0;
   const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
   void *d_sc, *d_out;
+  const void* tab;
+  if ((rc = fixed_base_table<C>(c, group, &tab))) return rc;
   if ((rc = c.get(WS_IN_C, n * 32, &d_sc))) return rc;
   if ((rc = c.get(WS_IN_A, n * PB, &d_out))) return rc;
   HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
-  kl::scale_aff<C>(st, group, nullptr, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  kl::fb_scale<C>(st, group, tab, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1959,6 +2060,18 @@ int bgls_set_miller_shape(int shape, int pairings_per_group) {
   g_shape.store(shape);
   g_ng.store(pairings_per_group);
   return 0;
+}
+
+int bgls_set_msm_min(size_t n) {
+  g_msm_min.store(n);
+  return 0;
+}
+
+int bgls_weighted_sum_dev(int curve, int group, const void* d_pts, const void* d_w16, size_t n, void* d_out, void* stream) {
+  if (group != BGLS_G1 && group != BGLS_G2) return fail(BGLS_ERR_ARG, "bad group");
+  if (!d_out || (n && (!d_pts || !d_w16))) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  DISPATCH(curve, weighted_sum_dev_t<CV>(group, d_pts, d_w16, n, d_out, stream));
 }
 
 int bgls_select_context(int index) {

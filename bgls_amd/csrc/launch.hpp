@@ -33,6 +33,24 @@ void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8
 void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed, int iters, uint64_t* sink);
 template <class C> size_t jac_bytes(int group) { return (size_t)3 * (group == 1 ? 1 : 2) * C::L * 4; }
 
+// ---- k_msm.hip   (bucket-method weighted sums, fixed-base generator multiples, in-place G1 scaling)
+struct MsmPlan { int c, W, K, S; uint32_t NB, NQ, NCH; };    // window bits, windows, digits per chunk, threads per bucket, buckets, chunks per window, chunks
+MsmPlan msm_plan(size_t n);
+template <class C> size_t msm_aff_bytes(int group);
+template <class C>
+void msm_parse(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, const MsmPlan& p, void* aff,
+               uint32_t* cnt, uint32_t* flags);
+void msm_scan(hipStream_t st, uint32_t* cnt, uint32_t NB, uint32_t* start, uint32_t* meta);
+template <class C>
+void msm_scatter(hipStream_t st, int group, const void* aff, const uint8_t* w16, size_t n, const MsmPlan& p, uint32_t* cursor, uint32_t* list);
+template <class C>
+void msm_buckets(hipStream_t st, int group, const void* aff, const uint32_t* list, const uint32_t* start, const MsmPlan& p, void* parts);
+template <class C> void msm_tail(hipStream_t st, int group, const void* buckets, const MsmPlan& p, void* chunks, void* wins, void* out_jac);
+template <class C> size_t fb_table_bytes(int group);
+template <class C> void fb_build(hipStream_t st, int group, void* table);
+template <class C> void fb_scale(hipStream_t st, int group, const void* table, const uint8_t* scalars, size_t n, uint8_t* out);
+template <class C> void scale_g1_inplace(hipStream_t st, Aff<F1<C>>* pts, const uint8_t* w16, size_t n);
+
 // ---- k_miller_bn.hip / k_miller_bls.hip   (dbg != 0 only in -DBGLS_DEV builds: timing variants, wrong results)
 template <class C>
 void miller_ab64(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,

@@ -124,6 +124,14 @@ int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, si
  * verifyAggSig with duplicate messages allowed. */
 int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob,
                               const uint64_t* msg_off, size_t n);
+/* getAggregatePubKey over device-resident inputs (bgls/blsHAE.go:74-77 = AggregatePoints(ScalePoints(points, w)),
+ * curves/curve.go:73-121,190-214): d_out (affine bytes of the group) = sum_i w_i P_i, weights = n 16-byte big-endian
+ * magnitudes.  Computed by the bucket method (k_msm.hip: a counting sort of the (point, window) pairs by digit, one
+ * thread per bucket, running sums) when n >= the threshold below and the digits are balanced, else by one
+ * double-and-add per point; both give the same bytes. */
+int bgls_weighted_sum_dev(int curve, int group, const void* d_pts, const void* d_w16, size_t n, void* d_out, void* stream);
+/* Smallest n for which weighted sums take the bucket method (default 32; tests pin both paths with 0 / SIZE_MAX). */
+int bgls_set_msm_min(size_t n);
 /* verifyMultiSignature over ScalePoints(keys, multiplicity) -- the body of KoskVerifyMultiSignatureWithMultiplicity
  * (bgls/blsKosk.go:137-150; that function prepends 0x01 to msg like KoskVerifyMultiSignature, the host mirror does
  * the same).  multiplicity: n int64 factors, negative = negate-then-multiply (curves/curve.go:190-214); NULL = plain
