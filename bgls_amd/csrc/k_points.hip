@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64, 2) k_sum_main(const uint8_t* pts, size_t n
 
 // one partial per wave from up to 64 Jacobian partials per wave (the upper levels of the tree: few elements, latency-bound)
 template <class F>
-__global__ void __launch_bounds__(64, 2) k_sum_wave(const Jac<F>* in, size_t n, Jac<F>* out) {
+__global__ void __launch_bounds__(64) k_sum_wave(const Jac<F>* in, size_t n, Jac<F>* out) {      // lone waves: full register budget, no spills
   const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
   Jac<F> acc = t < n ? in[t] : jac_inf<F>();
 #pragma unroll 1
@@ -70,8 +70,10 @@ __global__ void __launch_bounds__(64, 2) k_sum_wave(const Jac<F>* in, size_t n, 
 // out[t] = in[2t] + in[2t+1]: one addition per thread.  The upper levels of the tree are latency-bound whatever their
 // shape; halving with half as many threads per launch keeps their MACHINE time small (a wave-shuffle tree runs every
 // level on all lanes), so the tail of one verification leaves the SIMDs to the main pass of the next.
-template <class F>
-__global__ void __launch_bounds__(64, 2) k_sum_pair(const Jac<F>* in, size_t n, Jac<F>* out) {
+// OCC: waves per SIMD the register budget is sized for (1 once the launch is down to a wave per SIMD or less: a lone
+// wave cannot hide the latency of spilled registers).
+template <class F, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_sum_pair(const Jac<F>* in, size_t n, Jac<F>* out) {
   const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
   const size_t lo = 2 * t;
   if (lo >= n) return;
@@ -317,8 +319,14 @@ void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t
 template <class C>
 void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out) {
   const size_t nout = (n + 1) / 2;
-  if (group == BGLS_G1) k_sum_pair<F1<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
-  else k_sum_pair<F2<C>><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
+  const bool lone = nout <= 64 * 1024;                    // at most one wave per SIMD
+  if (group == BGLS_G1) {
+    if (lone) k_sum_pair<F1<C>, 1><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
+    else k_sum_pair<F1<C>, 2><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
+  } else {
+    if (lone) k_sum_pair<F2<C>, 1><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
+    else k_sum_pair<F2<C>, 2><<<nblk(nout, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
+  }
 }
 template <class C>
 void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out) {

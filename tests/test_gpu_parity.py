@@ -418,6 +418,8 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["signers_per_gpu"] == 4096
     other = d["records"]["bls12_8192"]                     # the BLS12-381 record rides on the same line for every N
     assert other["n_gpus"] == 2 and other["value"] > 0 and other["config"]["signers_per_gpu"] == 4096
+    ms = d["records"]["altbn128_multisig_8192"]            # config 4 cut over the ranks: partial key sums, one all-gather
+    assert ms["n_gpus"] == 2 and ms["value"] > 0 and ms["scaling"] == "strong"
 
 
 def test_two_contexts_in_flight(gpu_lib, curve):
