@@ -16,7 +16,7 @@ for d in glob.glob(src + "/stats_*") + glob.glob(src + "/pmc_*"):
         if f.endswith("agent_info.csv") or f.endswith("kernel_trace.csv") and os.path.getsize(f) > 3_000_000:
             continue
         shutil.copy(f, out)
-for f in glob.glob(src + "/bench_*.json") + [src + "/pytest_gpu.log"]:
+for f in glob.glob(src + "/bench_*.json") + glob.glob(src + "/bench_*.txt") + [src + "/pytest_gpu.log"]:
     if os.path.exists(f):
         shutil.copy(f, dst)
 
