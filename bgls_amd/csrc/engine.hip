@@ -551,7 +551,10 @@ struct Engine {
     size_t cnt = waves * 64;
     while (cnt > 1) {
       // halving launches while there is parallelism to speak of, then 64 -> 1 per wave with lane shuffles
-      if (cnt > 4096) {
+      if (group == BGLS_G2 && cnt <= 8192) {
+        kl::sum_coop<C>(st, a, cnt, b);                    // few additions left: one wave per addition, ~12 us a level
+        cnt = (cnt + 1) / 2;
+      } else if (cnt > 4096) {
         kl::sum_pair<C>(st, group, a, cnt, b);
         cnt = (cnt + 1) / 2;
       } else {
@@ -630,14 +633,13 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
   // apk = sum(keys)  (AggregatePoints)
   if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags))) return rc;
-  // pairs (-H(msg), apk) and (sig, g2): one message through the batch hashing path, then the two-pairing product on the
-  // cooperative Miller kernel with the (sig, g2) pair on the pre-computed generator lines
+  // pairs (H(msg), apk) and (-sig, g2) -- the reference's e(sig, g2) = e(H(msg), apk) (bgls/bgls.go:59-70) as a product that
+  // must be 1: one message through the batch hashing path, then the two-pairing product on the cooperative Miller kernel
+  // with the (-sig, g2) pair on the pre-computed generator lines
   MsgView mv = {d_msg, nullptr, msg_len, msg_len};
   Aff<F1<C>>* g1s = (Aff<F1<C>>*)d_g1s;
-  if ((rc = E::hash_to_g1(c, st, mv, 1, g1s + 2, (uint32_t*)d_flags))) return rc;
-  kl::g1_to_bytes<C>(st, g1s + 2, 1, (uint8_t*)d_part);                                    // scratch: H(m) bytes
-  kl::g1_parse<C>(st, (const uint8_t*)d_part, 1, 1, g1s, (uint32_t*)d_flags);               // -H(m)
-  kl::g1_parse<C>(st, d_sig, 1, 0, g1s + 1, (uint32_t*)d_flags);                            // sig
+  if ((rc = E::hash_to_g1(c, st, mv, 1, g1s, (uint32_t*)d_flags))) return rc;               // H(m)
+  kl::g1_parse<C>(st, d_sig, 1, 1, g1s + 1, (uint32_t*)d_flags);                            // -sig
   if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
   if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
   return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
@@ -1094,7 +1096,7 @@ int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, co
   if ((rc = c.get(WS_MSM_LIST, n * (size_t)p.W * 4, &list))) return rc;
   if ((rc = c.get(WS_JAC_A, (size_t)p.NB * p.S * JB, &buckets))) return rc;
   const size_t half = p.S > 1 ? (size_t)p.NB * p.S / 2 : 0;                  // second buffer of the partials' pairwise folds
-  if ((rc = c.get(WS_JAC_B, (half + (size_t)p.NCH + p.W + 1) * JB, &tail))) return rc;
+  if ((rc = c.get(WS_JAC_B, (half + kl::msm_tail_points(p)) * JB, &tail))) return rc;
   uint32_t* d_meta = (uint32_t*)cnt + p.NB;
   HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)p.NB + 2) * 4, st));
   kl::msm_parse<C>(st, group, d_pts, d_w16, d_signs, n, p, aff, (uint32_t*)cnt, d_flags);
@@ -1105,9 +1107,7 @@ int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, co
   HIPCHK(hipStreamSynchronize(st));
   const size_t mean = n >> p.c;
   if (meta[0] > (mean * 8 > 64 ? mean * 8 : 64)) return weighted_sum_naive<C>(c, st, group, d_pts, d_w16, d_signs, n, d_out, d_flags);
-  uint8_t* chunks = (uint8_t*)tail + half * JB;
-  uint8_t* wins = chunks + (size_t)p.NCH * JB;
-  uint8_t* res = wins + (size_t)p.W * JB;
+  void* res = nullptr;
   kl::msm_scatter<C>(st, group, aff, d_w16, n, p, (uint32_t*)cnt, (uint32_t*)list);
   kl::msm_buckets<C>(st, group, aff, (const uint32_t*)list, (const uint32_t*)start, p, buckets);
   void *a = buckets, *b = tail;
@@ -1115,7 +1115,7 @@ int weighted_sum_dev(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, co
     kl::sum_pair<C>(st, group, a, cntp, b);
     std::swap(a, b);
   }
-  kl::msm_tail<C>(st, group, a, p, chunks, wins, res);
+  kl::msm_tail<C>(st, group, a, p, (uint8_t*)tail + half * JB, &res);
   kl::jac_to_bytes<C>(st, group, res, 1, d_out);
   HIPCHK(hipGetLastError());
   return 0;

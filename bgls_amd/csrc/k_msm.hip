@@ -19,6 +19,7 @@
 #include "wire.hpp"
 #include "launch.hpp"
 #include "points_inl.hpp"
+#include "jac_coop.hpp"
 #include "../../include/bgls_hip.h"
 
 using namespace bgls;
@@ -199,6 +200,17 @@ __global__ void __launch_bounds__(64) k_msm_final(const Jac<F>* wins, int W, int
   if (lane == 0) out[0] = acc;
 }
 
+// G2: window j doubled c j times, one wave per window (jac_coop.hpp: ~7 us a doubling instead of 23)
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_shift(Jac<F2<C>>* wins, int c) {
+  const int j = blockIdx.x;
+  Jac<F2<C>> acc = wins[j];
+  const CoopF2<C> k(0);
+#pragma unroll 1
+  for (int i = 0; i < c * j; ++i) acc = coop_jac_dbl<C>(k, acc);
+  if (threadIdx.x == 0) wins[j] = acc;
+}
+
 // ---- fixed-base: table[j * 255 + d - 1] = d 2^(8 j) G  (j < 32 byte positions, d = 1 .. 255), Montgomery affine
 constexpr int FB_ROW = 255, FB_WINDOWS = 32;
 
@@ -302,11 +314,40 @@ static void msm_buckets_f(hipStream_t st, const void* aff, const uint32_t* list,
   else
     k_msm_buckets<F, 1><<<nblk(nthreads, 64), 64, 0, st>>>((const Aff<F>*)aff, list, start, nthreads, p.S, (Jac<F>*)buckets);
 }
+size_t msm_tail_points(const MsmPlan& p) { return (size_t)p.NCH + p.NCH / 2 + 2 * (size_t)p.W + 4; }
+
+// G1: chunk sums, one wave per window, one wave for the final doublings and the sum over windows
 template <class F>
-static void msm_tail_f(hipStream_t st, const void* folded, const MsmPlan& p, void* chunks, void* wins, void* out) {
-  k_msm_chunks<F><<<nblk(p.NCH, 64), 64, 0, st>>>((const Jac<F>*)folded, p.c, p.K, 1, p.NCH, (Jac<F>*)chunks);
-  k_msm_windows<F><<<p.W, 64, 0, st>>>((const Jac<F>*)chunks, p.NQ, (Jac<F>*)wins);
-  k_msm_final<F><<<1, 64, 0, st>>>((const Jac<F>*)wins, p.W, p.c, (Jac<F>*)out);
+static void msm_tail_f(hipStream_t st, const void* folded, const MsmPlan& p, void* scratch, void** result) {
+  Jac<F>* chunks = (Jac<F>*)scratch;
+  Jac<F>* wins = chunks + p.NCH;
+  Jac<F>* out = wins + p.W;
+  k_msm_chunks<F><<<nblk(p.NCH, 64), 64, 0, st>>>((const Jac<F>*)folded, p.c, p.K, 1, p.NCH, chunks);
+  k_msm_windows<F><<<p.W, 64, 0, st>>>(chunks, p.NQ, wins);
+  k_msm_final<F><<<1, 64, 0, st>>>(wins, p.W, p.c, out);
+  *result = out;
+}
+// G2: the chunk sums are added per window by a pairwise tree of wave-per-addition launches (NQ is a power of two: the
+// halving keeps the windows apart), every window is doubled into place by its own wave, and the windows are added up
+template <class C>
+static void msm_tail_g2(hipStream_t st, const void* folded, const MsmPlan& p, void* scratch, void** result) {
+  typedef F2<C> F;
+  Jac<F>* a = (Jac<F>*)scratch;
+  Jac<F>* b = a + p.NCH;
+  k_msm_chunks<F><<<nblk(p.NCH, 64), 64, 0, st>>>((const Jac<F>*)folded, p.c, p.K, 1, p.NCH, a);
+  size_t cnt = p.NCH;
+  while (cnt > (size_t)p.W) {
+    sum_coop<C>(st, a, cnt, b);
+    cnt /= 2;
+    std::swap(a, b);
+  }
+  k_msm_shift<C><<<p.W, 64, CoopF2<C>::WAVE_DW * 4, st>>>(a, p.c);
+  while (cnt > 1) {
+    sum_coop<C>(st, a, cnt, b);
+    cnt = (cnt + 1) / 2;
+    std::swap(a, b);
+  }
+  *result = a;
 }
 // partial bucket sums: NB * S Jacobian points, the S partials of a bucket next to each other
 template <class C>
@@ -316,9 +357,9 @@ void msm_buckets(hipStream_t st, int group, const void* aff, const uint32_t* lis
 }
 // buckets (one Jacobian point each) -> the weighted sum
 template <class C>
-void msm_tail(hipStream_t st, int group, const void* buckets, const MsmPlan& p, void* chunks, void* wins, void* out_jac) {
-  if (group == BGLS_G1) msm_tail_f<F1<C>>(st, buckets, p, chunks, wins, out_jac);
-  else msm_tail_f<F2<C>>(st, buckets, p, chunks, wins, out_jac);
+void msm_tail(hipStream_t st, int group, const void* buckets, const MsmPlan& p, void* scratch, void** result) {
+  if (group == BGLS_G1) msm_tail_f<F1<C>>(st, buckets, p, scratch, result);
+  else msm_tail_g2<C>(st, buckets, p, scratch, result);
 }
 
 template <class C>
@@ -345,7 +386,7 @@ void scale_g1_inplace(hipStream_t st, Aff<F1<C>>* pts, const uint8_t* w16, size_
                              uint32_t*);                                                                                                    \
   template void msm_scatter<C>(hipStream_t, int, const void*, const uint8_t*, size_t, const MsmPlan&, uint32_t*, uint32_t*);                \
   template void msm_buckets<C>(hipStream_t, int, const void*, const uint32_t*, const uint32_t*, const MsmPlan&, void*);                     \
-  template void msm_tail<C>(hipStream_t, int, const void*, const MsmPlan&, void*, void*, void*);                                            \
+  template void msm_tail<C>(hipStream_t, int, const void*, const MsmPlan&, void*, void**);                                                  \
   template size_t fb_table_bytes<C>(int);                                                                                                   \
   template void fb_build<C>(hipStream_t, int, void*);                                                                                       \
   template void fb_scale<C>(hipStream_t, int, const void*, const uint8_t*, size_t, uint8_t*);                                               \

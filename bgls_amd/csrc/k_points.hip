@@ -4,6 +4,7 @@
 #include "wire.hpp"
 #include "launch.hpp"
 #include "points_inl.hpp"
+#include "jac_coop.hpp"
 #include "../../include/bgls_hip.h"
 
 using namespace bgls;
@@ -80,6 +81,18 @@ __global__ void __launch_bounds__(64, OCC) k_sum_pair(const Jac<F>* in, size_t n
   Jac<F> acc = in[lo];
   if (lo + 1 < n) acc = jac_add_inl<F>(acc, in[lo + 1]);
   out[t] = acc;
+}
+// out[b] = in[2b] + in[2b+1], one WAVE per addition (jac_coop.hpp): the levels of a G2 tree with a few thousand additions
+// or fewer, where a thread-per-addition launch is a set of lone waves at 45-50 us per addition
+template <class C>
+__global__ void __launch_bounds__(64) k_sum_coop(const Jac<F2<C>>* in, size_t n, Jac<F2<C>>* out) {
+  const size_t lo = 2 * (size_t)blockIdx.x;
+  Jac<F2<C>> acc = in[lo];
+  if (lo + 1 < n) {
+    const CoopF2<C> k(0);
+    acc = coop_jac_add<C>(k, acc, in[lo + 1]);
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 // fan-in R, out-of-line additions: used by the weighted sums (few elements per thread)
 template <class F>
@@ -329,6 +342,10 @@ void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out) {
   }
 }
 template <class C>
+void sum_coop(hipStream_t st, const void* in, size_t n, void* out) {
+  k_sum_coop<C><<<(unsigned)((n + 1) / 2), 64, CoopF2<C>::WAVE_DW * 4, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
+}
+template <class C>
 void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out) {
   if (group == BGLS_G1) k_sum_wave<F1<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F1<C>>*)in, n, (Jac<F1<C>>*)out);
   else k_sum_wave<F2<C>><<<nblk(n, 64), 64, 0, st>>>((const Jac<F2<C>>*)in, n, (Jac<F2<C>>*)out);
@@ -395,6 +412,7 @@ void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed,
   template void sum_main<C>(hipStream_t, int, bool, const uint8_t*, size_t, unsigned, void*, uint32_t*);                         \
   template void sum_wave<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
   template void sum_pair<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
+  template void sum_coop<C>(hipStream_t, const void*, size_t, void*);                                                            \
   template void sum_next<C>(hipStream_t, int, const void*, size_t, int, void*);                                                  \
   template void jac_to_bytes<C>(hipStream_t, int, const void*, size_t, uint8_t*);                                                \
   template void wsum_first<C>(hipStream_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, void*, uint32_t*);       \

@@ -19,6 +19,7 @@ template <class C> void g1_parse(hipStream_t st, const uint8_t* in, size_t n, in
 template <class C> void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
 template <class C> void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out);
 template <class C> void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out);
+template <class C> void sum_coop(hipStream_t st, const void* in, size_t n, void* out);        // G2, one wave per addition (jac_coop.hpp)
 template <class C> void sum_next(hipStream_t st, int group, const void* in, size_t n, int R, void* out);
 template <class C> void jac_to_bytes(hipStream_t st, int group, const void* in, size_t n, uint8_t* out);
 template <class C> void wsum_first(hipStream_t st, int group, const uint8_t* pts, const uint8_t* w16, const uint8_t* signs, size_t n, void* out, uint32_t* flags);
@@ -45,7 +46,9 @@ template <class C>
 void msm_scatter(hipStream_t st, int group, const void* aff, const uint8_t* w16, size_t n, const MsmPlan& p, uint32_t* cursor, uint32_t* list);
 template <class C>
 void msm_buckets(hipStream_t st, int group, const void* aff, const uint32_t* list, const uint32_t* start, const MsmPlan& p, void* parts);
-template <class C> void msm_tail(hipStream_t st, int group, const void* buckets, const MsmPlan& p, void* chunks, void* wins, void* out_jac);
+// buckets (one Jacobian point each) -> the weighted sum; scratch: msm_tail_points(p) Jacobian points, the result is *result
+size_t msm_tail_points(const MsmPlan& p);
+template <class C> void msm_tail(hipStream_t st, int group, const void* buckets, const MsmPlan& p, void* scratch, void** result);
 template <class C> size_t fb_table_bytes(int group);
 template <class C> void fb_build(hipStream_t st, int group, void* table);
 template <class C> void fb_scale(hipStream_t st, int group, const void* table, const uint8_t* scalars, size_t n, uint8_t* out);
