@@ -65,6 +65,24 @@ def test_hash_to_g1_random_vs_oracle(gpu_lib, curve, kat):
         assert got[i] == coracle.hash_to_g1(curve["id"], many[i])
 
 
+def test_hash_to_g1_large_batch_schedule(gpu_lib):
+    """alt-bn128 batches of 2^17 messages and more test one counter per message and round while most messages are still
+    open (k_hash.hip h2c_bn): same points as the oracle on a strided sample (about one message in sixteen of it needs five
+    tries or more, i.e. reaches the later rounds), and the same bytes as the small-batch schedule on the first 4096."""
+    cid, fp = 0, 32
+    rnd = random.Random(1717)
+    n = (1 << 17) + 77
+    blob = rnd.randbytes(64 * n)
+    offs = (ctypes.c_uint64 * (n + 1))(*range(0, 64 * (n + 1), 64))
+    o = out(n * 2 * fp)
+    assert gpu_lib.bgls_hash_to_g1(cid, B(blob), offs, n, o) == 0
+    got = bytes(o)
+    small = hash_batch(gpu_lib, cid, fp, [blob[64 * i:64 * i + 64] for i in range(4096)])
+    assert b"".join(small) == got[:4096 * 2 * fp]
+    for i in list(range(0, n, 997)) + [n - 1, n - 2, 1 << 16, (1 << 17) - 1, 1 << 17]:
+        assert got[2 * fp * i:2 * fp * (i + 1)] == coracle.hash_to_g1(cid, blob[64 * i:64 * i + 64]), i
+
+
 def test_generators(gpu_lib, curve, kat):
     cid, n = curve["id"], curve["fp"]
     g1, g2 = out(2 * n), out(4 * n)
