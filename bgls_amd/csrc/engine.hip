@@ -297,9 +297,9 @@ struct Engine {
       kl::h2c_bn(st, mv, n, (uint32_t*)lists, (uint32_t*)cnts, out, d_flags);
     } else {
       void *pts, *kinds;
-      if ((rc = c.get(WS_H2C_PTS, 2 * n * sizeof(Aff<G1F>), &pts))) return rc;
+      if ((rc = c.get(WS_H2C_PTS, 2 * n * sizeof(Jac<G1F>), &pts))) return rc;
       if ((rc = c.get(WS_H2C_KIND, 2 * n * 4, &kinds))) return rc;
-      kl::h2c_bls(st, mv, n, (Aff<G1F>*)pts, (uint32_t*)kinds, out, raw);
+      kl::h2c_bls(st, mv, n, (Jac<G1F>*)pts, (uint32_t*)kinds, out, raw);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -136,8 +136,17 @@ __global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<
 }
 
 // BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
-// curves/hash.go:254-265), then exactly one square-root exponentiation.
-__global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items, Aff<F1<BLS381>>* pts, uint32_t* kinds) {
+// curves/hash.go:254-265), then exactly one square-root exponentiation -- and NO inversion.  The reference computes the
+// three Shallue-van de Woestijne candidates through 1 / (u v), u = t^2 + 1 + b, v = 3 t^2 (curves/hash.go:97-167); they
+// are the fractions
+//     x0 = (Z u - sqrt(-3) t^2) / u,    x1 = -x0 - 1 = (-N0 - u) / u,    x2 = 1 - u^2 / v = (v - u^2) / v,
+// and for x = N / D:  g(x) = x^3 + b = G / D^3 with G = N^3 + b D^3, so that
+//     g(x) is a square  <=>  chi(G D) >= 0                         (D^4 is a square; g = 0 <=> G = 0, which counts as one),
+//     sqrt(G / D^3) = G D^3 (G D^9)^((p-3)/4)                      (p = 3 mod 4; either root: the parity rule picks the sign),
+// and the point leaves as Jacobian (X, Y, Z) = (N D, y D^3, D).  The affine x and y are the reference's field elements (x is
+// the same fraction, y the root with the parity of t), so the hash point, normalised once per message by k_bls_combine,
+// has the same bytes; the binary-Euclid inversion this replaces was 40 % of the kernel.
+__global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items, Jac<F1<BLS381>>* pts, uint32_t* kinds) {
   typedef BLS381 C;
   size_t item = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (item >= n_items) return;
@@ -150,21 +159,33 @@ __global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items
   else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) kind = H2C_MINUS_G1;
   kinds[item] = kind;
   if (kind != H2C_SW) return;
-  BlsSwPrep pr = bls_sw_prep(tm);
   const Fp<C> b = fp_load<C>(C::B);
-  Fp<C> x = pr.x0;
-  Fp<C> g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
-  if (fp_jacobi<C>(g) < 0) {
-    x = fp_sub<C>(fp_neg<C>(pr.x0), fp_one<C>());
-    g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
-    if (fp_jacobi<C>(g) < 0) {
-      x = pr.x2;
-      g = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), b);
+  const Fp<C> t2 = fp_sqr<C>(tm);
+  const Fp<C> u = fp_add<C>(fp_add<C>(t2, fp_one<C>()), b);
+  const Fp<C> v = fp_mul3<C>(t2);
+  const Fp<C> N0 = fp_sub<C>(fp_mul<C>(fp_load<C>(C::Z_SW), u), fp_mul<C>(fp_load<C>(C::SQRT_M3), t2));
+  Fp<C> N = N0, D = u;
+  Fp<C> D3 = fp_mul<C>(fp_sqr<C>(D), D);
+  const Fp<C> bD3 = fp_mul<C>(b, D3);
+  Fp<C> G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), bD3);
+  if (fp_jacobi<C>(fp_mul<C>(G, D)) < 0) {
+    N = fp_sub<C>(fp_neg<C>(N0), u);
+    G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), bD3);
+    if (fp_jacobi<C>(fp_mul<C>(G, D)) < 0) {
+      D = v;
+      N = fp_sub<C>(v, fp_sqr<C>(u));
+      D3 = fp_mul<C>(fp_sqr<C>(D), D);
+      G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), fp_mul<C>(b, D3));
     }
   }
-  Fp<C> y = fp_sqrt_candidate<C>(g);
+  u32 e[C::L];                                              // (p - 3) / 4 = (p + 1) / 4 - 1 (the low limb is odd)
+#pragma unroll
+  for (int k = 0; k < C::L; ++k) e[k] = C::EXP_SQRT[k];
+  e[0] -= 1u;
+  const Fp<C> D9 = fp_mul<C>(fp_sqr<C>(D3), D3);
+  Fp<C> y = fp_mul<C>(fp_mul<C>(fp_pow_w4<C, C::L>(fp_mul<C>(G, D9), e), G), D3);
   if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
-  pts[item] = {x, y, false};
+  pts[item] = {fp_mul<C>(N, D), fp_mul<C>(y, D3), D};
 }
 
 // per message: h * (sw_0 + sw_1) + special contributions, to affine.  The sum is normalised once (one
@@ -176,7 +197,7 @@ __global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items
 // exponentiation by h in GT (k_cofactor_epilogue) instead of n 126-bit scalar multiplications; the rare
 // "+-generator" outcomes enter as +-G1K, G1K = (h^-1 mod r) g1.
 template <bool RAW>
-__global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+__global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Jac<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
   typedef BLS381 C;
   typedef F1<C> F;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -185,7 +206,7 @@ __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS38
   const Aff<F> g1 = {fp_load<C>(RAW ? C::G1KX : C::G1X), fp_load<C>(RAW ? C::G1KY : C::G1Y), false};
   for (int k = 0; k < 2; ++k) {
     const uint32_t kind = kinds[2 * i + k];
-    if (kind == H2C_SW) sw = jac_add_aff<F>(sw, pts[2 * i + k]);
+    if (kind == H2C_SW) sw = jac_add<F>(sw, pts[2 * i + k]);
     else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
     else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
   }
@@ -202,6 +223,52 @@ __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Aff<F1<BLS38
     if (dig != 0) r = jac_add_aff<F>(r, dig > 0 ? S : nS);
   }
   out[i] = jac_to_aff<F>(jac_add<F>(r, special));
+}
+
+// The verification path's combine (RAW) with the normalisation shared: a thread sums the two encodings of KB consecutive
+// messages, parks the Jacobian sums in the work-item array, and inverts the product of their Z coordinates once
+// (Montgomery's trick: the binary-Euclid inversion is ~240 field products' worth of divergent work, the trick costs 3 per
+// message).  A sum at infinity contributes 1 to the product and leaves as the point at infinity.
+template <int KB>
+__global__ void __launch_bounds__(64) k_bls_combine_raw_batched(size_t n, Jac<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+  typedef BLS381 C;
+  typedef F1<C> F;
+  const size_t i0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * KB;
+  if (i0 >= n) return;
+  const Aff<F> g1 = {fp_load<C>(C::G1KX), fp_load<C>(C::G1KY), false};
+  Fp<C> pre[KB];                                            // pre[k] = Z_0 ... Z_k (infinite sums skipped)
+  Fp<C> run = fp_one<C>();
+#pragma unroll 1
+  for (int k = 0; k < KB; ++k) {
+    const size_t i = i0 + k;
+    if (i < n) {
+      Jac<F> sw = jac_inf<F>();
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t kind = kinds[2 * i + h];
+        if (kind == H2C_SW) sw = jac_add<F>(sw, pts[2 * i + h]);
+        else if (kind == H2C_PLUS_G1) sw = jac_add_aff<F>(sw, g1);
+        else if (kind == H2C_MINUS_G1) sw = jac_add_aff<F>(sw, aff_neg<F>(g1));
+      }
+      pts[2 * i] = sw;
+      if (!jac_is_inf<F>(sw)) run = fp_mul<C>(run, sw.Z);
+    }
+    pre[k] = run;
+  }
+  Fp<C> inv = fp_inv<C>(run);
+#pragma unroll 1
+  for (int k = KB - 1; k >= 0; --k) {
+    const size_t i = i0 + k;
+    if (i >= n) continue;
+    const Jac<F> sw = pts[2 * i];
+    if (jac_is_inf<F>(sw)) {
+      out[i] = {fp_zero<C>(), fp_zero<C>(), true};
+      continue;
+    }
+    const Fp<C> zi = k ? fp_mul<C>(inv, pre[k - 1]) : inv;   // 1 / Z_k
+    inv = fp_mul<C>(inv, sw.Z);
+    const Fp<C> zi2 = fp_sqr<C>(zi);
+    out[i] = {fp_mul<C>(sw.X, zi2), fp_mul<C>(fp_mul<C>(sw.Y, zi2), zi), false};
+  }
 }
 
 // ---- BLAKE2Xb expansion (bgls/blsHAE.go:80-93): node i of the XOF is one compression of the 64-byte root with its
@@ -270,10 +337,11 @@ void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn,
 }
 
 // BLS12-381: pts / kinds hold 2n work items (message, tag); raw = uncleared sum (verification path, cofactor in GT)
-void h2c_bls(hipStream_t st, MsgView mv, size_t n, Aff<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw) {
+void h2c_bls(hipStream_t st, MsgView mv, size_t n, Jac<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw) {
   const size_t items = 2 * n;
   k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, pts, kinds);
-  if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  if (raw && n >= ((size_t)1 << 18)) k_bls_combine_raw_batched<4><<<nblk((n + 3) / 4, 64), 64, 0, st>>>(n, pts, kinds, out);
+  else if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
   else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
 }
 

@@ -142,3 +142,31 @@ def test_config5_bls12_2pow20_in_8_shards(gpu_lib):
     assert run(dup, shards, t_sig_dup, scan=True)[0] == 0         # VerifyAggregateSignature does not
     # host-buffer door, whole batch in one call
     assert lib.bgls_verify_aggregate(cid, agg, keys, B(msgs), off, n, 0) == 1
+
+
+def test_bls12_hash_normalisation_batches_agree(gpu_lib):
+    """BLS12-381 batches of 2^18 messages and more normalise the hash points four at a time with one shared inversion
+    (k_bls_combine_raw_batched); smaller ones one at a time.  A ragged 2^18 + 3 batch in one call and the same batch cut at
+    2^17 (two calls on the per-message kernel) give the same partial Miller product."""
+    import torch
+    lib, cid, fp = gpu_lib, 1, 48
+    n = (1 << 18) + 3
+    gtb = 12 * fp
+    rnd = random.Random(0xB6150000 + 55)
+    keys = gen_keys(lib, cid, fp, [rnd.randrange(1, ORDER[cid]) for _ in range(n)])
+    dev = torch.device("cuda:0")
+    t_keys = torch.frombuffer(bytearray(bytes(keys)), dtype=torch.uint8).to(dev)
+    t_msgs = torch.frombuffer(bytearray(rnd.randbytes(64 * n)), dtype=torch.uint8).to(dev)
+
+    def part(lo, hi):
+        p = torch.zeros(gtb, dtype=torch.uint8, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert lib.bgls_miller_product_dev(cid, None, t_keys.data_ptr() + lo * 4 * fp, t_msgs.data_ptr() + lo * 64, 64, 64, hi - lo, 0,
+                                           p.data_ptr(), flags.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert int(flags.cpu()[0]) == 0
+        return bytes(p.cpu().numpy())
+
+    whole = part(0, n)
+    cut = coracle.gt_mul(cid, part(0, 1 << 17), part(1 << 17, n))
+    assert whole == cut
