@@ -167,7 +167,11 @@ int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uin
 int bgls_point_check(int curve, int group, const uint8_t* a);
 /* The same validation over a batch (what constructing n Points costs in the reference: MakeG1Point / MakeG2Point with
  * check, UnmarshalG1 / UnmarshalG2; curves/altbn128.go:149-179,296-376, curves/bls12_381.go:196-264): ok_out[i] = 1 iff
- * point i has canonical coordinates, lies on its curve and -- G2 -- in the order-r subgroup.  Returns 0 or < 0. */
+ * point i has canonical coordinates, lies on its curve and -- G2 -- in the order-r subgroup.  G1 points are tested for the
+ * curve only: alt-bn128's G1 is the whole curve, and a BLS12-381 G1 point's component outside the order-r subgroup is
+ * annihilated by the reduced pairing (its order divides the cofactor, coprime to r: e(P + T, Q) = e(P, Q)), so no verdict
+ * depends on it; what upstream's G1 Check() tests beyond the curve equation is unpinned (the library is not vendored).
+ * Returns 0 or < 0. */
 int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out);
 /* GetG1 / GetG2 (curves/altbn128.go:423-429, curves/bls12_381.go:275-281) */
 int bgls_generator(int curve, int group, uint8_t* out);
