@@ -491,3 +491,39 @@ def test_batch_beyond_one_launch(gpu_lib, curve):
         assert gpu_lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(bytes(bad)), off, n, 0) == 0
     g1 = out(2 * n_fp); gpu_lib.bgls_generator(cid, 1, g1)
     assert gpu_lib.bgls_verify_aggregate(cid, g1, B(keys), B(blob), off, n, 0) == 0
+
+
+def test_host_threads_on_their_own_contexts(gpu_lib):
+    """Four host threads, each on its own context (bgls_select_context is per thread), verify different instances of both
+    curves at once -- valid and tampered, small (latency kernels) and large (batch kernels), aggregate and multi-signature,
+    plus hashed-exponent sums: every call answers as it does alone.  ctypes releases the GIL during the calls, so the
+    library's context locks, per-device tables and workspaces really are entered concurrently."""
+    import threading
+    lib = gpu_lib
+    jobs = []
+    for k, (cid, n_fp, n) in enumerate(((0, 32, 40), (1, 48, 300), (0, 32, 3000), (1, 48, 90))):
+        agg, keys, msgs = make_instance(lib, cid, n_fp, n, 9000 + k)
+        bad = list(msgs); bad[n // 3] = bytes([bad[n // 3][0] ^ 0x40]) + bad[n // 3][1:]
+        jobs.append((cid, n, agg, keys, msgs, bad))
+    errors = []
+
+    def work(k):
+        try:
+            cid, n, agg, keys, msgs, bad = jobs[k]
+            assert lib.bgls_select_context(k) == 0
+            for it in range(6):
+                assert lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(b"".join(msgs)), offsets(msgs), n, 0) == 1, (k, it)
+                assert lib.bgls_verify_aggregate(cid, B(agg), B(keys), B(b"".join(bad)), offsets(bad), n, 0) == 0, (k, it)
+                t = out(16 * n)
+                assert lib.bgls_hae_exponents(cid, B(keys), n, t) == 0
+                assert bytes(t) == coracle.blake2xb(keys, 16 * n)
+        except Exception as e:                                        # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    lib.bgls_select_context(0)
+    assert not errors, errors
