@@ -294,7 +294,7 @@ struct Engine {
         if ((rc = c.get(WS_H2C_CNT, 64, &cnts))) return rc;
         HIPCHK(hipMemsetAsync(cnts, 0, 64, st));
       }
-      kl::h2c_bn(st, mv, n, (uint32_t*)lists, (uint32_t*)cnts, out, d_flags);
+      kl::h2c_bn(st, mv, n, (uint32_t*)lists, (uint32_t*)cnts, out, d_flags, throughput_mode());
     } else {
       void *pts, *kinds;
       if ((rc = c.get(WS_H2C_PTS, 2 * n * sizeof(Jac<G1F>), &pts))) return rc;

@@ -297,7 +297,7 @@ void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t m
 // alt-bn128: (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.  Each
 // round costs one try of latency, so the schedule is short: after three rounds a message is still unfinished with
 // probability 2^-37.  Acceptance test = Legendre symbol, square root once at the end (k_h2c_bn_finish).
-void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn, Aff<F1<BN254>>* out, uint32_t* flags) {
+void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn, Aff<F1<BN254>>* out, uint32_t* flags, bool lean) {
   if (n < 256) {
     k_h2c_bn_jacobi<<<nblk(n, 64), 64, 0, st>>>(mv, n, out, flags);
     return;
@@ -310,9 +310,10 @@ void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn,
     return (unsigned)(b > 8192 ? 8192 : b);
   };
   const double N = (double)n;
-  if (n >= ((size_t)1 << 17)) {
-    // Large batches are bound by the number of tests, not by the latency of a round: test one counter at a time while
-    // half of the messages are still open (2.3 n tests in all instead of the 4 n of the schedule below).
+  if (lean || n >= ((size_t)1 << 17)) {
+    // Large batches -- and any batch that shares the machine with other verifications (throughput mode) -- are bound by
+    // the number of tests, not by the latency of a round: test one counter at a time while half of the messages are still
+    // open (2.3 n tests in all instead of the 4 n of the schedule below, two more rounds of latency).
     k_h2c_bn_round<1><<<nblk(n, 64), 64, 0, st>>>(mv, n, nullptr, nullptr, 0, L0, cn + 1, 0, out, flags);
     k_h2c_bn_round<1><<<grid(N / 2, 1), 64, 0, st>>>(mv, n, L0, cn + 1, 1, L1, cn + 2, 0, out, flags);
     k_h2c_bn_round<2><<<grid(N / 4, 2), 64, 0, st>>>(mv, n, L1, cn + 2, 2, L0, cn + 3, 0, out, flags);
