@@ -110,7 +110,7 @@ __device__ __forceinline__ void lds_store_f2(int off, const Fp2<C>& a) {
 //   A[t] = entry a_e0 + t*a_es of region ra;  B = entries {2k, 2k+1} = {e_k, xi e_k} of region rb.
 template <class C, int NT, bool XF = false>
 __device__ __forceinline__ Fp2<C> coop_dot_inl(LReg ra, int a_e0, int a_es, LReg rb, int j, const int* sh) {
-  constexpr int L = C::L, W = 2 * C::L;
+  constexpr int W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) v0[k] = v1[k] = s[k] = 0;
@@ -154,7 +154,7 @@ __device__ __noinline__ Fp2<C> coop_dot(LReg ra, int a_e0, int a_es, LReg rb, in
 __device__ __constant__ const unsigned COOP_SQ_TAB[6] = {0x5be2e900u, 0xffe3ea88u, 0x64eb0990u, 0xffec9198u, 0x6d1299a0u, 0xff9aa1a8u};
 template <class C, bool XF = false>
 __device__ __forceinline__ Fp2<C> coop_sqr_sym_inl(LReg rb, int j) {
-  constexpr int L = C::L, W = 2 * C::L;
+  constexpr int W = 2 * C::L;
   u32 v0[W], v1[W], s[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) v0[k] = v1[k] = s[k] = 0;
@@ -207,7 +207,6 @@ __device__ __forceinline__ void coop_publish(int rb_off, int j, const Fp2<C>& v,
 // f <- f * g for two distributed values: g's coefficient of this lane is `gj`, f lives in RB.
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_mul(int gb, int j, const Fp2<C>& gj, bool live, int rl = Coop<C>::RL) {
-  typedef Coop<C> K;
   if (live) lds_st<C>(reg_rl<C>(gb, rl), j, gj);
   wave_sync();
   Fp2<C> r;
@@ -231,7 +230,6 @@ __device__ __forceinline__ Fp2<C> coop_sqr(int gb, int j) {
 // f <- f * line_m, line coefficients at RL[m][0..2]
 template <class C, bool INL = false>
 __device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m, int rl = Coop<C>::RL) {
-  typedef Coop<C> K;
   if constexpr (INL) return coop_dot_inl<C, 3>(reg_rl<C>(gb, rl), 3 * m, 1, reg_rb<C>(gb), j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
   else return coop_dot<C, 3>(reg_rl<C>(gb, rl), 3 * m, 1, reg_rb<C>(gb), j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
 }
@@ -240,7 +238,6 @@ __device__ __forceinline__ Fp2<C> coop_mul_line(int gb, int j, int m, int rl = C
 template <class C>
 __device__ __forceinline__ void coop_write_line(int gb, int j, const LineCoeffs<C>& l, const Fp<C>& xP, const Fp<C>& yP, bool valid,
                                                 bool live, int rl = Coop<C>::RL) {
-  typedef Coop<C> K;
   Fp2<C> e0, e1, e2;
   if constexpr (C::TWIST_D) {
     e0 = f2_muls<C>(l.c0, yP); e1 = f2_muls<C>(l.c1, xP); e2 = l.c2;
