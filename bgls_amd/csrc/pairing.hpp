@@ -120,13 +120,13 @@ BGLS_HD void dbl_step_emit(G2Proj<C>& R, Emit&& emit) {
   Fp2<C> Fv = f2_mul3<C>(E);
   R.X = f2_mul_inl<C>(A, f2_sub<C>(B, Fv));
   Fp2<C> G = f2_half<C>(f2_add<C>(B, Fv));
-  R.Y = f2_sub<C>(f2_sqr_inl<C>(G), f2_mul3<C>(f2_sqr_inl<C>(E)));
+  R.Y = f2_sqrsub3_inl<C>(G, E);
 }
 template <class C, class Emit>
 BGLS_HD void add_step_emit(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq, Emit&& emit) {
   Fp2<C> th = f2_sub<C>(R.Y, f2_mul_inl<C>(yq, R.Z));
   Fp2<C> la = f2_sub<C>(R.X, f2_mul_inl<C>(xq, R.Z));
-  emit(2, f2_sub<C>(f2_mul_inl<C>(th, xq), f2_mul_inl<C>(la, yq)));
+  emit(2, f2_mulsub_inl<C>(th, xq, la, yq));
   emit(0, la);
   emit(1, f2_neg<C>(th));
   Fp2<C> D = f2_sqr_inl<C>(la);
@@ -135,7 +135,7 @@ BGLS_HD void add_step_emit(G2Proj<C>& R, const Fp2<C>& xq, const Fp2<C>& yq, Emi
   Fp2<C> Hh = f2_sub<C>(f2_add<C>(E, f2_mul_inl<C>(R.Z, f2_sqr_inl<C>(th))), f2_dbl<C>(G));
   R.X = f2_mul_inl<C>(la, Hh);
   R.Z = f2_mul_inl<C>(R.Z, E);
-  R.Y = f2_sub<C>(f2_mul_inl<C>(th, f2_sub<C>(G, Hh)), f2_mul_inl<C>(E, R.Y));
+  R.Y = f2_mulsub_inl<C>(th, f2_sub<C>(G, Hh), E, R.Y);
 }
 
 template <class C>

@@ -113,6 +113,71 @@ BGLS_HD Fp2<C> f2_sqr_inl(const Fp2<C>& a) {
   return r;
 }
 
+// a b - c d with ONE Montgomery reduction per component: six wide products, two reductions instead of four.  The wide
+// differences carry a bias of 3 p^2 and stay below 5 p^2 < 2 p 2^(32L) on both curves.
+template <class C>
+BGLS_HD Fp2<C> f2_mulsub_inl(const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c, const Fp2<C>& d) {
+  constexpr int W = 2 * C::L;
+  u32 re[W], im[W], t[W], u[W];
+  mul_wide<C>(re, a.c0.v, b.c0.v);
+  mul_wide<C>(t, a.c1.v, b.c1.v);
+  {
+    const Fp<C> sa = fp_add_nr<C>(a.c0, a.c1), sb = fp_add_nr<C>(b.c0, b.c1);
+    mul_wide<C>(im, sa.v, sb.v);
+  }
+  w_sub<W>(im, im, re);
+  w_sub<W>(im, im, t);                 // a0 b1 + a1 b0                     in [0, 2 p^2)
+  w_add<W>(re, re, C::P2W3);
+  w_sub<W>(re, re, t);                 // a0 b0 - a1 b1 + 3 p^2             in (2 p^2, 4 p^2)
+  mul_wide<C>(t, c.c0.v, d.c0.v);
+  w_sub<W>(re, re, t);
+  mul_wide<C>(u, c.c1.v, d.c1.v);
+  w_add<W>(re, re, u);                 // ... - c0 d0 + c1 d1               in (p^2, 5 p^2)
+  w_add<W>(t, t, u);                   // c0 d0 + c1 d1
+  {
+    const Fp<C> sc = fp_add_nr<C>(c.c0, c.c1), sd = fp_add_nr<C>(d.c0, d.c1);
+    mul_wide<C>(u, sc.v, sd.v);
+  }
+  w_sub<W>(u, u, t);                   // c0 d1 + c1 d0                     in [0, 2 p^2)
+  w_add<W>(im, im, C::P2W3);
+  w_sub<W>(im, im, u);                 // imaginary part + 3 p^2            in (p^2, 5 p^2)
+  Fp2<C> r;
+  r.c0 = redc_k<C, 2>(re);
+  r.c1 = redc_k<C, 2>(im);
+  return r;
+}
+// g^2 - 3 e^2, same idea (bias 6 p^2, values below 8 p^2 < 2 p 2^(32L))
+template <class C>
+BGLS_HD Fp2<C> f2_sqrsub3_inl(const Fp2<C>& g, const Fp2<C>& e) {
+  constexpr int W = 2 * C::L;
+  u32 re[W], im[W], t[W], t3[W];
+  {
+    const Fp<C> s = fp_add_nr<C>(g.c0, g.c1), d = fp_sub<C>(g.c0, g.c1);
+    mul_wide<C>(re, s.v, d.v);         // g0^2 - g1^2 (as (g0+g1)(g0-g1))   in [0, 2 p^2)
+  }
+  mul_wide<C>(im, g.c0.v, g.c1.v);
+  w_add<W>(im, im, im);                // 2 g0 g1                           in [0, 2 p^2)
+  {
+    const Fp<C> s = fp_add_nr<C>(e.c0, e.c1), d = fp_sub<C>(e.c0, e.c1);
+    mul_wide<C>(t, s.v, d.v);
+  }
+  w_add<W>(t3, t, t);
+  w_add<W>(t3, t3, t);                 // 3 (e0^2 - e1^2)                   in [0, 6 p^2)
+  w_add<W>(re, re, C::P2W6);
+  w_sub<W>(re, re, t3);
+  mul_wide<C>(t, e.c0.v, e.c1.v);
+  w_add<W>(t3, t, t);
+  w_add<W>(t3, t3, t3);
+  w_add<W>(t3, t3, t);
+  w_add<W>(t3, t3, t);                 // 6 e0 e1                           in [0, 6 p^2)
+  w_add<W>(im, im, C::P2W6);
+  w_sub<W>(im, im, t3);
+  Fp2<C> r;
+  r.c0 = redc_k<C, 2>(re);
+  r.c1 = redc_k<C, 2>(im);
+  return r;
+}
+
 template <class C>
 BGLS_FN Fp2<C> f2_mul(const Fp2<C>& a, const Fp2<C>& b) {
   return f2_mul_inl<C>(a, b);
