@@ -161,6 +161,80 @@ def cpu_baseline(cid, inst, lib):
                       % (cnt, cores, min(cnt, 4096) / dt_shared)}
 
 
+def _num(x, digits=4):
+    """numbers only, short: floats to `digits` significant figures"""
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def collective_info(cid, world):
+    """what the N > 1 exchange is: one all-gather of GT partials + status words per step"""
+    info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 4), "op": "all_gather"}
+    try:
+        info["backend"] = dist.get_backend()
+        info["world"] = dist.get_world_size()
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        pass
+    return info
+
+
+def compact_line(full):
+    """The ONE line the driver parses (kept under 4 KB: numbers and short strings only).  `roofline.frac` is the
+    exclusive figure -- algorithmic MACs of one launch of the dominant kernel / its HIP-event duration with one
+    verification in flight, the number `rocprofv3 --kernel-trace --stats` reproduces; `frac_timed_region` is the
+    conservative reading over the overlapped timed region (every other stage's time included)."""
+    def roof(r):
+        if not r:
+            return None
+        ex = r.get("exclusive") or {}
+        out = {"bound": r.get("bound"), "kernel": ex.get("kernel", r.get("kernel")), "unit": r.get("unit"), "peak": _num(r.get("peak")),
+               "achieved": _num(ex.get("achieved", r.get("achieved"))), "frac": _num(ex.get("frac", r.get("frac"))),
+               "launch_ms": _num(ex.get("launch_ms", r.get("launch_ms"))), "traffic": r.get("traffic")}
+        if ex:
+            out["frac_timed_region"] = _num(r.get("frac"))
+            out["kernel_timed_region"] = r.get("kernel")
+        hb = r.get("hbm_side")
+        if hb:
+            out["hbm_gbps"] = _num(hb.get("achieved"))
+        return out
+
+    def cpu(c):
+        if not c:
+            return None
+        return {k: _num(c.get(k)) for k in ("value", "unit", "cores", "kind", "per_core_ms_per_pairing") if k in c} | {"sample": str(c.get("sample", ""))[:120]}
+
+    cfg = full.get("config", {})
+    line = {"metric": full.get("metric"), "value": _num(full.get("value"), 6), "unit": full.get("unit"), "n_gpus": full.get("n_gpus"),
+            "steps": full.get("steps"), "warmup": full.get("warmup"), "ms_per_step": _num(full.get("ms_per_step"), 6),
+            "higher_is_better": True, "scaling": full.get("scaling", "strong"), "vs_baseline": None, "dtype": full.get("dtype"), "data": full.get("data"),
+            "config": {"workload": "%s VerifyAggregateSignature, one %s-signer batch, keys+msgs resident in HBM" % (cfg.get("curve"), cfg.get("signers")),
+                       "curve": cfg.get("curve"), "signers": cfg.get("signers"), "signers_per_gpu": cfg.get("signers_per_gpu"), "in_flight": cfg.get("in_flight")},
+            "roofline": roof(full.get("roofline")), "cpu_baseline": cpu(full.get("cpu_baseline"))}
+    if "collective" in full:
+        line["collective"] = full["collective"]
+    recs = {}
+    for k, r in (full.get("records") or {}).items():
+        if not r:
+            continue
+        rf = r.get("roofline") or {}
+        ex = rf.get("exclusive") or {}
+        recs[k] = {"value": _num(r.get("value"), 5), "ms_per_step": _num(r.get("ms_per_step"), 5), "frac": _num(ex.get("frac", rf.get("frac")))}
+        if r.get("cpu_baseline"):
+            recs[k]["cpu"] = _num(r["cpu_baseline"].get("value"))
+    line["records"] = recs
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= 4096:                    # never let the line outgrow the driver's tail: drop the secondary map first
+        line["records"] = {k: {"value": v["value"]} for k, v in recs.items()}
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= 4096:
+        line["records"] = {"dropped": len(recs)}
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
 class Lanes:
     """L verifications in flight on L library contexts / streams: every step is still one complete pass (duplicate scan,
     hash, Miller, reduce, exchange when N > 1, final exponentiation, verdict checked), but the serial latency-bound stages
@@ -376,6 +450,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         rec["roofline"]["note"] = ("prepared path: no point steps inside the timed region; achieved = (pairs + 1) x %d Fp multiplications (per pair: 88 / 69 lines x "
                                    "(2 Fp2 products on 6 lanes + 4 scalings) + the shared squarings) x %d MAC / launch_ms" % (PREPARED_FPMUL[cid], MAC_PER_FPMUL[cid]))
         rec["prepared_upload_ms"] = upload_s * 1e3
+        rec["roofline"].pop("whole_path_frac", None)      # the whole-path work model counts point steps this path does not execute
     if h2d_elapsed is not None:
         rec["with_message_h2d"] = {"value": n_total * steps / h2d_elapsed, "ms_per_step": h2d_elapsed / steps * 1e3,
                                    "note": "the same steps with the %d MiB of messages copied from pinned host memory inside every step "
@@ -630,10 +705,19 @@ def main():
     elif world == 1 and not args.no_cpu_baseline and args.only is None:
         head["cpu_baseline"] = cpu_baseline(cid, inst, lib)
     if rank == 0:
-        out = dict(head)
-        out.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None})
-        out["records"] = records
-        print(json.dumps(out), flush=True)
+        full = dict(head)
+        full.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None})
+        full["records"] = records
+        if world > 1:
+            full["collective"] = collective_info(cid, world)
+        # full per-record detail: an EARLIER stdout line and a file; the LAST line is the compact record the driver parses
+        try:
+            with open(os.path.join(ROOT, "bench_records.json"), "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError:
+            pass
+        print("DETAIL " + json.dumps(full), flush=True)
+        print(compact_line(full), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,64 @@
+"""bench.py's LAST stdout line must stay a compact JSON record (< 4 KB) carrying the headline, `roofline` and
+`cpu_baseline`: round 2's line outgrew the driver's tail and its record did not parse."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _canned_record(bench, name, prose=4000):
+    note = "x" * prose            # the full records carry long prose notes: none of it may reach the last line
+    return {"metric": "aggregate-verify signer-pairs/sec", "value": 14234567.891, "unit": "signer-pairs/s", "ms_per_step": 73.66612345, "ms_per_step_min": 72.1,
+            "ms_per_step_all": [72.1, 73.7, 74.9], "steps": 20, "warmup": 5, "repetitions": 3, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": note, "curve": name, "signers": 1 << 20, "signers_per_gpu": 1 << 20, "in_flight": 4, "parallelism": note},
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_miller_s60<BN254>", "peak": 33.251234, "unit": "TMAC/s", "achieved": 15.9, "frac": 0.4781234,
+                         "launch_ms": 4.6, "launches_per_step": 16, "macs_per_launch": 7.35e10, "traffic": 104857600, "traffic_detail": {"note": note},
+                         "exclusive": {"kernel": "k_miller_ab64<BN254>", "launch_ms": 5.788, "achieved": 12.7, "frac": 0.3912345, "note": note},
+                         "hbm_side": {"achieved": 2.7, "peak": 8000.0, "unit": "GB/s", "note": note}, "whole_path_frac": 0.52, "note": note},
+            "sequential": {"ms_per_step_median": 91.0, "note": note}, "stage_ms_per_step": {"miller": 70.0}, "stage_ms_exclusive": {"miller": 84.0},
+            "cpu_baseline": {"value": 8912.3, "unit": "signer-pairs/s", "cores": 64, "kind": "port", "per_core_ms_per_pairing": 2.61, "sample": note}}
+
+
+def test_last_line_is_compact_and_complete():
+    bench = _bench()
+    full = _canned_record(bench, "altbn128")
+    full.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None})
+    full["records"] = {k: _canned_record(bench, "bls12") for k in
+                       ("bls12_1048576", "altbn128_65536", "bls12_65536", "altbn128_1048576_prepared_keys", "bls12_1048576_prepared_keys",
+                        "altbn128_multisig_1048576", "altbn128_multisig_batch_64x16384", "altbn128_64")}
+    full["collective"] = {"backend": "nccl", "world": 8, "rccl_version": "2.22.3", "bytes_per_step": 8 * 580, "op": "all_gather"}
+    line = bench.compact_line(full)
+    assert len(line) < 4096, len(line)
+    assert "\n" not in line
+    rec = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "records"):
+        assert key in rec, key
+    assert rec["config"]["curve"] == "altbn128" and rec["config"]["signers"] == 1 << 20
+    roof = rec["roofline"]
+    # frac = the exclusive, rocprof-reproducible figure; the timed-region reading is labelled
+    assert roof["kernel"] == "k_miller_ab64<BN254>" and abs(roof["frac"] - 0.3912) < 1e-3
+    assert abs(roof["frac_timed_region"] - 0.4781) < 1e-3 and roof["kernel_timed_region"] == "k_miller_s60<BN254>"
+    assert set(roof) >= {"bound", "kernel", "peak", "achieved", "frac", "launch_ms", "traffic", "unit"}
+    assert rec["cpu_baseline"]["cores"] == 64 and rec["cpu_baseline"]["kind"] == "port" and len(rec["cpu_baseline"]["sample"]) <= 120
+    assert len(rec["records"]) == 8
+    for r in rec["records"].values():
+        assert set(r) <= {"value", "ms_per_step", "frac", "cpu"}
+
+
+def test_line_shrinks_rather_than_overflowing():
+    bench = _bench()
+    full = _canned_record(bench, "altbn128")
+    full["records"] = {"record_with_a_long_name_%03d" % i: _canned_record(bench, "bls12", 10) for i in range(120)}
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and json.loads(line)["value"] > 0
+    full["records"] = {"r%d" % i: _canned_record(bench, "bls12", 10) for i in range(40)}
+    assert len(bench.compact_line(full)) < 4096
