@@ -1,0 +1,320 @@
+// k_miller_x60: the fused Miller-loop kernel on carry-free 28-bit limbs, both curves (rx.hpp, rx_pair.hpp).
+//
+// Block = 3 waves, 60 pairings, 168 registers per lane (three waves per SIMD, four blocks per CU):
+//   two PRODUCER waves  30 pairings each, one pairing per LANE PAIR (rx_pair.hpp): parse the key, walk the G2 point steps,
+//                       scale the line by the hash point and hand its three Fp2 coefficients over through LDS
+//   one CONSUMER wave   10 groups x 6 lanes; a group shares ONE Fp12 accumulator among its six pairings
+//                       (f <- f^2 l_1 ... l_6, coop.hpp); lane j owns coefficient j of  f = sum e_j w^j
+// Per line step:   producers: point step (lines stay in registers) | barrier A | store lines | barrier B
+//                  consumer:  barrier A | f <- f^2 (doubling steps)  | barrier B | fold six lines
+// so the producers' step s+1 overlaps the consumer's folds of step s, and the squaring overlaps the stores; one line
+// buffer instead of two (38.6 KB of LDS per block: four blocks per CU).
+//
+// What the 32-bit kernels (k_miller_ab64 / k_miller_s60) lose and this one does not: three VALU instructions per multiplier
+// instruction (carry add, re-zeroed addend) -- here every dot product is bare v_mad_u64_u32 into 64-bit columns; a producer
+// lane holding a whole G2 point plus three piles (256 registers, 150-650 spilled) -- here half a point and one pile.
+//
+// Work per pairing in units of NL^2 multiplier instructions (NL = 10 / 14): producer 2 x (28 per doubling, 39 per
+// addition step), consumer 66 per line + 108 / 6 per squaring.  Same line coefficients and the same product order as the
+// other kernels: the partial products are bit-identical to k_miller_ab64's.
+//
+// Replaces the n calls of CurveSystem.Pair behind PairingProduct: curves/curve.go:125-170, curves/altbn128.go:130-145,
+// curves/bls12_381.go:228-240.
+#pragma once
+#include "dev_common.hpp"
+#include "coop.hpp"
+#include "rx_pair.hpp"
+
+namespace bgls {
+
+template <class C>
+struct MX {
+  static constexpr int NL = C::RX_NL;
+  static constexpr int HS = (NL + 3) & ~3;            // dwords per half (16-byte aligned): 12 / 16
+  static constexpr int ES = 2 * HS;                   // per Fp2 entry
+  static constexpr int RB = 0;                        // [6][2] entries: coefficient k -> {e_k, xi e_k}
+  static constexpr int RL = 12 * ES;                  // [6 lines][3] entries
+  static constexpr int GROUP_DW = 30 * ES + 4;        // +4: the ten groups start on different banks
+  static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
+  static constexpr int NPARK = (C::CURVE_ID == 0 ? 8 : 4) + 3;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP + the step's three line coefficients  (NL dwords each)
+  static constexpr size_t park_bytes(size_t nblocks) { return nblocks * NPARK * NL * 128 * 4; }
+};
+
+template <class C>
+__device__ __forceinline__ Ux<C> mx_ld_half(int off) {
+  extern __shared__ u32 lds[];
+  constexpr int N = C::RX_NL;
+  Ux<C> r;
+  const uint4* p = reinterpret_cast<const uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    const uint4 v = p[k];
+    r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y; r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w;
+  }
+  if constexpr (N % 4 == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(lds + off + (N & ~3));
+    r.v[N - 2] = v.x; r.v[N - 1] = v.y;
+  }
+  return r;
+}
+template <class C>
+__device__ __forceinline__ void mx_st_half(int off, const Ux<C>& a) {
+  extern __shared__ u32 lds[];
+  constexpr int N = C::RX_NL;
+  uint4* p = reinterpret_cast<uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) p[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
+  if constexpr (N % 4 == 2) *reinterpret_cast<uint2*>(lds + off + (N & ~3)) = make_uint2(a.v[N - 2], a.v[N - 1]);
+}
+
+// ---- consumer pieces (one output coefficient per lane)
+template <class C>
+__device__ __forceinline__ void mx_publish(int rbo, int j, const Ux2<C>& v, bool live) {
+  typedef MX<C> K;
+  if (live) {
+    mx_st_half<C>(rbo + (2 * j) * K::ES, v.c0);
+    mx_st_half<C>(rbo + (2 * j) * K::ES + K::HS, v.c1);
+    const Ux2<C> x = ux_mulxi<C>(v);
+    mx_st_half<C>(rbo + (2 * j + 1) * K::ES, x.c0);
+    mx_st_half<C>(rbo + (2 * j + 1) * K::ES + K::HS, x.c1);
+  }
+  wave_sync();
+}
+// f <- f * line_m:  c_j = sum_t L[3m + t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
+template <class C>
+__device__ __forceinline__ Ux2<C> mx_fold(int rlo, int rbo, int m, int j) {
+  typedef MX<C> K;
+  const int* sh = C::TWIST_D ? COOP_SH_D : COOP_SH_M;
+  return ux_dot_k2p<C, 3>(
+      [&](int t, int h) { return mx_ld_half<C>(rlo + (3 * m + t) * K::ES + h * K::HS); },
+      [&](int t, int h) {
+        int k = j - sh[t];
+        const int wrap = k < 0 ? 1 : 0;
+        k += 6 * wrap;
+        return mx_ld_half<C>(rbo + (2 * k + wrap) * K::ES + h * K::HS);
+      });
+}
+// f <- f^2 with the symmetric terms merged (COOP_SQ_TAB)
+template <class C>
+__device__ __forceinline__ Ux2<C> mx_sqr(int rbo, int j) {
+  typedef MX<C> K;
+  const unsigned row = COOP_SQ_TAB[j];
+  // table entry per slot: bits 0-2 = i (7 = unused), bits 3-5 = k, bit 6 = wrap (xi copy), bit 7 = doubled
+  return ux_sqr_dot<C>(
+      [&](int t) {
+        const unsigned e = (row >> (8 * t)) & 0xFFu;
+        return (e & 7u) == 7u ? 0 : (((e >> 7) & 1u) ? 2 : 1);
+      },
+      [&](int t, int h) {
+        const unsigned e = (row >> (8 * t)) & 0xFFu;
+        const int i = (e & 7u) == 7u ? 0 : (int)(e & 7u);
+        return mx_ld_half<C>(rbo + (2 * i) * K::ES + h * K::HS);
+      },
+      [&](int t, int h) {
+        const unsigned e = (row >> (8 * t)) & 0xFFu;
+        const int k2 = (e & 7u) == 7u ? 0 : 2 * (int)((e >> 3) & 7u) + (int)((e >> 6) & 1u);
+        return mx_ld_half<C>(rbo + k2 * K::ES + h * K::HS);
+      });
+}
+
+template <class C>
+struct MxPark {
+  static constexpr int NL = C::RX_NL;
+  static __device__ __forceinline__ void st(u32* base, int slot, const Sx<C, SX_T>& a) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) base[(size_t)(slot * NL + k) * 128] = (u32)a.v[k];
+  }
+  static __device__ __forceinline__ Sx<C, SX_T> ld(const u32* base, int slot) {
+    Sx<C, SX_T> r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.v[k] = (i32)base[(size_t)(slot * NL + k) * 128];
+    return r;
+  }
+  static __device__ __forceinline__ void st_u(u32* base, int slot, const Ux<C>& a) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) base[(size_t)(slot * NL + k) * 128] = a.v[k];
+  }
+  static __device__ __forceinline__ Ux<C> ld_u(const u32* base, int slot) {
+    Ux<C> r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.v[k] = base[(size_t)(slot * NL + k) * 128];
+    return r;
+  }
+  static __device__ __forceinline__ const u32* launder(const u32* p) {       // opaque to the optimiser: no hoisting out of the step loop
+    asm volatile("" : "+v"(p));
+    return p;
+  }
+};
+
+// rot_mode: how the three roles are dealt to the three waves of a block (the hardware places wave w of a block on some
+// SIMD; rotating the roles from block to block keeps each SIMD's mix of producers and consumers even)
+template <class C>
+__global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
+                                                        int rot_mode) {
+  typedef MX<C> K;
+  constexpr int NL = C::RX_NL;
+  const int w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int rot = rot_mode == 0 ? 0 : (rot_mode == 1 ? (int)(blockIdx.x % 3u) : (int)((blockIdx.x >> 3) % 3u));
+  int role = w + rot;
+  if (role >= 3) role -= 3;
+  if (role < 2) {
+    // ---------------------------------------------------------------- producer: 30 pairings, one per lane pair
+    const int q = lane >> 1;
+    const bool odd = lane & 1;
+    const bool owner = q < 30;
+    const int pi = role * 30 + (owner ? q : 0);
+    const size_t idx = (size_t)blockIdx.x * 60 + pi;
+    const int tg = pi / 6, m = pi % 6;
+    u32* const mypark = park + (size_t)blockIdx.x * K::NPARK * NL * 128 + (role * 64 + lane);
+    constexpr int P_NYP = K::NPARK - 5, P_XP = K::NPARK - 4, P_LINE = K::NPARK - 3;
+    bool valid = owner && idx < n;
+    PointX<C> T;
+    {
+      Aff<F2<C>> Q;
+      Aff<F1<C>> P;
+      if (valid) {
+        bool ok = g2_from_bytes<C>(Q, g2s + idx * 4 * C::FP_BYTES);
+        ok = ok && aff_on_curve<F2<C>>(Q);
+        if (!ok) atomicOr(flags, FLAG_ENC);
+        P = g1s[idx];
+        valid = !P.inf && !Q.inf;
+      }
+      if (!valid) {
+        Q.x = f2_load<C>(C::G2);
+        Q.y = f2_load<C>(C::G2 + 2 * C::L);
+        P.x = fp_load<C>(C::G1X);
+        P.y = fp_load<C>(C::G1Y);
+      }
+      const Sx<C, SX_T> xq = ux_to_sx<C>(to_ux<C>(odd ? Q.x.c1 : Q.x.c0));
+      const Sx<C, SX_T> yq = ux_to_sx<C>(to_ux<C>(odd ? Q.y.c1 : Q.y.c0));
+      MxPark<C>::st(mypark, 0, xq);
+      MxPark<C>::st(mypark, 1, yq);
+      if constexpr (C::CURVE_ID == 0) {
+        // Q1 = pi(Q), -Q2 = -pi^2(Q) on the twist (pairing.hpp miller_loop)
+        const Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
+        const Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+        const Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
+        const Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+        MxPark<C>::st(mypark, 2, ux_to_sx<C>(to_ux<C>(odd ? x1.c1 : x1.c0)));
+        MxPark<C>::st(mypark, 3, ux_to_sx<C>(to_ux<C>(odd ? y1.c1 : y1.c0)));
+        MxPark<C>::st(mypark, 4, ux_to_sx<C>(to_ux<C>(odd ? x2.c1 : x2.c0)));
+        MxPark<C>::st(mypark, 5, ux_to_sx<C>(to_ux<C>(odd ? y2.c1 : y2.c0)));
+      }
+      MxPark<C>::st(mypark, P_NYP, ux_to_sx<C>(to_ux<C>(fp_neg<C>(P.y))));
+      MxPark<C>::st(mypark, P_XP, ux_to_sx<C>(to_ux<C>(P.x)));
+      T.X = xq;
+      T.Y = yq;
+      T.Z = sx_select<C>(odd, ux_to_sx<C>(ux_zero<C>()), sx_const<C>(C::RX_ONE));
+    }
+    const int rl_off = tg * K::GROUP_DW + K::RL + (3 * m) * K::ES + (odd ? K::HS : 0);
+    // The three line coefficients of a step are parked in the lane's workspace as they appear (they are ready long before
+    // the hand-over and would hold 3 NL registers through the rest of the step) and fetched back before barrier A.
+    auto emit = [&](int which, const auto& v) __attribute__((always_inline)) {
+      const int entry = which == 1 ? 1 : ((which == 0) == C::TWIST_D ? 0 : 2);     // D-type: c0 yP, c1 xP, c2;  M-type: c2, c1 xP, c0 yP
+      MxPark<C>::st_u(mypark, P_LINE + entry, sx_to_ux<C>(v));
+    };
+    auto hand_over = [&]() __attribute__((always_inline)) {
+      Ux<C> e[3];
+      {
+        const u32* pk = MxPark<C>::launder(mypark);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[k] = MxPark<C>::ld_u(pk, P_LINE + k);
+      }
+      if (!valid) {                       // the constant line 1
+        e[0] = odd ? ux_zero<C>() : ux_load<C>(C::RX_ONE);
+        e[1] = ux_zero<C>();
+        e[2] = ux_zero<C>();
+      }
+      __syncthreads();                    // A: the consumer has finished with the previous lines
+      if (owner) {
+        mx_st_half<C>(rl_off, e[0]);
+        mx_st_half<C>(rl_off + K::ES, e[1]);
+        mx_st_half<C>(rl_off + 2 * K::ES, e[2]);
+      }
+      __syncthreads();                    // B: lines visible
+    };
+    struct Env {
+      const u32* pk;
+      int xs, ys;
+      bool neg_y;
+      __device__ __forceinline__ Sx<C, SX_T> nyP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 5); }
+      __device__ __forceinline__ Sx<C, SX_T> xP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 4); }
+      __device__ __forceinline__ Sx<C, SX_T> xq() const { return MxPark<C>::ld(MxPark<C>::launder(pk), xs); }
+      __device__ __forceinline__ Sx<C, SX_T> yq() const {
+        const Sx<C, SX_T> y = MxPark<C>::ld(MxPark<C>::launder(pk), ys);
+        return sx_select<C>(neg_y, sx_neg<C>(y), y);
+      }
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      dbl_step_x<C>(T, Env{mypark, 0, 1, false}, odd, emit);
+      hand_over();
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        add_step_x<C>(T, Env{mypark, 0, 1, d < 0}, odd, emit);
+        hand_over();
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+#pragma unroll 1
+      for (int s = 0; s < 2; ++s) {
+        add_step_x<C>(T, Env{mypark, 2 + 2 * s, 3 + 2 * s, false}, odd, emit);
+        hand_over();
+      }
+    }
+  } else {
+    // ---------------------------------------------------------------- consumer: 10 groups x 6 lanes
+    const bool live = lane < 60;
+    const int g = live ? lane / 6 : 9;
+    const int j = live ? lane % 6 : lane - 60;
+    const int gb = g * K::GROUP_DW;
+    const int rbo = gb + K::RB, rlo = gb + K::RL;
+    Ux2<C> fj;
+    {
+      const Ux<C> one = ux_load<C>(C::RX_ONE);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { fj.c0.v[k] = j == 0 ? one.v[k] : 0u; fj.c1.v[k] = 0u; }
+    }
+    mx_publish<C>(rbo, j, fj, live);
+    auto fold6 = [&]() __attribute__((always_inline)) {
+#pragma unroll 1
+      for (int m = 0; m < 6; ++m) {
+        fj = mx_fold<C>(rlo, rbo, m, j);
+        mx_publish<C>(rbo, j, fj, live);
+      }
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      __syncthreads();                    // A
+      if (i > 1) {                        // f = 1 before the first step
+        fj = mx_sqr<C>(rbo, j);
+        mx_publish<C>(rbo, j, fj, live);
+      }
+      __syncthreads();                    // B
+      fold6();
+      if (C::LOOP_NAF[i] != 0) {
+        __syncthreads();
+        __syncthreads();
+        fold6();
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+#pragma unroll 1
+      for (int s = 0; s < 2; ++s) {
+        __syncthreads();
+        __syncthreads();
+        fold6();
+      }
+    }
+    if (live) {
+      Fp2<C> r = from_ux<C>(fj);
+      if constexpr (C::CURVE_ID != 0) {
+        if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w
+      }
+      out[((size_t)blockIdx.x * 10 + g) * 6 + j] = r;
+    }
+  }
+}
+
+}  // namespace bgls

@@ -1,0 +1,574 @@
+// Carry-free 28-bit-limb field arithmetic for both curves: NL limbs of 28 bits in 32-bit registers, Montgomery radix
+// R' = 2^(28 NL)  (alt-bn128: NL = 10, 26 spare bits above p;  BLS12-381: NL = 14, 11 spare bits).
+//
+// Why: with 32-bit limbs (fp.hpp) every limb product drags a carry add and a re-zeroed addend along -- three VALU
+// instructions per multiplier instruction, and the multiplier (v_mad_u64_u32, a quarter-rate instruction) is the resource
+// that bounds this path.  With 28-bit limbs all limb products of a whole dot product go straight into 64-bit column
+// accumulators (d = a * b + d, nothing else), 2^8 of head-room per column; carries are resolved once per reduction.  The
+// Miller kernel built on this header (miller_x.hpp) runs BOTH roles of the loop on it:
+//
+//   Ux / Ux2   unsigned, "tight" (limbs 0..NL-2 below 2^28, small non-negative top limb): the form values have in LDS and
+//              the form the consumer's dot products work on.  Differences are formed with a column bias (a multiple of p).
+//   Sx<LB>     signed limbs with a compile-time magnitude bound LB (units of 2^24; tight = 16): the producer's point
+//              steps.  Additions and subtractions are limb-wise and free of carries; every product checks at compile time
+//              that its column sums stay inside the signed 64-bit budget (Pile<B>).
+//
+// The reference has no field arithmetic (it imports bn256/cloudflare and dis2/bls12: curves/altbn128.go:11,
+// curves/bls12_381.go:11); results here are the same field elements as fp.hpp's, in another radix.
+//
+// The header compiles for the host as well (tests/harness): with BGLS_RX_CHECK every column accumulation is checked for
+// overflow there, which is how the worst-case operands of the unit tests prove the bounds.
+#pragma once
+#include "tower.hpp"
+
+namespace bgls {
+
+typedef int32_t i32;
+typedef int64_t i64;
+constexpr u32 RX_MASK = (1u << 28) - 1;
+
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(BGLS_RX_CHECK)
+extern int g_rx_overflow;
+#define RX_HOST_CHECK 1
+#else
+#define RX_HOST_CHECK 0
+#endif
+
+// d <- a * b + d.  On the device this is ONE v_mad_u64_u32 / v_mad_i64_i32 accumulating in place, written as inline
+// assembly: left to itself the compiler renames the loop-carried column accumulators (out-of-place multiply-adds plus a
+// v_mov_b64 per column and iteration) and schedules every operand load of a loop body up front, which costs a copy per
+// multiplier instruction and pushed the kernels hundreds of registers over their budget.  The statements are volatile, so
+// the multiplier instructions issue in program order: consecutive ones write different columns and a column is revisited
+// NL - 1 instructions later, far beyond the instruction's latency.  A row of limb products goes out as blocks of up to
+// seven instructions per asm statement (rx_row_*): the compiler separates two adjacent asm statements by an s_nop.
+BGLS_HD void rx_macu(u64& c, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+#elif RX_HOST_CHECK
+  u64 r;
+  if (__builtin_add_overflow(c, (u64)a * b, &r)) g_rx_overflow = 1;
+  c = r;
+#else
+  c = (u64)a * b + c;
+#endif
+}
+BGLS_HD void rx_macs(i64& c, i32 a, i32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+#elif RX_HOST_CHECK
+  i64 r;
+  if (__builtin_add_overflow(c, (i64)a * b, &r)) g_rx_overflow = 1;
+  c = r;
+#else
+  c = (i64)a * b + c;
+#endif
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RX_M1(OP, k, A, B) OP " %" #k ", vcc, %" #A ", %" #B ", %" #k "\n\t"
+// K accumulators c[0..K), one left factor a, K right factors b[0..K) (BC = "v": registers, "s": scalar constants)
+#define RX_ROW4(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 4, 5) RX_M1(OP, 1, 4, 6) RX_M1(OP, 2, 4, 7) RX_M1(OP, 3, 4, 8) \
+  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]) : "vcc")
+#define RX_ROW5(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 5, 6) RX_M1(OP, 1, 5, 7) RX_M1(OP, 2, 5, 8) RX_M1(OP, 3, 5, 9) RX_M1(OP, 4, 5, 10) \
+  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]) : "vcc")
+#define RX_ROW6(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 6, 7) RX_M1(OP, 1, 6, 8) RX_M1(OP, 2, 6, 9) RX_M1(OP, 3, 6, 10) RX_M1(OP, 4, 6, 11) RX_M1(OP, 5, 6, 12) \
+  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]), "+v"((c)[5]) \
+  : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]), BC((b)[5]) : "vcc")
+#define RX_ROW7(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 7, 8) RX_M1(OP, 1, 7, 9) RX_M1(OP, 2, 7, 10) RX_M1(OP, 3, 7, 11) RX_M1(OP, 4, 7, 12) RX_M1(OP, 5, 7, 13) RX_M1(OP, 6, 7, 14) \
+  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]), "+v"((c)[5]), "+v"((c)[6]) \
+  : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]), BC((b)[5]), BC((b)[6]) : "vcc")
+#define RX_ROW_DISPATCH(OP, BC, K, c, a, b)            \
+  do {                                                 \
+    if constexpr (K == 7) RX_ROW7(OP, BC, c, a, b);    \
+    else if constexpr (K == 6) RX_ROW6(OP, BC, c, a, b); \
+    else if constexpr (K == 5) RX_ROW5(OP, BC, c, a, b); \
+    else if constexpr (K == 4) RX_ROW4(OP, BC, c, a, b); \
+    else { static_assert(K >= 4 && K <= 7, "row block"); } \
+  } while (0)
+#endif
+
+// c[0..K) += a * b[0..K)   (4 <= K <= 7; CONST: the b are compile-time constants, held in scalar registers)
+template <int K, bool CONST>
+BGLS_HD void rx_rowu_blk(u64* c, u32 a, const u32* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CONST) RX_ROW_DISPATCH("v_mad_u64_u32", "s", K, c, a, b);
+  else RX_ROW_DISPATCH("v_mad_u64_u32", "v", K, c, a, b);
+#else
+  for (int j = 0; j < K; ++j) rx_macu(c[j], a, b[j]);
+#endif
+}
+template <int K, bool CONST>
+BGLS_HD void rx_rows_blk(i64* c, i32 a, const i32* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CONST) RX_ROW_DISPATCH("v_mad_i64_i32", "s", K, c, a, b);
+  else RX_ROW_DISPATCH("v_mad_i64_i32", "v", K, c, a, b);
+#else
+  for (int j = 0; j < K; ++j) rx_macs(c[j], a, b[j]);
+#endif
+}
+// c[0..K) += a * b[0..K) for any K >= 4, in blocks of at most seven
+template <int K, bool CONST>
+BGLS_HD void rx_rowu(u64* c, u32 a, const u32* b) {
+  if constexpr (K <= 7) rx_rowu_blk<K, CONST>(c, a, b);
+  else if constexpr (K <= 11) { rx_rowu_blk<K - K / 2, CONST>(c, a, b); rx_rowu_blk<K / 2, CONST>(c + (K - K / 2), a, b + (K - K / 2)); }
+  else { rx_rowu_blk<7, CONST>(c, a, b); rx_rowu<K - 7, CONST>(c + 7, a, b + 7); }
+}
+template <int K, bool CONST>
+BGLS_HD void rx_rows(i64* c, i32 a, const i32* b) {
+  if constexpr (K <= 7) rx_rows_blk<K, CONST>(c, a, b);
+  else if constexpr (K <= 11) { rx_rows_blk<K - K / 2, CONST>(c, a, b); rx_rows_blk<K / 2, CONST>(c + (K - K / 2), a, b + (K - K / 2)); }
+  else { rx_rows_blk<7, CONST>(c, a, b); rx_rows<K - 7, CONST>(c + 7, a, b + 7); }
+}
+
+// ===================================================================================================== unsigned, tight
+template <class C>
+struct Ux {
+  u32 v[C::RX_NL];
+};
+template <class C>
+struct Ux2 {
+  Ux<C> c0, c1;
+};
+
+template <class C>
+BGLS_HD Ux<C> ux_load(const u32* k) {
+  Ux<C> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = k[i];
+  return r;
+}
+template <class C>
+BGLS_HD Ux<C> ux_zero() {
+  Ux<C> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = 0;
+  return r;
+}
+
+// columns += a * b : NL^2 multiplier instructions and nothing else
+template <class C>
+BGLS_HD void ux_acc(u64 (&c)[2 * C::RX_NL], const Ux<C>& a, const Ux<C>& b) {
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) rx_rowu<C::RX_NL, false>(c + i, a.v[i], b.v);
+}
+
+// Montgomery reduction of the columns by R': returns T / R' mod p, tight, value < T / R' + p
+template <class C>
+BGLS_HD Ux<C> ux_redc(u64 (&c)[2 * C::RX_NL]) {
+  constexpr int N = C::RX_NL;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const u32 m = ((u32)c[i] * C::RX_NP) & RX_MASK;
+    rx_rowu<N, true>(c + i, m, C::RX_P);
+    c[i + 1] += c[i] >> 28;
+  }
+  Ux<C> r;
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+    r.v[k - N] = (u32)c[k] & RX_MASK;
+    c[k + 1] += c[k] >> 28;
+  }
+  r.v[N - 1] = (u32)c[2 * N - 1];
+  return r;
+}
+
+// limbs back below 2^28 (the top limb takes what is left); value unchanged.  Limbs must be non-negative.
+template <class C>
+BGLS_HD Ux<C> ux_norm(const Ux<C>& a) {
+  Ux<C> r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL - 1; ++i) {
+    const u32 t = a.v[i] + c;
+    r.v[i] = t & RX_MASK;
+    c = t >> 28;
+  }
+  r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + c;
+  return r;
+}
+
+// xi * a, normalised; a tight with value < 2 p (a reduction's output); the result is tight, non-negative and below 32 p.  alt-bn128: xi = 9 + i; BLS12-381: 1 + i.
+template <class C>
+BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
+  Ux2<C> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) {
+    r.c0.v[i] = (u32)C::XI_RE * a.c0.v[i] + (C::RX_FAT[i] - a.c1.v[i]);
+    r.c1.v[i] = (u32)C::XI_RE * a.c1.v[i] + a.c0.v[i];
+  }
+  r.c0 = ux_norm<C>(r.c0);
+  r.c1 = ux_norm<C>(r.c1);
+  return r;
+}
+
+// ---- the consumer's dot products.  Operands are fetched through functors (LDS on the device, arrays in the unit tests):
+//      lda(t, h) / ldb(t, h) return half h (0 = real, 1 = imaginary part) of the t-th left / right operand.
+//
+// c = sum_{t<NT} A_t * B_t in Fp2, NT <= 3, Karatsuba over i in TWO passes so that only two column piles are ever live:
+//   pass 1:  D = sum a0 b0,  E = sum a1 b1        ->  real part = D + BIAS - E   (BIAS: a multiple of p above every column of E)
+//   pass 2:  X = -(D + E) + sum (a0 + a1)(b0 + b1) ->  imaginary part            (wrap-around arithmetic: the column totals
+//            sum (a0 b1 + a1 b0) are non-negative because every limb is, so the 64-bit result is exact)
+// 3 NT NL^2 + 2 NL^2 multiplier instructions.  Operands tight, values < 32 p (column budget: tools/gen_constants.py).
+template <class C, int NT, class LA, class LB>
+BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
+  constexpr int N = C::RX_NL;
+  static_assert(NT >= 1 && NT <= 3, "column budget");
+  u64 d[2 * N], e[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) d[k] = e[k] = 0;
+#pragma unroll 1
+  for (int t = 0; t < NT; ++t) {
+    {
+      const Ux<C> a0 = lda(t, 0), b0 = ldb(t, 0);
+      ux_acc<C>(d, a0, b0);
+    }
+    {
+      const Ux<C> a1 = lda(t, 1), b1 = ldb(t, 1);
+      ux_acc<C>(e, a1, b1);
+    }
+  }
+  Ux2<C> r;
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) {
+    const u64 dk = d[k], ek = e[k];
+    e[k] = dk + C::RX_BIAS_D3[k] - ek;
+    d[k] = 0 - (dk + ek);
+  }
+  r.c0 = ux_redc<C>(e);
+#if RX_HOST_CHECK
+  u64 chk[2 * N];
+  for (int k = 0; k < 2 * N; ++k) chk[k] = 0;
+#endif
+#pragma unroll 1
+  for (int t = 0; t < NT; ++t) {
+    Ux<C> sa, sb;
+    {
+      const Ux<C> a0 = lda(t, 0), a1 = lda(t, 1);
+#pragma unroll
+      for (int q = 0; q < N; ++q) sa.v[q] = a0.v[q] + a1.v[q];
+    }
+    {
+      const Ux<C> b0 = ldb(t, 0), b1 = ldb(t, 1);
+#pragma unroll
+      for (int q = 0; q < N; ++q) sb.v[q] = b0.v[q] + b1.v[q];
+    }
+#if RX_HOST_CHECK
+    ux_acc<C>(chk, sa, sb);             // the true (non-negative) pile is checked; the wrap-around sum below cannot be
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) d[i + j] += (u64)sa.v[i] * sb.v[j];
+#else
+    ux_acc<C>(d, sa, sb);
+#endif
+  }
+  r.c1 = ux_redc<C>(d);
+  return r;
+}
+
+// c = sum over up to four slots of A_t * B_t with doubled slots (the symmetric squaring of coop.hpp: at most six
+// term-equivalents per lane), schoolbook over i: the Karatsuba pile would leave the 64-bit budget on NL = 14.
+//   kind(t) = 0 (unused slot), 1 (plain) or 2 (doubled);  lda / ldb as above (halves are fetched one pair at a time so that
+//   two piles and two halves are all that is live)
+template <class C, class KD, class LA, class LB>
+BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
+  constexpr int N = C::RX_NL;
+  u64 d[2 * N], e[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) d[k] = e[k] = 0;
+  auto scaled = [&](int t, int h) __attribute__((always_inline)) {       // left operand: doubled or masked out
+    const int kd = kind(t);
+    const u32 keep = kd ? 0xFFFFFFFFu : 0u;
+    const u32 sh = kd == 2 ? 1u : 0u;
+    Ux<C> a = lda(t, h);
+#pragma unroll
+    for (int q = 0; q < N; ++q) a.v[q] = (a.v[q] << sh) & keep;
+    return a;
+  };
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    {
+      const Ux<C> a0 = scaled(t, 0), b0 = ldb(t, 0);
+      ux_acc<C>(d, a0, b0);
+    }
+    {
+      const Ux<C> a1 = scaled(t, 1), b1 = ldb(t, 1);
+      ux_acc<C>(e, a1, b1);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) d[k] = d[k] + C::RX_BIAS_S6[k] - e[k];
+  Ux2<C> r;
+  r.c0 = ux_redc<C>(d);
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) e[k] = 0;
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    {
+      const Ux<C> a0 = scaled(t, 0), b1 = ldb(t, 1);
+      ux_acc<C>(e, a0, b1);
+    }
+    {
+      const Ux<C> a1 = scaled(t, 1), b0 = ldb(t, 0);
+      ux_acc<C>(e, a1, b0);
+    }
+  }
+  r.c1 = ux_redc<C>(e);
+  return r;
+}
+
+// ---- conversions between the library's form (32-bit limbs, Montgomery radix R = 2^(32 L)) and this one
+// x R (reduced, 32-bit limbs) -> x R' (tight, value < 2 p): split into 28-bit limbs, one product by R'^2 / R
+template <class C>
+BGLS_HD Ux<C> to_ux(const Fp<C>& y) {
+  constexpr int N = C::RX_NL;
+  Ux<C> s;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int lo = 28 * i, q = lo >> 5, r = lo & 31;
+    u64 two = q < C::L ? (u64)y.v[q] : 0;
+    if (q + 1 < C::L) two |= (u64)y.v[q + 1] << 32;
+    s.v[i] = (u32)(two >> r) & RX_MASK;
+  }
+  u64 c[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+  ux_acc<C>(c, s, ux_load<C>(C::RX_TO));
+  return ux_redc<C>(c);
+}
+template <class C>
+BGLS_HD Ux2<C> to_ux(const Fp2<C>& a) {
+  return {to_ux<C>(a.c0), to_ux<C>(a.c1)};
+}
+// x R' (tight, value < 4 p: a reduction's output) -> x R in the library's form
+template <class C>
+BGLS_HD Fp<C> from_ux(const Ux<C>& a) {
+  constexpr int N = C::RX_NL;
+  constexpr int L = C::L;
+  u32 w[L + 1];
+#pragma unroll
+  for (int k = 0; k <= L; ++k) {
+    const int lo = 32 * k;
+    const int i = lo / 28, r = lo % 28;
+    u64 acc = 0;
+    if (i < N) acc = (u64)a.v[i] >> r;
+    int have = 28 - r;
+    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += 28; }
+    if (have < 32 && i + 2 < N) acc |= (u64)a.v[i + 2] << have;
+    w[k] = (u32)acc;
+  }
+  // subtract 2p, then p, where possible (value < 4 p < 2^(32 L + 1))
+#pragma unroll
+  for (int sh = 1; sh >= 0; --sh) {
+    u32 d[L + 1];
+    u32 bw = 0;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) {
+      const u32 pk = (k < L ? (C::P[k] << sh) : 0u) | ((sh && k >= 1) ? (C::P[k - 1] >> (32 - sh)) : 0u);
+      d[k] = subb(w[k], pk, bw);
+    }
+    const u32 keep = bw ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) w[k] = (d[k] & keep) | (w[k] & ~keep);
+  }
+  Fp<C> y;
+#pragma unroll
+  for (int k = 0; k < L; ++k) y.v[k] = w[k];
+  return fp_mul<C>(y, fp_load<C>(C::RX_BACK));
+}
+template <class C>
+BGLS_HD Fp2<C> from_ux(const Ux2<C>& a) {
+  return {from_ux<C>(a.c0), from_ux<C>(a.c1)};
+}
+
+// ===================================================================================================== signed, bounded
+// |limb i| < LB * 2^24 for i < NL-1 (tight: limbs in [0, 2^28), LB = 16); the top limb is small (|value| stays below ~64 p
+// everywhere in the point steps: R' / p > 2^11 leaves room for products of such values).
+template <class C, int LB>
+struct Sx {
+  i32 v[C::RX_NL];
+};
+constexpr int SX_T = 16;       // tight
+constexpr int SX_F = 17;       // after one parallel carry step (sx_normf)
+
+template <class C, int LA, int LB>
+BGLS_HD Sx<C, LA + LB> sx_add(const Sx<C, LA>& a, const Sx<C, LB>& b) {
+  static_assert(LA + LB < 128, "limb leaves 31 bits");
+  Sx<C, LA + LB> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <class C, int LA, int LB>
+BGLS_HD Sx<C, LA + LB> sx_sub(const Sx<C, LA>& a, const Sx<C, LB>& b) {
+  static_assert(LA + LB < 128, "limb leaves 31 bits");
+  Sx<C, LA + LB> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = a.v[i] - b.v[i];
+  return r;
+}
+template <class C, int LA>
+BGLS_HD Sx<C, LA> sx_neg(const Sx<C, LA>& a) {
+  Sx<C, LA> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = -a.v[i];
+  return r;
+}
+template <int K, class C, int LA>
+BGLS_HD Sx<C, K * LA> sx_mulc(const Sx<C, LA>& a) {
+  static_assert(K * LA < 128, "limb leaves 31 bits");
+  Sx<C, K * LA> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = K * a.v[i];
+  return r;
+}
+template <class C, int LA>
+BGLS_HD Sx<C, LA> sx_select(bool c, const Sx<C, LA>& a, const Sx<C, LA>& b) {
+  Sx<C, LA> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// widen the static bound (no code)
+template <int LB, class C, int LA>
+BGLS_HD Sx<C, LB> sx_as(const Sx<C, LA>& a) {
+  static_assert(LB >= LA, "bound can only grow");
+  Sx<C, LB> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = a.v[i];
+  return r;
+}
+// full carry propagation: limbs 0..NL-2 into [0, 2^28), the (signed) top limb takes the rest
+template <class C, int LA>
+BGLS_HD Sx<C, SX_T> sx_norm(const Sx<C, LA>& a) {
+  Sx<C, SX_T> r;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL - 1; ++i) {
+    const i32 t = a.v[i] + c;
+    r.v[i] = t & (i32)RX_MASK;
+    c = t >> 28;
+  }
+  r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + c;
+  return r;
+}
+// one parallel carry step (no dependency chain): limbs into (-2^4, 2^28 + 2^4)
+template <class C, int LA>
+BGLS_HD Sx<C, SX_F> sx_normf(const Sx<C, LA>& a) {
+  static_assert(LA < 128, "limb leaves 31 bits");
+  Sx<C, SX_F> r;
+  r.v[0] = a.v[0] & (i32)RX_MASK;
+#pragma unroll
+  for (int i = 1; i < C::RX_NL - 1; ++i) r.v[i] = (a.v[i] & (i32)RX_MASK) + (a.v[i - 1] >> 28);
+  r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + (a.v[C::RX_NL - 2] >> 28);
+  return r;
+}
+// a / 2 mod p: add p when odd (the parity of the value is the parity of limb 0), then shift every limb, the dropped bit of
+// limb i+1 entering limb i at 2^27
+template <class C, int LA>
+BGLS_HD Sx<C, (LA + 16 + 1) / 2 + 8> sx_half(const Sx<C, LA>& a) {
+  constexpr int N = C::RX_NL;
+  const i32 odd = -(a.v[0] & 1);
+  i32 t[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = a.v[i] + ((i32)C::RX_P[i] & odd);
+  Sx<C, (LA + 16 + 1) / 2 + 8> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> 1) + (i + 1 < N ? (t[i + 1] & 1) << 27 : 0);
+  return r;
+}
+
+// Interleaved Montgomery product (coarsely integrated operand scanning on carry-free columns): the running accumulator
+// is NL + 1 columns of 64 bits -- 30 registers on BLS12-381 where a full double-width pile is 56 -- and one call folds
+// up to four limb-product rows per step into it before the step's reduction row:
+//      t <- (t + sum_k a_k[i] * b_k + m p) / 2^28,   m = -t[0] / p mod 2^28,    i = 0 .. NL-1
+// Result: sum_k a_k b_k / R' mod p, tight limbs, signed top limb, value in (T / R', T / R' + p).
+// Static budget: a column collects at most NL rows of sum_k LA_k LB_k 2^48 plus NL 2^56 of the reduction's own products
+// and the carries; the total must stay below 2^63.
+template <class C, int B>
+struct MontAcc {
+  static_assert((long long)C::RX_NL * (B + 256) + 64 < 32768, "column budget (signed 64-bit)");
+};
+template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2, int LA3, int LB3>
+BGLS_HD Sx<C, SX_T> sx_mont4(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>* a1, const Sx<C, LB1>* b1, const Sx<C, LA2>* a2,
+                             const Sx<C, LB2>* b2, const Sx<C, LA3>* a3, const Sx<C, LB3>* b3) {
+  constexpr int N = C::RX_NL;
+  (void)sizeof(MontAcc<C, LA0 * LB0 + (LA1 ? LA1 * LB1 : 0) + (LA2 ? LA2 * LB2 : 0) + (LA3 ? LA3 * LB3 : 0)>);
+  i64 t[N + 1];
+#pragma unroll
+  for (int k = 0; k <= N; ++k) t[k] = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    // column 0 first: the row's Montgomery factor m depends on it and is ready by the time the row's other products are issued
+    rx_macs(t[0], a0.v[i], b0.v[0]);
+    if (a1) rx_macs(t[0], a1->v[i], b1->v[0]);
+    if (a2) rx_macs(t[0], a2->v[i], b2->v[0]);
+    if (a3) rx_macs(t[0], a3->v[i], b3->v[0]);
+    const i32 m = (i32)(((u32)t[0] * C::RX_NP) & RX_MASK);
+    rx_rows<N - 1, false>(t + 1, a0.v[i], b0.v + 1);
+    if (a1) rx_rows<N - 1, false>(t + 1, a1->v[i], b1->v + 1);
+    if (a2) rx_rows<N - 1, false>(t + 1, a2->v[i], b2->v + 1);
+    if (a3) rx_rows<N - 1, false>(t + 1, a3->v[i], b3->v + 1);
+    rx_rows<N, true>(t, m, (const i32*)C::RX_P);
+    const i64 carry = t[0] >> 28;
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = t[j + 1];
+    t[N] = 0;
+    t[0] += carry;
+  }
+  Sx<C, SX_T> r;
+#pragma unroll
+  for (int k = 0; k < N - 1; ++k) {
+    r.v[k] = (i32)((u32)t[k] & RX_MASK);
+    t[k + 1] += t[k] >> 28;
+  }
+  r.v[N - 1] = (i32)t[N - 1];
+  return r;
+}
+template <class C, int LA0, int LB0>
+BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0) {
+  return sx_mont4<C, LA0, LB0, 0, 0, 0, 0, 0, 0>(a0, b0, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr,
+                                                 (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
+}
+template <class C, int LA0, int LB0, int LA1, int LB1>
+BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1) {
+  return sx_mont4<C, LA0, LB0, LA1, LB1, 0, 0, 0, 0>(a0, b0, &a1, &b1, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr,
+                                                     (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
+}
+template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2>
+BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1, const Sx<C, LA2>& a2,
+                            const Sx<C, LB2>& b2) {
+  return sx_mont4<C, LA0, LB0, LA1, LB1, LA2, LB2, 0, 0>(a0, b0, &a1, &b1, &a2, &b2, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
+}
+template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2, int LA3, int LB3>
+BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1, const Sx<C, LA2>& a2,
+                            const Sx<C, LB2>& b2, const Sx<C, LA3>& a3, const Sx<C, LB3>& b3) {
+  return sx_mont4<C, LA0, LB0, LA1, LB1, LA2, LB2, LA3, LB3>(a0, b0, &a1, &b1, &a2, &b2, &a3, &b3);
+}
+
+// signed, bounded  ->  tight and NON-NEGATIVE (the form LDS holds): add the fat multiple of p that dominates every limb,
+// then carry.  |value| must be below K RX_FAT_VB p with K = ceil(LA / 16) (the point steps hand over reductions' outputs
+// and one difference of two: |value| < 2.2 p, K <= 2); the result is below (2 K RX_FAT_VB + 2) p + |value| <= 21 p.
+template <class C, int LA>
+BGLS_HD Ux<C> sx_to_ux(const Sx<C, LA>& a) {
+  constexpr int K = (LA + 15) / 16;
+  static_assert(K >= 1 && K <= 8, "fat constants cover limbs below 8 * 2^28");
+  Ux<C> t;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) t.v[i] = (u32)((i32)C::RX_FAT[(K - 1) * C::RX_NL + i] + a.v[i]);
+  return ux_norm<C>(t);
+}
+template <class C>
+BGLS_HD Sx<C, SX_T> ux_to_sx(const Ux<C>& a) {
+  Sx<C, SX_T> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = (i32)a.v[i];
+  return r;
+}
+template <class C>
+BGLS_HD Sx<C, SX_T> sx_const(const u32* k) {
+  Sx<C, SX_T> r;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = (i32)k[i];
+  return r;
+}
+
+}  // namespace bgls

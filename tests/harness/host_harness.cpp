@@ -1,10 +1,37 @@
 // TEST-ONLY: compiles the device arithmetic headers for the host so that every routine can be
 // diffed against the oracle in the CPU test tier (no GPU here).  Never linked into the product.
 #include <string.h>
+#include <atomic>
+#include <thread>
+#define BGLS_RX_CHECK 1
 #include "../../bgls_amd/csrc/pairing.hpp"
 #include "../../bgls_amd/csrc/h2c.hpp"
 #include "../../bgls_amd/csrc/wire.hpp"
 #include "../../bgls_amd/csrc/r28.hpp"
+#include "../../bgls_amd/csrc/rx_pair.hpp"
+
+namespace bgls { int g_rx_overflow = 0; }
+
+// ---- host emulation of a lane pair (rx_pair.hpp): two threads in lock-step, values exchanged through a rendezvous
+static std::atomic<int> g_pair_slot[2];
+static std::atomic<int> g_pair_cnt{0}, g_pair_gen{0};
+static thread_local int tl_pair_lane = 0;
+static void pair_barrier() {
+  const int gen = g_pair_gen.load();
+  if (g_pair_cnt.fetch_add(1) == 1) {
+    g_pair_cnt.store(0);
+    g_pair_gen.fetch_add(1);
+  } else {
+    while (g_pair_gen.load(std::memory_order_acquire) == gen) { }
+  }
+}
+int rx_host_pair_swap(int v) {
+  g_pair_slot[tl_pair_lane].store(v);
+  pair_barrier();
+  const int r = g_pair_slot[1 - tl_pair_lane].load();
+  pair_barrier();
+  return r;
+}
 
 using namespace bgls;
 
@@ -254,4 +281,156 @@ int ht_r28(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   }
   return -1;
 }
+}
+
+// ---- rx.hpp, consumer side, on RAW limbs (so that the unit tests can feed worst-case limb patterns): A and B hold three
+// Fp2 operands each as [t][half][NL] u32; out = [half][NL].  Returns the overflow flag of the checked column arithmetic.
+//   op 0: ux_dot_k2p<3>   op 1: ux_sqr_dot with kinds k0..k3 packed in `arg` (2 bits each; operands t = 0..3 from A / B
+//   with A, B holding FOUR operands)   op 2: ux_mulxi(A[0])   op 3: to_ux / from_ux round trip is ht_rx_conv below
+template <class C>
+static int rx_raw(int op, int arg, const u32* A, const u32* Bv, u32* out) {
+  constexpr int N = C::RX_NL;
+  g_rx_overflow = 0;
+  auto ld = [&](const u32* base, int t, int h) { Ux<C> r; for (int i = 0; i < N; ++i) r.v[i] = base[(t * 2 + h) * N + i]; return r; };
+  Ux2<C> r;
+  if (op == 0) r = ux_dot_k2p<C, 3>([&](int t, int h) { return ld(A, t, h); }, [&](int t, int h) { return ld(Bv, t, h); });
+  else if (op == 1) r = ux_sqr_dot<C>([&](int t) { return (arg >> (2 * t)) & 3; }, [&](int t, int h) { return ld(A, t, h); }, [&](int t, int h) { return ld(Bv, t, h); });
+  else if (op == 2) { Ux2<C> a = {ld(A, 0, 0), ld(A, 0, 1)}; r = ux_mulxi<C>(a); }
+  else return -1;
+  for (int i = 0; i < N; ++i) { out[i] = r.c0.v[i]; out[N + i] = r.c1.v[i]; }
+  return g_rx_overflow;
+}
+extern "C" int ht_rx_raw(int curve, int op, int arg, const u32* A, const u32* Bv, u32* out) {
+  return curve == 0 ? rx_raw<BN254>(op, arg, A, Bv, out) : rx_raw<BLS381>(op, arg, A, Bv, out);
+}
+// a (FP_BYTES big-endian, canonical) -> limbs of to_ux(a R);  and back: from_ux(limbs) -> canonical bytes
+template <class C>
+static int rx_conv(int dir, uint8_t* bytes, u32* limbs) {
+  constexpr int N = C::RX_NL;
+  g_rx_overflow = 0;
+  if (dir == 0) {
+    const Ux<C> u = to_ux<C>(fp_to_mont<C>(fp_from_be<C>(bytes)));
+    for (int i = 0; i < N; ++i) limbs[i] = u.v[i];
+  } else {
+    Ux<C> u;
+    for (int i = 0; i < N; ++i) u.v[i] = limbs[i];
+    fp_to_be<C>(bytes, fp_from_mont<C>(from_ux<C>(u)));
+  }
+  return g_rx_overflow;
+}
+extern "C" int ht_rx_conv(int curve, int dir, uint8_t* bytes, u32* limbs) {
+  return curve == 0 ? rx_conv<BN254>(dir, bytes, limbs) : rx_conv<BLS381>(dir, bytes, limbs);
+}
+
+// ---- rx_pair.hpp: the whole sequence of point steps of one Miller loop on an emulated lane pair, every line (as handed
+// to the consumer: three tight Fp2 entries, scaled by the hash point) and the final point compared with pairing.hpp's
+// dbl_step_t / add_step_t.  Returns 0 when everything matches, else 1 + the index of the first differing step; -3 on overflow.
+template <class C>
+struct RxMillerRun {
+  static constexpr int N = C::RX_NL;
+  static constexpr int MAXS = 96;
+  Ux<C> got[MAXS][3][2];       // [step][entry][half]
+  Sx<C, SX_T> fin[3][2];
+  int nsteps[2];
+  Aff<F1<C>> P;
+  Aff<F2<C>> Q;
+  struct Env {
+    Sx<C, SX_T> nyp, xp, xq_, yq_;
+    Sx<C, SX_T> nyP() const { return nyp; }
+    Sx<C, SX_T> xP() const { return xp; }
+    Sx<C, SX_T> xq() const { return xq_; }
+    Sx<C, SX_T> yq() const { return yq_; }
+  };
+  void lane(int l) {
+    tl_pair_lane = l;
+    const bool odd = l == 1;
+    auto half = [&](const Fp2<C>& v) { return ux_to_sx<C>(to_ux<C>(odd ? v.c1 : v.c0)); };
+    Env env;
+    env.nyp = ux_to_sx<C>(to_ux<C>(fp_neg<C>(P.y)));
+    env.xp = ux_to_sx<C>(to_ux<C>(P.x));
+    const Sx<C, SX_T> xq = half(Q.x), yq = half(Q.y);
+    PointX<C> T;
+    T.X = xq;
+    T.Y = yq;
+    T.Z = sx_select<C>(odd, ux_to_sx<C>(ux_zero<C>()), sx_const<C>(C::RX_ONE));
+    int s = 0;
+    auto emit = [&](int which, const auto& v) {
+      const int entry = which == 1 ? 1 : ((which == 0) == C::TWIST_D ? 0 : 2);
+      got[s][entry][l] = sx_to_ux<C>(v);
+    };
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      dbl_step_x<C>(T, env, odd, emit);
+      ++s;
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        env.xq_ = xq;
+        env.yq_ = d > 0 ? yq : sx_neg<C>(yq);
+        add_step_x<C>(T, env, odd, emit);
+        ++s;
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      const Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2)), y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
+      const Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2)), y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
+      env.xq_ = half(x1); env.yq_ = half(y1);
+      add_step_x<C>(T, env, odd, emit);
+      ++s;
+      env.xq_ = half(x2); env.yq_ = half(y2);
+      add_step_x<C>(T, env, odd, emit);
+      ++s;
+    }
+    nsteps[l] = s;
+    fin[0][l] = T.X; fin[1][l] = T.Y; fin[2][l] = T.Z;
+  }
+};
+template <class C>
+static int rx_miller_check(const uint8_t* g1, const uint8_t* g2) {
+  static RxMillerRun<C> run;
+  if (!g1_from_bytes<C>(run.P, g1) || !g2_from_bytes<C>(run.Q, g2)) return -2;
+  g_rx_overflow = 0;
+  g_pair_cnt.store(0);
+  std::thread t1([&] { run.lane(1); });
+  run.lane(0);
+  t1.join();
+  if (g_rx_overflow) return -3;
+  // reference walk
+  G2Proj<C> R = {run.Q.x, run.Q.y, f2_one<C>()};
+  int s = 0;
+  auto same = [&](const Fp2<C>& want, const Ux<C>& h0, const Ux<C>& h1) {
+    // handed-over values are lazy (up to ~21 p): a product by one brings them below 2 p, which from_ux accepts
+    const Ux<C> one = ux_load<C>(C::RX_ONE), zero = ux_zero<C>();
+    const Ux2<C> red = ux_dot_k2p<C, 1>([&](int, int h) { return h ? h1 : h0; }, [&](int, int h) { return h ? zero : one; });
+    const Fp2<C> g = {from_ux<C>(red.c0), from_ux<C>(red.c1)};
+    return f2_eq<C>(g, want);
+  };
+  auto check_line = [&](const LineCoeffs<C>& l) {
+    const Fp2<C> a = f2_muls<C>(l.c0, run.P.y), b = f2_muls<C>(l.c1, run.P.x);
+    const Fp2<C> e0 = C::TWIST_D ? a : l.c2, e2 = C::TWIST_D ? l.c2 : a;
+    const bool ok = same(e0, run.got[s][0][0], run.got[s][0][1]) && same(b, run.got[s][1][0], run.got[s][1][1]) && same(e2, run.got[s][2][0], run.got[s][2][1]);
+    // handed-over entries must be tight and non-negative
+    bool tight = true;
+    for (int e = 0; e < 3; ++e) for (int h = 0; h < 2; ++h) for (int i = 0; i + 1 < C::RX_NL; ++i) tight = tight && run.got[s][e][h].v[i] < (1u << 28);
+    ++s;
+    return ok && tight;
+  };
+  for (int i = 1; i < C::LOOP_LEN; ++i) {
+    if (!check_line(dbl_step_t<C, true>(R))) return s;
+    const int d = C::LOOP_NAF[i];
+    if (d != 0 && !check_line(add_step_t<C, true>(R, run.Q.x, d > 0 ? run.Q.y : f2_neg<C>(run.Q.y)))) return s;
+  }
+  if constexpr (C::CURVE_ID == 0) {
+    const Fp2<C> x1 = f2_mul<C>(f2_conj<C>(run.Q.x), gamma_const<C>(1, 2)), y1 = f2_mul<C>(f2_conj<C>(run.Q.y), gamma_const<C>(1, 3));
+    const Fp2<C> x2 = f2_mul<C>(run.Q.x, gamma_const<C>(2, 2)), y2 = f2_neg<C>(f2_mul<C>(run.Q.y, gamma_const<C>(2, 3)));
+    if (!check_line(add_step_t<C, true>(R, x1, y1))) return s;
+    if (!check_line(add_step_t<C, true>(R, x2, y2))) return s;
+  }
+  if (s != run.nsteps[0] || s != run.nsteps[1]) return 1000 + s;
+  // the running point itself (signed tight halves -> non-negative -> library form)
+  const Fp2<C> want[3] = {R.X, R.Y, R.Z};
+  for (int k = 0; k < 3; ++k)
+    if (!same(want[k], sx_to_ux<C>(run.fin[k][0]), sx_to_ux<C>(run.fin[k][1]))) return 2000 + k;
+  return 0;
+}
+extern "C" int ht_rx_miller(int curve, const uint8_t* g1, const uint8_t* g2) {
+  return curve == 0 ? rx_miller_check<BN254>(g1, g2) : rx_miller_check<BLS381>(g1, g2);
 }

@@ -151,6 +151,84 @@ def main():
         o += arr("R28_BACK", limbs((R * R // Rp) % p * 1 % p if (R * R) % Rp == 0 else (R * R * pow(Rp, -1, p)) % p, L))   # 32-bit Montgomery multiplier: x R' -> x R
         return o
 
+    def rx_consts(p, L, N, xi, b2x3=None):
+        """Constants of the generic carry-free 28-bit-limb representation (rx.hpp): N limbs, Montgomery radix R' = 2^(28 N).
+        alt-bn128: N = 10 (26 spare bits), BLS12-381: N = 14 (11 spare bits)."""
+        W = 28
+        Mk = (1 << W) - 1
+        lim = lambda x: [(x >> (W * i)) & Mk for i in range(N)]
+        R = 1 << (32 * L)
+        Rp = 1 << (W * N)
+        assert Rp > 4 * p
+        o = "  static constexpr int RX_NL = %d;\n" % N
+        o += arr("RX_P", lim(p))
+        o += "  static constexpr uint32_t RX_NP = 0x%xu;\n" % ((-pow(p, -1, 1 << W)) % (1 << W))
+        o += arr("RX_ONE", lim(Rp % p))
+        o += arr("RX_R2", lim(Rp * Rp % p))
+        # (x R mod p, as an integer in 28-bit limbs) * RX_TO / R' = x R'
+        o += arr("RX_TO", lim(Rp * Rp * pow(R, -1, p) % p))
+        # 32-bit Montgomery multiplier: (x R' mod p as an integer) * BACK / R = x R
+        o += arr("RX_BACK", limbs(R * R * pow(Rp, -1, p) % p, L))
+        # Fat multiples of p for limb-wise negation: FAT[k-1] has limbs 0..N-2 in [k 2^28, (k+1) 2^28) and a top limb >= TOPK * k,
+        # so FAT_k - b has non-negative limbs for every b with limbs below k 2^28 and value below k * RX_FAT_VB * p
+        top_p = p >> (W * (N - 1))
+        VB = 4
+        fats = []
+        for k in range(1, 9):
+            base = sum((k << W) << (W * i) for i in range(N - 1)) + ((k * VB * (top_p + 1) + 1) << (W * (N - 1)))
+            mult = -(-base // p)
+            d = mult * p - base
+            assert 0 <= d < p
+            assert mult <= 2 * k * VB + 2
+            f = [(k << W) + ((d >> (W * i)) & Mk) for i in range(N - 1)] + [(k * VB * (top_p + 1) + 1) + (d >> (W * (N - 1)))]
+            assert sum(v << (W * i) for i, v in enumerate(f)) == mult * p and all((k << W) <= v < ((k + 1) << W) for v in f[:-1])
+            assert f[-1] < (1 << 31)
+            fats += f
+        o += "  static constexpr int RX_FAT_VB = %d;\n" % VB
+        o += arr("RX_FAT", fats)                   # [8][N]
+        # Column biases (multiples of p) for the consumer's dot products of TIGHT non-negative operands (limbs < 2^28, value < 32 p):
+        #   RX_BIAS_D3: >= column k of sum_{t<3} a1 b1           (re = D + BIAS - E of the three-term Karatsuba fold)
+        #   RX_BIAS_S6: >= column k of six term-equivalents      (symmetric squaring: up to 3 doubled + 0 plain or 2 doubled + 2 plain)
+        la = [1 << 28] * (N - 1) + [32 * (top_p + 1)]
+        col = [0] * (2 * N)
+        for i in range(N):
+            for j in range(N):
+                col[i + j] += (la[i] - 1) * (la[j] - 1)
+        def bias_for(mult):
+            bias = []
+            for k in range(2 * N):
+                need = mult * col[k]
+                bias.append(((need >> W) + 1) << W if need else 0)      # multiple of 2^28 above the need: leaves the low digit free for the fix-up
+            Vb = sum(b << (W * k) for k, b in enumerate(bias))
+            fix = (-Vb) % p
+            for k in range(N):
+                bias[k] += (fix >> (W * k)) & Mk
+            assert fix >> (W * N) == 0 and sum(b << (W * k) for k, b in enumerate(bias)) % p == 0
+            assert all(bias[k] >= mult * col[k] for k in range(2 * N))
+            return bias
+        b3 = bias_for(3)
+        b6 = bias_for(6)
+        # 64-bit column budget: worst case of every pile the consumer forms, plus the reduction's own products and carries
+        red = [0] * (2 * N)
+        for i in range(N):
+            for j in range(N):
+                red[i + j] += Mk * Mk
+        scol = [0] * (2 * N)
+        for i in range(N):
+            for j in range(N):
+                scol[i + j] += (2 * la[i] - 2) * (2 * la[j] - 2)
+        for k in range(2 * N):
+            carry = 1 << 37
+            assert 3 * scol[k] + red[k] + carry < (1 << 64), ("S pile", k)                 # sum (a0+a1)(b0+b1), three terms
+            assert 3 * col[k] + b3[k] + red[k] + carry < (1 << 64), ("D + BIAS", k)
+            assert 6 * col[k] + b6[k] + red[k] + carry < (1 << 64), ("sqr D + BIAS", k)
+            assert 12 * col[k] + red[k] + carry < (1 << 64), ("sqr cross pile", k)          # six term-equivalents x (a0 b1 + a1 b0)
+        o += "  static constexpr uint64_t RX_BIAS_D3[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b3))
+        o += "  static constexpr uint64_t RX_BIAS_S6[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b6))
+        if b2x3 is not None:
+            o += arr("RX_B2X3_RE", lim(b2x3[0] * Rp % p)) + arr("RX_B2X3_IM", lim(b2x3[1] * Rp % p))
+        return o
+
     def bn_extra(M, limbs, L):
         g2 = [10857046999023057135944570762232829481370756359578518086990519993285655852781,
               11559732032986387107991004021392285783925812861821192530917403151452391805634,
@@ -212,9 +290,12 @@ def main():
         o += arr("R3", limbs((1 << (32 * L)) ** 3 % p_bls, L))    # to Montgomery-convert a 2L-limb value: redc(wide) * R3
         return o
 
+    f2bn = F2(p_bn)
+    b2bn = f2bn.mul((3, 0), f2bn.inv((9, 1)))
+    bn_b2x3 = (3 * b2bn[0] % p_bn, 3 * b2bn[1] % p_bn)
     txt = "// GENERATED by tools/gen_constants.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\nnamespace bgls {\n\n"
-    txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, lambda M, limbs, L: bn_extra(M, limbs, L) + r28_consts(p_bn, L))
-    txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, bls_extra)
+    txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, lambda M, limbs, L: bn_extra(M, limbs, L) + r28_consts(p_bn, L) + rx_consts(p_bn, L, 10, (9, 1), bn_b2x3))
+    txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, lambda M, limbs, L: bls_extra(M, limbs, L) + rx_consts(p_bls, L, 14, (1, 1), (12, 12)))
     txt += "}  // namespace bgls\n"
     with open(OUT, "w") as f:
         f.write(txt)
