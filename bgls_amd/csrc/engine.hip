@@ -177,7 +177,21 @@ bool throughput_mode() {
 // Miller shape (bgls_set_miller_shape): 0 = fused producer/consumer blocks (k_miller_ab64 / k_miller_s60), 1..3 = decoupled
 // k_lines + k_fold through a line table in HBM (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs with Karatsuba dot
 // products; alt-bn128 only for 2 and 3), ng = pairings folded per group and squaring.
-std::atomic<int> g_shape{0}, g_ng{6};
+// 4 = k_miller_x60 (carry-free 28-bit limbs, both curves; the second argument is then the role rotation mode 0..2).
+// BGLS_MILLER_SHAPE / BGLS_X60_ROT preset them from the environment.
+std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{0};
+int miller_shape() {
+  int v = g_shape.load();
+  if (v < 0) {
+    const char* e = getenv("BGLS_MILLER_SHAPE");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v > 4) v = 0;
+    const char* r = getenv("BGLS_X60_ROT");
+    if (r) g_x60_rot.store(atoi(r) & 15);
+    g_shape.store(v);
+  }
+  return v;
+}
 
 #ifdef BGLS_DEV
 // development builds only: BGLS_MILLER_DBG=1/2 times the producer / consumer half of the fused Miller kernels (WRONG results)
@@ -366,7 +380,7 @@ struct Engine {
     void *pa, *pb;
     Fp2<C>* red = nullptr;
     bool epilogue = cofactor;
-    if (npairs <= LAT_MAX && !cofactor && g_shape.load() == 0) {
+    if (npairs <= LAT_MAX && !cofactor && miller_shape() == 0) {
       // a handful of pairings: one block per pairing (k_miller_lat), the signature pair as one more block
       const size_t blocks = npairs + (sig ? 1 : 0);
       if ((rc = c.get(WS_F_A, (blocks + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
@@ -379,9 +393,30 @@ struct Engine {
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;
       return emit_partial(c, st, red, false, nullptr, gl, d_partial);
     }
-    if (g_shape.load() > 0 && npairs >= 1) {
+    if (miller_shape() == 4 && npairs >= 1) {
+      // k_miller_x60: 60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes
+      // to the epilogue kernel
+      const size_t nb60 = (npairs + 59) / 60, groups = nb60 * 10;
+      constexpr size_t XB = 16384;                      // blocks per launch
+      void* park;
+      if ((rc = c.get(WS_QP, kl::miller_x60_park_bytes<C>(nb60 < XB ? nb60 : XB), &park))) return rc;
+      if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
+      if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      {
+        Scope sc(c, st, ST_MILLER);
+        for (size_t blk0 = 0; blk0 < nb60; blk0 += XB) {
+          const size_t nblocks = nb60 - blk0 < XB ? nb60 - blk0 : XB;
+          const size_t p0 = blk0 * 60;
+          kl::miller_x60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, (uint32_t*)park, g_x60_rot.load());
+        }
+        HIPCHK(hipGetLastError());
+      }
+      if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, groups, &red))) return rc;
+      return emit_partial(c, st, red, cofactor || sig != nullptr, sig, gl, d_partial);
+    }
+    if (miller_shape() > 0 && npairs >= 1) {
       // decoupled: line table in HBM, then folds; batches above 2^16 pairings go chunk by chunk through one table
-      int variant = g_shape.load() - 1;
+      int variant = miller_shape() - 1;
       if (C::CURVE_ID != 0 && variant > 0) variant = 0;
       const int ng = g_ng.load();
       const size_t chunk = (size_t)1 << 18;
@@ -2057,7 +2092,13 @@ int bgls_set_throughput_mode(int on) {
 }
 
 int bgls_set_miller_shape(int shape, int pairings_per_group) {
-  if (shape < 0 || shape > 3 || pairings_per_group < 1 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
+  if (shape < 0 || shape > 4 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
+  if (shape == 4) {                       // k_miller_x60: the second argument selects the role rotation (0..2)
+    g_x60_rot.store(pairings_per_group & 15);
+    g_shape.store(shape);
+    return 0;
+  }
+  if (pairings_per_group < 1) return fail(BGLS_ERR_ARG, "bad Miller shape");
   g_shape.store(shape);
   g_ng.store(pairings_per_group);
   return 0;

@@ -37,7 +37,7 @@ struct MX {
   static constexpr int GROUP_DW = 30 * ES + 4;        // +4: the ten groups start on different banks
   static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
   static constexpr int NPARK = (C::CURVE_ID == 0 ? 8 : 4) + 3;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP + the step's three line coefficients  (NL dwords each)
-  static constexpr size_t park_bytes(size_t nblocks) { return nblocks * NPARK * NL * 128 * 4; }
+  static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * HS * 4; }
 };
 
 template <class C>
@@ -117,27 +117,50 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int rbo, int j) {
       });
 }
 
+// A producer lane's parked values: its own region of the workspace, NPARK slots of HS dwords (16-byte aligned), moved with
+// 16-byte accesses off ONE address register.  (A lane-interleaved layout coalesces better but needs a separate 64-bit
+// address per limb -- the element stride exceeds the instructions' immediate offsets -- and those addresses cost more
+// registers than the values they fetch.)
 template <class C>
 struct MxPark {
   static constexpr int NL = C::RX_NL;
-  static __device__ __forceinline__ void st(u32* base, int slot, const Sx<C, SX_T>& a) {
+  static constexpr int HS = MX<C>::HS;
+  static __device__ __forceinline__ void st_raw(u32* lane_base, int slot, const u32 (&v)[NL]) {
+    uint4* p = reinterpret_cast<uint4*>(lane_base + slot * HS);
 #pragma unroll
-    for (int k = 0; k < NL; ++k) base[(size_t)(slot * NL + k) * 128] = (u32)a.v[k];
+    for (int k = 0; k < NL / 4; ++k) p[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    if constexpr (NL % 4 == 2) *reinterpret_cast<uint2*>(lane_base + slot * HS + (NL & ~3)) = make_uint2(v[NL - 2], v[NL - 1]);
+  }
+  static __device__ __forceinline__ void ld_raw(const u32* lane_base, int slot, u32 (&v)[NL]) {
+    const uint4* p = reinterpret_cast<const uint4*>(lane_base + slot * HS);
+#pragma unroll
+    for (int k = 0; k < NL / 4; ++k) {
+      const uint4 q = p[k];
+      v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+    if constexpr (NL % 4 == 2) {
+      const uint2 q = *reinterpret_cast<const uint2*>(lane_base + slot * HS + (NL & ~3));
+      v[NL - 2] = q.x; v[NL - 1] = q.y;
+    }
+  }
+  static __device__ __forceinline__ void st(u32* base, int slot, const Sx<C, SX_T>& a) {
+    u32 w[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) w[k] = (u32)a.v[k];
+    st_raw(base, slot, w);
   }
   static __device__ __forceinline__ Sx<C, SX_T> ld(const u32* base, int slot) {
+    u32 w[NL];
+    ld_raw(base, slot, w);
     Sx<C, SX_T> r;
 #pragma unroll
-    for (int k = 0; k < NL; ++k) r.v[k] = (i32)base[(size_t)(slot * NL + k) * 128];
+    for (int k = 0; k < NL; ++k) r.v[k] = (i32)w[k];
     return r;
   }
-  static __device__ __forceinline__ void st_u(u32* base, int slot, const Ux<C>& a) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) base[(size_t)(slot * NL + k) * 128] = a.v[k];
-  }
+  static __device__ __forceinline__ void st_u(u32* base, int slot, const Ux<C>& a) { st_raw(base, slot, a.v); }
   static __device__ __forceinline__ Ux<C> ld_u(const u32* base, int slot) {
     Ux<C> r;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) r.v[k] = base[(size_t)(slot * NL + k) * 128];
+    ld_raw(base, slot, r.v);
     return r;
   }
   static __device__ __forceinline__ const u32* launder(const u32* p) {       // opaque to the optimiser: no hoisting out of the step loop
@@ -148,25 +171,29 @@ struct MxPark {
 
 // rot_mode: how the three roles are dealt to the three waves of a block (the hardware places wave w of a block on some
 // SIMD; rotating the roles from block to block keeps each SIMD's mix of producers and consumers even)
-template <class C>
+// DBG (development tools only, never instantiated in the library): 1 = producer work only, 2 = consumer work only -- wrong
+// results, used to time the two roles separately.
+template <class C, int DBG = 0>
 __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
                                                         int rot_mode) {
   typedef MX<C> K;
   constexpr int NL = C::RX_NL;
   const int w = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int rot = rot_mode == 0 ? 0 : (rot_mode == 1 ? (int)(blockIdx.x % 3u) : (int)((blockIdx.x >> 3) % 3u));
+  const int rmode = rot_mode & 3;
+  const int rot = rmode == 0 ? 0 : (rmode == 1 ? (int)(blockIdx.x % 3u) : (int)((blockIdx.x >> 3) % 3u));
   int role = w + rot;
   if (role >= 3) role -= 3;
   if (role < 2) {
     // ---------------------------------------------------------------- producer: 30 pairings, one per lane pair
+    if (rot_mode & 8) __builtin_amdgcn_s_setprio(3);
     const int q = lane >> 1;
     const bool odd = lane & 1;
     const bool owner = q < 30;
     const int pi = role * 30 + (owner ? q : 0);
     const size_t idx = (size_t)blockIdx.x * 60 + pi;
     const int tg = pi / 6, m = pi % 6;
-    u32* const mypark = park + (size_t)blockIdx.x * K::NPARK * NL * 128 + (role * 64 + lane);
+    u32* const mypark = park + ((size_t)blockIdx.x * 128 + (role * 64 + lane)) * (K::NPARK * K::HS);
     constexpr int P_NYP = K::NPARK - 5, P_XP = K::NPARK - 4, P_LINE = K::NPARK - 3;
     bool valid = owner && idx < n;
     PointX<C> T;
@@ -248,23 +275,24 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      dbl_step_x<C>(T, Env{mypark, 0, 1, false}, odd, emit);
+      if constexpr (DBG != 2) dbl_step_x<C>(T, Env{mypark, 0, 1, false}, odd, emit);
       hand_over();
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        add_step_x<C>(T, Env{mypark, 0, 1, d < 0}, odd, emit);
+        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 0, 1, d < 0}, odd, emit);
         hand_over();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
 #pragma unroll 1
       for (int s = 0; s < 2; ++s) {
-        add_step_x<C>(T, Env{mypark, 2 + 2 * s, 3 + 2 * s, false}, odd, emit);
+        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 2 + 2 * s, 3 + 2 * s, false}, odd, emit);
         hand_over();
       }
     }
   } else {
     // ---------------------------------------------------------------- consumer: 10 groups x 6 lanes
+    if (rot_mode & 4) __builtin_amdgcn_s_setprio(3);       // the consumer is the long pole of a block's step: let it issue first
     const bool live = lane < 60;
     const int g = live ? lane / 6 : 9;
     const int j = live ? lane % 6 : lane - 60;
@@ -278,6 +306,7 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
     }
     mx_publish<C>(rbo, j, fj, live);
     auto fold6 = [&]() __attribute__((always_inline)) {
+      if constexpr (DBG == 1) return;
 #pragma unroll 1
       for (int m = 0; m < 6; ++m) {
         fj = mx_fold<C>(rlo, rbo, m, j);
@@ -287,7 +316,7 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();                    // A
-      if (i > 1) {                        // f = 1 before the first step
+      if (DBG != 1 && i > 1) {            // f = 1 before the first step
         fj = mx_sqr<C>(rbo, j);
         mx_publish<C>(rbo, j, fj, live);
       }

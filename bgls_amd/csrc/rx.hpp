@@ -487,26 +487,28 @@ template <class C, int B>
 struct MontAcc {
   static_assert((long long)C::RX_NL * (B + 256) + 64 < 32768, "column budget (signed 64-bit)");
 };
-template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2, int LA3, int LB3>
-BGLS_HD Sx<C, SX_T> sx_mont4(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>* a1, const Sx<C, LB1>* b1, const Sx<C, LA2>* a2,
-                             const Sx<C, LB2>* b2, const Sx<C, LA3>* a3, const Sx<C, LB3>* b3) {
+// NP products (1..4).  cols[k] = the limbs of product k's COLUMN factor (register-resident); row(k, i) = limb i of its ROW
+// factor, produced where it is used -- the point steps derive it from a neighbour lane's register, so a row factor never
+// occupies NL registers.  BUDGET = sum over the products of (column bound) * (row bound), units 2^48.
+template <class C, int NP, int BUDGET, class Row>
+BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
   constexpr int N = C::RX_NL;
-  (void)sizeof(MontAcc<C, LA0 * LB0 + (LA1 ? LA1 * LB1 : 0) + (LA2 ? LA2 * LB2 : 0) + (LA3 ? LA3 * LB3 : 0)>);
+  static_assert(NP >= 1 && NP <= 4, "products per reduction");
+  (void)sizeof(MontAcc<C, BUDGET>);
   i64 t[N + 1];
 #pragma unroll
   for (int k = 0; k <= N; ++k) t[k] = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
+    i32 r[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) r[k] = row(k, i);
     // column 0 first: the row's Montgomery factor m depends on it and is ready by the time the row's other products are issued
-    rx_macs(t[0], a0.v[i], b0.v[0]);
-    if (a1) rx_macs(t[0], a1->v[i], b1->v[0]);
-    if (a2) rx_macs(t[0], a2->v[i], b2->v[0]);
-    if (a3) rx_macs(t[0], a3->v[i], b3->v[0]);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rx_macs(t[0], r[k], cols[k][0]);
     const i32 m = (i32)(((u32)t[0] * C::RX_NP) & RX_MASK);
-    rx_rows<N - 1, false>(t + 1, a0.v[i], b0.v + 1);
-    if (a1) rx_rows<N - 1, false>(t + 1, a1->v[i], b1->v + 1);
-    if (a2) rx_rows<N - 1, false>(t + 1, a2->v[i], b2->v + 1);
-    if (a3) rx_rows<N - 1, false>(t + 1, a3->v[i], b3->v + 1);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rx_rows<N - 1, false>(t + 1, r[k], cols[k] + 1);
     rx_rows<N, true>(t, m, (const i32*)C::RX_P);
     const i64 carry = t[0] >> 28;
 #pragma unroll
@@ -522,26 +524,6 @@ BGLS_HD Sx<C, SX_T> sx_mont4(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const S
   }
   r.v[N - 1] = (i32)t[N - 1];
   return r;
-}
-template <class C, int LA0, int LB0>
-BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0) {
-  return sx_mont4<C, LA0, LB0, 0, 0, 0, 0, 0, 0>(a0, b0, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr,
-                                                 (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
-}
-template <class C, int LA0, int LB0, int LA1, int LB1>
-BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1) {
-  return sx_mont4<C, LA0, LB0, LA1, LB1, 0, 0, 0, 0>(a0, b0, &a1, &b1, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr,
-                                                     (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
-}
-template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2>
-BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1, const Sx<C, LA2>& a2,
-                            const Sx<C, LB2>& b2) {
-  return sx_mont4<C, LA0, LB0, LA1, LB1, LA2, LB2, 0, 0>(a0, b0, &a1, &b1, &a2, &b2, (const Sx<C, 0>*)nullptr, (const Sx<C, 0>*)nullptr);
-}
-template <class C, int LA0, int LB0, int LA1, int LB1, int LA2, int LB2, int LA3, int LB3>
-BGLS_HD Sx<C, SX_T> sx_mont(const Sx<C, LA0>& a0, const Sx<C, LB0>& b0, const Sx<C, LA1>& a1, const Sx<C, LB1>& b1, const Sx<C, LA2>& a2,
-                            const Sx<C, LB2>& b2, const Sx<C, LA3>& a3, const Sx<C, LB3>& b3) {
-  return sx_mont4<C, LA0, LB0, LA1, LB1, LA2, LB2, LA3, LB3>(a0, b0, &a1, &b1, &a2, &b2, &a3, &b3);
 }
 
 // signed, bounded  ->  tight and NON-NEGATIVE (the form LDS holds): add the fat multiple of p that dominates every limb,

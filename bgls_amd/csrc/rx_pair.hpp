@@ -2,8 +2,8 @@
 //
 // One pairing's running point T = (X, Y, Z) over Fp2 is spread over two neighbouring lanes: the even lane holds the real
 // parts, the odd lane the imaginary parts.  An Fp2 product a b = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) i then costs each lane
-// two limb-product piles and ONE reduction (the partner's halves arrive through DPP quad permutes, 2 NL v_mov_dpp per
-// product against 3 NL^2 multiplier instructions), a squaring one pile and one reduction.  Compared with a whole point
+// two limb products and ONE reduction, interleaved row by row over NL + 1 columns (the partner's halves arrive through DPP
+// quad permutes, 3 NL v_mov_dpp per product against 3 NL^2 multiplier instructions), a squaring one product and one reduction.  Compared with a whole point
 // step on one lane this halves the live state (3 NL registers of T per lane instead of 6 NL, one pile instead of three) --
 // the point-step wave of the 32-bit kernels spilled 150-650 registers -- and halves the latency of a step.
 //
@@ -23,7 +23,7 @@ int rx_host_pair_swap(int v);
 
 namespace bgls {
 
-// the partner lane's value (lanes 2k <-> 2k+1)
+// values from the lanes of the own pair (lanes 2k, 2k+1): the partner's, the even lane's, the odd lane's
 RX_DEV i32 pair_swap1(i32 v) {
 #if defined(__HIPCC__)
   return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
@@ -31,71 +31,90 @@ RX_DEV i32 pair_swap1(i32 v) {
   return rx_host_pair_swap(v);
 #endif
 }
+RX_DEV i32 pair_even1(i32 v, bool odd) {
+#if defined(__HIPCC__)
+  (void)odd;
+  return __builtin_amdgcn_update_dpp(0, v, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
+#else
+  const i32 o = rx_host_pair_swap(v);
+  return odd ? o : v;
+#endif
+}
+RX_DEV i32 pair_odd1(i32 v, bool odd) {
+#if defined(__HIPCC__)
+  (void)odd;
+  return __builtin_amdgcn_update_dpp(0, v, 0xF5 /* quad_perm [1,1,3,3] */, 0xF, 0xF, true);
+#else
+  const i32 o = rx_host_pair_swap(v);
+  return odd ? v : o;
+#endif
+}
+// the partner's half, negated on the even lane: the "- a1 b1" of the real part is then a plain product
 template <class C, int LA>
-RX_DEV Sx<C, LA> pair_swap(const Sx<C, LA>& a) {
+RX_DEV Sx<C, LA> pair_swap_neg_even(const Sx<C, LA>& a, bool odd) {
+  const i32 sgn = odd ? 0 : -1;
   Sx<C, LA> r;
 #pragma unroll
-  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = pair_swap1(a.v[i]);
+  for (int i = 0; i < C::RX_NL; ++i) r.v[i] = (pair_swap1(a.v[i]) ^ sgn) - sgn;
   return r;
 }
 
-// own half of a * b
+// own half of a * b:   even lane  a0 b0 - a1 b1,   odd lane  a1 b0 + a0 b1.
+// Column factors: the own half of a and the partner's (sign-adjusted); row factors: limb i of b's even-lane half and of its
+// odd-lane half, fetched per row by quad permutes -- no select, and b's neighbour half never occupies NL registers.
 template <class C, int LA, int LB>
 RX_DEV Sx<C, SX_T> pair_mul(const Sx<C, LA>& a, const Sx<C, LB>& b, bool odd) {
-  const Sx<C, LA> pa = pair_swap<C>(a);
-  const Sx<C, LB> pb = pair_swap<C>(b);
-  const Sx<C, LB> p = sx_select<C>(odd, pb, b);
-  const Sx<C, LB> q = sx_select<C>(odd, b, sx_neg<C>(pb));
-  return sx_mont<C>(a, p, pa, q);
+  const Sx<C, LA> pa = pair_swap_neg_even<C>(a, odd);
+  const i32* const cols[2] = {a.v, pa.v};
+  return sx_montr<C, 2, 2 * LA * LB>(cols, [&](int k, int i) { return k == 0 ? pair_even1(b.v[i], odd) : pair_odd1(b.v[i], odd); });
 }
-// own half of a * k for a constant k = (k_re, k_im) known to every lane
+// own half of a * k for a constant k = (k_re, k_im) known to every lane:  a0 kr - a1 ki  |  a1 kr + a0 ki
 template <class C, int LA>
 RX_DEV Sx<C, SX_T> pair_mul_const(const Sx<C, LA>& a, const u32* k_re, const u32* k_im, bool odd) {
-  const Sx<C, LA> pa = pair_swap<C>(a);
-  const Sx<C, SX_T> kr = sx_const<C>(k_re), ki = sx_const<C>(k_im);
-  // even: a0 kr - a1 ki      odd: a1 kr + a0 ki
-  const Sx<C, SX_T> q = sx_select<C>(odd, ki, sx_neg<C>(ki));
-  return sx_mont<C>(a, kr, pa, q);
+  const Sx<C, LA> pa = pair_swap_neg_even<C>(a, odd);
+  const i32* const cols[2] = {a.v, pa.v};
+  return sx_montr<C, 2, 2 * LA * SX_T>(cols, [&](int k, int i) { return (i32)(k == 0 ? k_re[i] : k_im[i]); });
 }
-// own half of a^2:  (a0 + a1)(a0 - a1)  |  2 a0 a1
+// own half of a^2:  (a0 + a1)(a0 - a1)  |  2 a1 a0
 template <class C, int LA>
 RX_DEV Sx<C, SX_T> pair_sqr(const Sx<C, LA>& a, bool odd) {
-  const Sx<C, LA> pa = pair_swap<C>(a);
-  const Sx<C, 2 * LA> u = sx_add<C>(a, sx_select<C>(odd, a, pa));
-  const Sx<C, 2 * LA> p = sx_select<C>(odd, sx_as<2 * LA, C>(pa), sx_sub<C>(a, pa));
-  return sx_mont<C>(u, p);
+  Sx<C, 2 * LA> u;                                            // a0 + a1 | 2 a1
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) u.v[i] = a.v[i] + pair_odd1(a.v[i], odd);
+  const i32 even = odd ? 0 : -1;
+  const i32* const cols[1] = {u.v};
+  return sx_montr<C, 1, 4 * LA * LA>(cols, [&](int, int i) { return pair_even1(a.v[i], odd) - (pair_odd1(a.v[i], odd) & even); });   // a0 - a1 | a0
 }
 // own half of a * s, s in Fp (the same value on both lanes)
 template <class C, int LA, int LS>
 RX_DEV Sx<C, SX_T> pair_muls(const Sx<C, LA>& a, const Sx<C, LS>& s) {
-  return sx_mont<C>(a, s);
+  const i32* const cols[1] = {s.v};
+  return sx_montr<C, 1, LA * LS>(cols, [&](int, int i) { return a.v[i]; });
 }
 // own half of a b - c d, one reduction
 template <class C, int LA, int LB, int LC, int LD>
 RX_DEV Sx<C, SX_T> pair_mulsub(const Sx<C, LA>& a, const Sx<C, LB>& b, const Sx<C, LC>& c, const Sx<C, LD>& d, bool odd) {
-  const Sx<C, LA> pa = pair_swap<C>(a);
-  const Sx<C, LB> pb = pair_swap<C>(b);
-  const Sx<C, LC> pc = pair_swap<C>(c);
-  const Sx<C, LD> pd = pair_swap<C>(d);
-  // minus (c d): the same two products with the left factors negated
-  return sx_mont<C>(a, sx_select<C>(odd, pb, b), pa, sx_select<C>(odd, b, sx_neg<C>(pb)), sx_neg<C>(c), sx_select<C>(odd, pd, d), sx_neg<C>(pc),
-                    sx_select<C>(odd, d, sx_neg<C>(pd)));
+  const Sx<C, LA> pa = pair_swap_neg_even<C>(a, odd);
+  const Sx<C, LC> nc = sx_neg<C>(c);
+  const Sx<C, LC> npc = sx_neg<C>(pair_swap_neg_even<C>(c, odd));
+  const i32* const cols[4] = {a.v, pa.v, nc.v, npc.v};
+  return sx_montr<C, 4, 2 * LA * LB + 2 * LC * LD>(cols, [&](int k, int i) {
+    return k == 0 ? pair_even1(b.v[i], odd) : (k == 1 ? pair_odd1(b.v[i], odd) : (k == 2 ? pair_even1(d.v[i], odd) : pair_odd1(d.v[i], odd)));
+  });
 }
 // own half of g^2 - e f, one reduction
 template <class C, int LG, int LE, int LF>
 RX_DEV Sx<C, SX_T> pair_sqrsub(const Sx<C, LG>& g, const Sx<C, LE>& e, const Sx<C, LF>& f, bool odd) {
-  const Sx<C, LG> pg = pair_swap<C>(g);
-  const Sx<C, 2 * LG> u = sx_add<C>(g, sx_select<C>(odd, g, pg));
-  const Sx<C, 2 * LG> p = sx_select<C>(odd, sx_as<2 * LG, C>(pg), sx_sub<C>(g, pg));
-  const Sx<C, LE> pe = pair_swap<C>(e);
-  const Sx<C, LF> pf = pair_swap<C>(f);
-  return sx_mont<C>(u, p, sx_neg<C>(e), sx_select<C>(odd, pf, f), sx_neg<C>(pe), sx_select<C>(odd, f, sx_neg<C>(pf)));
-}
-// own half of xi * a  (alt-bn128: 9 + i, BLS12-381: 1 + i):  XI_RE a0 - a1  |  XI_RE a1 + a0
-template <class C, int LA>
-RX_DEV Sx<C, (C::XI_RE + 1) * LA> pair_mulxi(const Sx<C, LA>& a, bool odd) {
-  const Sx<C, LA> pa = pair_swap<C>(a);
-  return sx_add<C>(sx_mulc<C::XI_RE, C>(a), sx_select<C>(odd, pa, sx_neg<C>(pa)));
+  Sx<C, 2 * LG> u;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
+  const i32 even = odd ? 0 : -1;
+  const Sx<C, LE> ne = sx_neg<C>(e);
+  const Sx<C, LE> npe = sx_neg<C>(pair_swap_neg_even<C>(e, odd));
+  const i32* const cols[3] = {u.v, ne.v, npe.v};
+  return sx_montr<C, 3, 4 * LG * LG + 2 * LE * LF>(cols, [&](int k, int i) {
+    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? pair_even1(f.v[i], odd) : pair_odd1(f.v[i], odd));
+  });
 }
 // 3 b' z of the doubling step: a product by the constant on both curves.  (BLS12-381's 3 b' = 12 (1 + i) could be formed with
 // additions, as pairing.hpp does, but the VALUE would grow to 25 p and the P-free line coefficient E - B must reach the
