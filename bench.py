@@ -54,7 +54,7 @@ ORDER = {0: 21888242871839275222246405745257275088548364400416034343698204186575
          1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
 CURVE = {"altbn128": 0, "bls12": 1}
 CNAME = {0: "altbn128", 1: "bls12"}
-LAUNCH_PAIRS = 1 << 16                                 # pairings per Miller launch (engine.hip: 1024 blocks of 64)
+LAUNCH_PAIRS = 32768 * 60                              # pairings per Miller launch (engine.hip: up to 32768 blocks of 60, k_miller_x60)
 
 
 def B(b):
@@ -120,13 +120,14 @@ def pinned_peak(lib):
 
 
 def traffic_for(kernel_key):
-    """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r2): a
+    """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r3, r2): a
     builder-held constant of the evidence run, not measured in this process (labelled as such)."""
-    path = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
-    if os.path.exists(path):
-        det = json.load(open(path))
-        if kernel_key in det:
-            return det[kernel_key].get("bytes_per_launch_fetch_x2"), dict(det[kernel_key], source="profiles/r2/pmc_traffic.json (evidence run, not this process)")
+    for rnd in ("r3", "r2"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if os.path.exists(path):
+            det = json.load(open(path))
+            if kernel_key in det:
+                return det[kernel_key].get("bytes_per_launch_fetch_x2"), dict(det[kernel_key], source="profiles/%s/pmc_traffic.json (evidence run, not this process)" % rnd)
     return None, None
 
 
@@ -362,10 +363,10 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         seq.append((time.perf_counter() - t0) * 1e3)
     sync()
     stages_excl = {s: stage(lib, s) for s in ("dup_check", "h2c", "miller", "reduce", "final_exp")}
-    use_tp = pipelined and cid == 0 and throughput and not prepared
+    use_tp = pipelined and throughput and not prepared
     if use_tp:
-        # launches overlap from here on: alt-bn128 Miller launches may take the shape that is fastest in that regime
-        # (bgls_set_throughput_mode: 60 pairings per block, see k_miller_s60); verdicts are identical in both modes
+        # launches overlap from here on: tell the engine (bgls_set_throughput_mode), which then takes k_miller_x60 also for
+        # batches whose last round of blocks is nearly empty -- the neighbours fill it; verdicts are identical in both modes
         check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
     if pipelined:
         lanes.run(L, lambda k: submit(k), True)
@@ -403,6 +404,8 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     value = n_total / med
     launches_per_step = 1 if prepared else (n + LAUNCH_PAIRS - 1) // LAUNCH_PAIRS
     pairs_per_launch = n if prepared else min(n, LAUNCH_PAIRS)
+    if not prepared and 61440 < n <= 65536:
+        launches_per_step, pairs_per_launch = 1, n
     macs_per_launch = (pairs_per_launch + 1) * (PREPARED_FPMUL if prepared else MILLER_FPMUL)[cid] * MAC_PER_FPMUL[cid]
     ex_ms, ex_cnt = stages_excl["miller"]
     excl_launch_s = ex_ms / max(ex_cnt, 1) / launches_per_step * 1e-3         # HIP events around the Miller stage, one verification in flight
@@ -411,9 +414,11 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     # (every other stage's time included -- the conservative reading); the exclusive figure is the kernel by itself.
     shared_launch_s = med / launches_per_step
     cname = "BN254" if cid == 0 else "BLS381"
-    forced_tp = cid == 0 and os.environ.get("BGLS_THROUGHPUT") == "1"      # profiling runs: the 60-pairing shape from the first call on
-    kernel_excl = "k_miller_s60<BN254>" if forced_tp else "k_miller_ab64<%s>" % cname
-    kernel_timed = "k_miller_s60<BN254>" if (use_tp or forced_tp) else kernel_excl
+    # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 unless a lone launch of
+    # 61 441 .. 65 536 pairings (one at a time), which takes k_miller_ab64
+    legacy_alone = 61440 < n <= 65536
+    kernel_excl = "k_miller_ab64<%s>" % cname if legacy_alone else "k_miller_x60<%s>" % cname
+    kernel_timed = "k_miller_x60<%s>" % cname if (use_tp or not legacy_alone) else kernel_excl
     if prepared:
         kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])

@@ -177,15 +177,16 @@ bool throughput_mode() {
 // Miller shape (bgls_set_miller_shape): 0 = fused producer/consumer blocks (k_miller_ab64 / k_miller_s60), 1..3 = decoupled
 // k_lines + k_fold through a line table in HBM (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs with Karatsuba dot
 // products; alt-bn128 only for 2 and 3), ng = pairings folded per group and squaring.
-// 4 = k_miller_x60 (carry-free 28-bit limbs, both curves; the second argument is then the role rotation mode 0..2).
+// 0 also means "automatic": k_miller_x60 (carry-free 28-bit limbs, both curves) wherever it wins, see Engine::miller.
+// 4 = k_miller_x60 always (the second argument is then its role / priority mode), 5 = the 32-bit fused kernels always.
 // BGLS_MILLER_SHAPE / BGLS_X60_ROT preset them from the environment.
-std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{0};
+std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{8};
 int miller_shape() {
   int v = g_shape.load();
   if (v < 0) {
     const char* e = getenv("BGLS_MILLER_SHAPE");
     v = e ? atoi(e) : 0;
-    if (v < 0 || v > 4) v = 0;
+    if (v < 0 || v > 5) v = 0;
     const char* r = getenv("BGLS_X60_ROT");
     if (r) g_x60_rot.store(atoi(r) & 15);
     g_shape.store(v);
@@ -393,11 +394,15 @@ struct Engine {
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;
       return emit_partial(c, st, red, false, nullptr, gl, d_partial);
     }
-    if (miller_shape() == 4 && npairs >= 1) {
-      // k_miller_x60: 60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes
-      // to the epilogue kernel
+    // k_miller_x60 (60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes to
+    // the epilogue kernel) is the default above the latency shape.  One exception: 1024 blocks are resident at a time, and a
+    // lone launch of slightly more (61 441 .. 65 536 pairings, e.g. exactly 2^16) would pay a second, nearly empty round
+    // of blocks, where k_miller_ab64's 1024 blocks of 64 pairings need one -- unless launches overlap (throughput mode),
+    // when the neighbours fill that round.
+    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX && (throughput_mode() || npairs <= 61440 || npairs > 65536);
+    if ((miller_shape() == 4 || x60_auto) && npairs >= 1) {
       const size_t nb60 = (npairs + 59) / 60, groups = nb60 * 10;
-      constexpr size_t XB = 16384;                      // blocks per launch
+      constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take 57 / 68 KB per block)
       void* park;
       if ((rc = c.get(WS_QP, kl::miller_x60_park_bytes<C>(nb60 < XB ? nb60 : XB), &park))) return rc;
       if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
@@ -414,7 +419,7 @@ struct Engine {
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, groups, &red))) return rc;
       return emit_partial(c, st, red, cofactor || sig != nullptr, sig, gl, d_partial);
     }
-    if (miller_shape() > 0 && npairs >= 1) {
+    if (miller_shape() > 0 && miller_shape() < 4 && npairs >= 1) {
       // decoupled: line table in HBM, then folds; batches above 2^16 pairings go chunk by chunk through one table
       int variant = miller_shape() - 1;
       if (C::CURVE_ID != 0 && variant > 0) variant = 0;
@@ -2092,9 +2097,9 @@ int bgls_set_throughput_mode(int on) {
 }
 
 int bgls_set_miller_shape(int shape, int pairings_per_group) {
-  if (shape < 0 || shape > 4 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
-  if (shape == 4) {                       // k_miller_x60: the second argument selects the role rotation (0..2)
-    g_x60_rot.store(pairings_per_group & 15);
+  if (shape < 0 || shape > 5 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
+  if (shape >= 4) {                       // 4: k_miller_x60 always (second argument: role / priority mode); 5: the 32-bit fused kernels always
+    if (shape == 4) g_x60_rot.store(pairings_per_group & 15);
     g_shape.store(shape);
     return 0;
   }

@@ -27,14 +27,15 @@
 
 namespace bgls {
 
-template <class C>
+template <class C, int NC = 1>
 struct MX {
   static constexpr int NL = C::RX_NL;
   static constexpr int HS = (NL + 3) & ~3;            // dwords per half (16-byte aligned): 12 / 16
   static constexpr int ES = 2 * HS;                   // per Fp2 entry
-  static constexpr int RB = 0;                        // [6][2] entries: coefficient k -> {e_k, xi e_k}
-  static constexpr int RL = 12 * ES;                  // [6 lines][3] entries
-  static constexpr int GROUP_DW = 30 * ES + 4;        // +4: the ten groups start on different banks
+  static constexpr int RB = 0;                        // [NC][6][2] entries: coefficient k -> {e_k, xi e_k}, one set per consumer wave
+  static constexpr int RL = NC * 12 * ES;             // [6 lines][3] entries
+  static constexpr int GROUP_DW = (NC * 12 + 18) * ES + 4;   // +4: the ten groups start on different banks
+  static constexpr int THREADS = 64 * (2 + NC);
   static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
   static constexpr int NPARK = (C::CURVE_ID == 0 ? 8 : 4) + 3;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP + the step's three line coefficients  (NL dwords each)
   static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * HS * 4; }
@@ -85,7 +86,7 @@ template <class C>
 __device__ __forceinline__ Ux2<C> mx_fold(int rlo, int rbo, int m, int j) {
   typedef MX<C> K;
   const int* sh = C::TWIST_D ? COOP_SH_D : COOP_SH_M;
-  return ux_dot_k2p<C, 3>(
+  return ux_dot_k2p<C, 3, (C::RX_NL <= 10)>(
       [&](int t, int h) { return mx_ld_half<C>(rlo + (3 * m + t) * K::ES + h * K::HS); },
       [&](int t, int h) {
         int k = j - sh[t];
@@ -173,17 +174,44 @@ struct MxPark {
 // SIMD; rotating the roles from block to block keeps each SIMD's mix of producers and consumers even)
 // DBG (development tools only, never instantiated in the library): 1 = producer work only, 2 = consumer work only -- wrong
 // results, used to time the two roles separately.
-template <class C, int DBG = 0>
-__global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
-                                                        int rot_mode) {
-  typedef MX<C> K;
+// NC = consumer waves per block (1 or 2).  With two, each folds three of a group's six lines into its OWN accumulator (the
+// block hands out 20 partial products instead of 10; the squaring is done twice): 158 instead of 140 units of work per step and
+// 60 pairings, but the block's critical path -- one consumer's squaring and folds -- drops from 84 to 51 units, and a SIMD sees
+// two busy waves instead of one and a half.
+template <class C, int DBG = 0, int NC = 1>
+__global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
+                                                                int rot_mode) {
+  typedef MX<C, NC> K;
+  static_assert(NC == 1 || NC == 2, "consumer waves");
   constexpr int NL = C::RX_NL;
   const int w = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
+  // Which wave consumes?  The hardware puts the three waves of a block on three of the CU's four SIMDs, and a full CU holds
+  // four blocks (168 registers: three waves per SIMD), so every SIMD is the one "missing" from exactly one block.  Taking
+  // the consumer on SIMD (missing + 1) mod 4 therefore gives every SIMD exactly one consumer and two producers -- the
+  // consumer is the long pole of a block's step, and two of them on one SIMD make that block (and, at one round of blocks,
+  // the launch) run at half speed: measured on 1024 resident blocks, wave index alone leaves 10 % of the SIMDs with two
+  // consumers and 10 % with none.  rot_mode & 3: 0 = by SIMD (default), 1 = wave 2 consumes, 2 = rotate by block index.
+  extern __shared__ u32 lds_roles[];
   const int rmode = rot_mode & 3;
-  const int rot = rmode == 0 ? 0 : (rmode == 1 ? (int)(blockIdx.x % 3u) : (int)((blockIdx.x >> 3) % 3u));
-  int role = w + rot;
-  if (role >= 3) role -= 3;
+  int role;
+  if (NC == 1 && rmode == 0) {
+    const int simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);      // HW_REG_HW_ID bits 5:4
+    if (lane == 0) lds_roles[w] = (u32)simd;
+    __syncthreads();
+    const int s0 = (int)lds_roles[0], s1 = (int)lds_roles[1], s2 = (int)lds_roles[2];
+    __syncthreads();                                           // the words are reused by the accumulator region
+    int cw = 2;                                                // fallback: wave 2
+    if (s0 != s1 && s0 != s2 && s1 != s2) {
+      const int want = (6 - (s0 + s1 + s2) + 1) & 3;
+      cw = s0 == want ? 0 : (s1 == want ? 1 : 2);
+    }
+    role = w == cw ? 2 : (w > cw ? w - 1 : w);
+  } else {
+    const int rot = (NC == 1 && rmode == 2) ? (int)(blockIdx.x % 3u) : 0;
+    role = w + rot;
+    if (NC == 1 && role >= 3) role -= 3;
+  }
   if (role < 2) {
     // ---------------------------------------------------------------- producer: 30 pairings, one per lane pair
     if (rot_mode & 8) __builtin_amdgcn_s_setprio(3);
@@ -297,7 +325,8 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
     const int g = live ? lane / 6 : 9;
     const int j = live ? lane % 6 : lane - 60;
     const int gb = g * K::GROUP_DW;
-    const int rbo = gb + K::RB, rlo = gb + K::RL;
+    const int cw = role - 2;                            // which consumer: lines [cw * 6 / NC, (cw + 1) * 6 / NC)
+    const int rbo = gb + K::RB + cw * 12 * K::ES, rlo = gb + K::RL;
     Ux2<C> fj;
     {
       const Ux<C> one = ux_load<C>(C::RX_ONE);
@@ -308,7 +337,7 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
     auto fold6 = [&]() __attribute__((always_inline)) {
       if constexpr (DBG == 1) return;
 #pragma unroll 1
-      for (int m = 0; m < 6; ++m) {
+      for (int m = cw * (6 / NC); m < (cw + 1) * (6 / NC); ++m) {
         fj = mx_fold<C>(rlo, rbo, m, j);
         mx_publish<C>(rbo, j, fj, live);
       }
@@ -341,7 +370,7 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
       if constexpr (C::CURVE_ID != 0) {
         if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w
       }
-      out[((size_t)blockIdx.x * 10 + g) * 6 + j] = r;
+      out[(((size_t)blockIdx.x * NC + cw) * 10 + g) * 6 + j] = r;
     }
   }
 }

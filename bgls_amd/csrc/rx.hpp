@@ -67,6 +67,9 @@ BGLS_HD void rx_macs(i64& c, i32 a, i32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RX_M1(OP, k, A, B) OP " %" #k ", vcc, %" #A ", %" #B ", %" #k "\n\t"
 // K accumulators c[0..K), one left factor a, K right factors b[0..K) (BC = "v": registers, "s": scalar constants)
+#define RX_ROW2(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 2, 3) RX_M1(OP, 1, 2, 4) : "+v"((c)[0]), "+v"((c)[1]) : "v"(a), BC((b)[0]), BC((b)[1]) : "vcc")
+#define RX_ROW3(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 3, 4) RX_M1(OP, 1, 3, 5) RX_M1(OP, 2, 3, 6) \
+  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]) : "vcc")
 #define RX_ROW4(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 4, 5) RX_M1(OP, 1, 4, 6) RX_M1(OP, 2, 4, 7) RX_M1(OP, 3, 4, 8) \
   : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]) : "vcc")
 #define RX_ROW5(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 5, 6) RX_M1(OP, 1, 5, 7) RX_M1(OP, 2, 5, 8) RX_M1(OP, 3, 5, 9) RX_M1(OP, 4, 5, 10) \
@@ -83,11 +86,13 @@ BGLS_HD void rx_macs(i64& c, i32 a, i32 b) {
     else if constexpr (K == 6) RX_ROW6(OP, BC, c, a, b); \
     else if constexpr (K == 5) RX_ROW5(OP, BC, c, a, b); \
     else if constexpr (K == 4) RX_ROW4(OP, BC, c, a, b); \
-    else { static_assert(K >= 4 && K <= 7, "row block"); } \
+    else if constexpr (K == 3) RX_ROW3(OP, BC, c, a, b); \
+    else if constexpr (K == 2) RX_ROW2(OP, BC, c, a, b); \
+    else { static_assert(K >= 2 && K <= 7, "row block"); } \
   } while (0)
 #endif
 
-// c[0..K) += a * b[0..K)   (4 <= K <= 7; CONST: the b are compile-time constants, held in scalar registers)
+// c[0..K) += a * b[0..K)   (2 <= K <= 7; CONST: the b are compile-time constants, held in scalar registers)
 template <int K, bool CONST>
 BGLS_HD void rx_rowu_blk(u64* c, u32 a, const u32* b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -152,15 +157,22 @@ BGLS_HD void ux_acc(u64 (&c)[2 * C::RX_NL], const Ux<C>& a, const Ux<C>& b) {
   for (int i = 0; i < C::RX_NL; ++i) rx_rowu<C::RX_NL, false>(c + i, a.v[i], b.v);
 }
 
-// Montgomery reduction of the columns by R': returns T / R' mod p, tight, value < T / R' + p
+// Montgomery reduction of the columns by R': returns T / R' mod p, tight, value < T / R' + p.
+// Row i adds m_i p to columns i .. i+NL-1, m_i = -c[i] / p mod 2^28.  The next row's factor depends on this row's first two
+// products only (c[i] gives the carry, c[i+1] the factor), so those two go first and the dependent scalar chain -- shift,
+// add, multiply, mask -- resolves under the row's other NL - 2 multiplier instructions; with the row issued in plain
+// column order a lone wave sat out that chain on every row (half of a reduction's time).
 template <class C>
 BGLS_HD Ux<C> ux_redc(u64 (&c)[2 * C::RX_NL]) {
   constexpr int N = C::RX_NL;
+  u32 m = ((u32)c[0] * C::RX_NP) & RX_MASK;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const u32 m = ((u32)c[i] * C::RX_NP) & RX_MASK;
-    rx_rowu<N, true>(c + i, m, C::RX_P);
+    rx_rowu_blk<2, true>(c + i, m, C::RX_P);
     c[i + 1] += c[i] >> 28;
+    const u32 m_next = ((u32)c[i + 1] * C::RX_NP) & RX_MASK;
+    rx_rowu<N - 2, true>(c + i + 2, m, C::RX_P + 2);
+    m = m_next;
   }
   Ux<C> r;
 #pragma unroll
@@ -209,22 +221,35 @@ BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
 //   pass 2:  X = -(D + E) + sum (a0 + a1)(b0 + b1) ->  imaginary part            (wrap-around arithmetic: the column totals
 //            sum (a0 b1 + a1 b0) are non-negative because every limb is, so the 64-bit result is exact)
 // 3 NT NL^2 + 2 NL^2 multiplier instructions.  Operands tight, values < 32 p (column budget: tools/gen_constants.py).
-template <class C, int NT, class LA, class LB>
+template <class C, int NT, bool PF = false, class LA, class LB>
 BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
   constexpr int N = C::RX_NL;
   static_assert(NT >= 1 && NT <= 3, "column budget");
   u64 d[2 * N], e[2 * N];
 #pragma unroll
   for (int k = 0; k < 2 * N; ++k) d[k] = e[k] = 0;
+  if constexpr (PF) {
+    // software-pipelined fetches: the operands of the next pile's products are requested before this pile's multiplier
+    // instructions are issued (2 NL more live registers: alt-bn128 has them, BLS12-381 at 168 registers does not)
+    Ux<C> a0 = lda(0, 0), b0 = ldb(0, 0);
 #pragma unroll 1
-  for (int t = 0; t < NT; ++t) {
-    {
-      const Ux<C> a0 = lda(t, 0), b0 = ldb(t, 0);
-      ux_acc<C>(d, a0, b0);
-    }
-    {
+    for (int t = 0; t < NT; ++t) {
       const Ux<C> a1 = lda(t, 1), b1 = ldb(t, 1);
+      ux_acc<C>(d, a0, b0);
+      if (t + 1 < NT) { a0 = lda(t + 1, 0); b0 = ldb(t + 1, 0); }
       ux_acc<C>(e, a1, b1);
+    }
+  } else {
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      {
+        const Ux<C> a0 = lda(t, 0), b0 = ldb(t, 0);
+        ux_acc<C>(d, a0, b0);
+      }
+      {
+        const Ux<C> a1 = lda(t, 1), b1 = ldb(t, 1);
+        ux_acc<C>(e, a1, b1);
+      }
     }
   }
   Ux2<C> r;
@@ -495,9 +520,11 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
   constexpr int N = C::RX_NL;
   static_assert(NP >= 1 && NP <= 4, "products per reduction");
   (void)sizeof(MontAcc<C, BUDGET>);
-  i64 t[N + 1];
+  // t[i .. i+N) are the live columns of row i (column k is dead once row k is done): written as one array of 2 N columns so
+  // that no value ever moves between registers -- a shifting window of N + 1 columns cost a v_mov_b64 per column and row.
+  i64 t[2 * N];
 #pragma unroll
-  for (int k = 0; k <= N; ++k) t[k] = 0;
+  for (int k = 0; k < 2 * N; ++k) t[k] = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     i32 r[NP];
@@ -505,24 +532,20 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
     for (int k = 0; k < NP; ++k) r[k] = row(k, i);
     // column 0 first: the row's Montgomery factor m depends on it and is ready by the time the row's other products are issued
 #pragma unroll
-    for (int k = 0; k < NP; ++k) rx_macs(t[0], r[k], cols[k][0]);
-    const i32 m = (i32)(((u32)t[0] * C::RX_NP) & RX_MASK);
+    for (int k = 0; k < NP; ++k) rx_macs(t[i], r[k], cols[k][0]);
+    const i32 m = (i32)(((u32)t[i] * C::RX_NP) & RX_MASK);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) rx_rows<N - 1, false>(t + 1, r[k], cols[k] + 1);
-    rx_rows<N, true>(t, m, (const i32*)C::RX_P);
-    const i64 carry = t[0] >> 28;
-#pragma unroll
-    for (int j = 0; j < N; ++j) t[j] = t[j + 1];
-    t[N] = 0;
-    t[0] += carry;
+    for (int k = 0; k < NP; ++k) rx_rows<N - 1, false>(t + i + 1, r[k], cols[k] + 1);
+    rx_rows<N, true>(t + i, m, (const i32*)C::RX_P);
+    t[i + 1] += t[i] >> 28;
   }
   Sx<C, SX_T> r;
 #pragma unroll
-  for (int k = 0; k < N - 1; ++k) {
-    r.v[k] = (i32)((u32)t[k] & RX_MASK);
+  for (int k = N; k < 2 * N - 1; ++k) {
+    r.v[k - N] = (i32)((u32)t[k] & RX_MASK);
     t[k + 1] += t[k] >> 28;
   }
-  r.v[N - 1] = (i32)t[N - 1];
+  r.v[N - 1] = (i32)t[2 * N - 1];
   return r;
 }
 

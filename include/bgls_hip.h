@@ -219,10 +219,14 @@ int bgls_final_verify_collect(int curve);
  * (60 pairings per block: a 2^16 batch is 1093 blocks, one more round than fit at once when it runs alone).  Results are
  * identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the environment. */
 int bgls_set_throughput_mode(int on);
-/* Shape of the Miller stage.  0 (default): fused producer/consumer blocks.  1..3: decoupled -- k_lines writes every
- * pairing's scaled line coefficients to a table in HBM, k_fold folds them into shared accumulators, pairings_per_group
- * pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs + Karatsuba; 2 and 3 alt-bn128 only, others
- * fall back to 1).  Results are identical for every shape. */
+/* Shape of the Miller stage.  0 (default): automatic -- k_miller_x60 (carry-free 28-bit limbs, lane-pair point steps; 60
+ * pairings per block) above 128 pairings, except for a lone launch of 61 441..65 536 pairings outside throughput mode,
+ * which takes the 32-bit fused kernel k_miller_ab64 (one round of 1024 blocks instead of two); up to 128 pairings the
+ * latency kernel.  1..3: decoupled -- k_lines writes every pairing's scaled line coefficients to a table in HBM, k_fold
+ * folds them into shared accumulators, pairings_per_group pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3:
+ * 28-bit limbs + Karatsuba; 2 and 3 alt-bn128 only, others fall back to 1).  4: k_miller_x60 for every batch
+ * (pairings_per_group is then its role / priority mode, development).  5: the 32-bit fused kernels for every batch.
+ * Results (partial products, GT bytes, verdicts) are identical for every shape. */
 int bgls_set_miller_shape(int shape, int pairings_per_group);
 /* Contexts 0..15: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
  * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */

@@ -1,0 +1,107 @@
+"""GPU tier for k_miller_x60 (bgls_amd/csrc/miller_x.hpp: the Miller loop on carry-free 28-bit limbs, lane-pair point steps),
+forced for every batch size with bgls_set_miller_shape(4, mode):
+
+  * PairingProduct (curves/curve.go:125-170) against the C oracle's GT bytes at sizes around the kernel's tile boundaries
+    (30 pairings per producer wave, 60 per block, 6 per accumulator group), with points at infinity among the inputs;
+  * the same batches through the 32-bit fused kernels (shape 5): identical GT bytes, also for thousands of pairings;
+  * every role / priority mode gives the same bytes; an off-curve key is reported, not folded."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import coracle
+
+pytestmark = pytest.mark.gpu
+
+
+def B(b):
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
+
+
+def out(n):
+    return (ctypes.c_uint8 * max(1, n))()
+
+
+@pytest.fixture()
+def shape(gpu_lib):
+    def set_shape(s, arg=8):
+        assert gpu_lib.bgls_set_miller_shape(s, arg if s == 4 else 6) == 0
+    yield set_shape
+    assert gpu_lib.bgls_set_miller_shape(0, 6) == 0
+
+
+def random_points(curve, rnd, n):
+    cid = curve["id"]
+    g1 = bytes.fromhex(curve["vec"]["pairings"][3]["g1"])
+    g2 = bytes.fromhex(curve["vec"]["pairings"][3]["g2"])
+    g1s = [coracle.scale_point(cid, 1, g1, rnd.randrange(1, 1 << 250)) for _ in range(n)]
+    g2s = [coracle.scale_point(cid, 2, g2, rnd.randrange(1, 1 << 250)) for _ in range(n)]
+    return g1s, g2s
+
+
+def test_pairing_product_equals_oracle_at_tile_boundaries(gpu_lib, curve, shape):
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(60 + cid)
+    for n in (1, 2, 29, 30, 31, 59, 60, 61, 66, 120, 121, 187):
+        g1s, g2s = random_points(curve, rnd, n)
+        if n >= 30:                                    # points at infinity contribute the factor 1 (curves/altbn128.go:478, curves/bls12_381.go:341)
+            g1s[n // 3] = bytes(2 * n_fp)
+            g2s[n // 2] = bytes(4 * n_fp)
+        a, b = b"".join(g1s), b"".join(g2s)
+        want = coracle.pairing_product(cid, a, b, n, threads=8)
+        shape(4)
+        o = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
+        assert bytes(o) == want, "k_miller_x60, n = %d" % n
+        shape(5)
+        o5 = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o5) == 0
+        assert bytes(o5) == want, "32-bit kernels, n = %d" % n
+
+
+def test_large_batches_same_bytes_as_the_32_bit_kernels(gpu_lib, curve, shape):
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(77 + cid)
+    n = 7000
+    g2 = out(4 * n_fp)
+    g1 = out(2 * n_fp)
+    gpu_lib.bgls_generator(cid, 2, g2)
+    gpu_lib.bgls_generator(cid, 1, g1)
+    k1 = b"".join(rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(n))
+    k2 = b"".join(rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(n))
+    g1s, g2s = out(n * 2 * n_fp), out(n * 4 * n_fp)
+    assert gpu_lib.bgls_scale_points(cid, 1, B(bytes(g1) * n), B(k1), None, n, g1s) == 0
+    assert gpu_lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(k2), None, n, g2s) == 0
+    shape(5)
+    ref = out(12 * n_fp)
+    assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, ref) == 0
+    for mode in (8, 0, 1, 2, 9, 4):
+        shape(4, mode)
+        o = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, o) == 0
+        assert bytes(o) == bytes(ref), "mode %d" % mode
+    # bilinearity pins the value itself: prod e(a_i g1, b_i g2) = e(g1, g2)^(sum a_i b_i)
+    shape(4)
+    from oracle.pyref.params import CURVES
+    r = CURVES[curve["name"]].r
+    if r:
+        s = sum(int.from_bytes(k1[32 * i:32 * i + 32], "big") * int.from_bytes(k2[32 * i:32 * i + 32], "big") for i in range(n)) % r
+        one = out(2 * n_fp)
+        assert gpu_lib.bgls_scale_points(cid, 1, g1, B(s.to_bytes(32, "big")), None, 1, one) == 0
+        e = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, one, g2, 1, e) == 0
+        assert bytes(e) == bytes(ref)
+
+
+def test_off_curve_key_is_reported(gpu_lib, curve, shape):
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(5)
+    n = 200
+    g1s, g2s = random_points(curve, rnd, n)
+    bad = bytearray(g2s[137])
+    bad[-1] ^= 1
+    g2s[137] = bytes(bad)
+    shape(4)
+    o = out(12 * n_fp)
+    assert gpu_lib.bgls_pairing_product(cid, B(b"".join(g1s)), B(b"".join(g2s)), n, o) < 0
