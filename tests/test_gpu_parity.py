@@ -432,11 +432,18 @@ def test_bench_two_ranks_share_one_gpu():
                           "--signers", "8192", "--no-cpu-baseline", "--reps", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-800:], out.stderr[-1500:])
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # the compact record is the LAST line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["signers_per_gpu"] == 4096
-    other = d["records"]["bls12_8192"]                     # the BLS12-381 record rides on the same line for every N
+    assert d["roofline"]["frac"] > 0 and d["collective"]["world"] == 2 and d["collective"]["backend"] == "gloo" and d["collective"]["bytes_per_step"] > 0
+    assert d["records"]["bls12_8192"]["value"] > 0 and d["records"]["altbn128_multisig_8192"]["value"] > 0
+    # the full per-record detail rides on an earlier line
+    det = [l for l in out.stdout.splitlines() if l.startswith("DETAIL {")]
+    assert len(det) == 1
+    full = json.loads(det[0][len("DETAIL "):])
+    other = full["records"]["bls12_8192"]                  # the BLS12-381 record is measured for every N
     assert other["n_gpus"] == 2 and other["value"] > 0 and other["config"]["signers_per_gpu"] == 4096
-    ms = d["records"]["altbn128_multisig_8192"]            # config 4 cut over the ranks: partial key sums, one all-gather
+    ms = full["records"]["altbn128_multisig_8192"]         # config 4 cut over the ranks: partial key sums, one all-gather
     assert ms["n_gpus"] == 2 and ms["value"] > 0 and ms["scaling"] == "strong"
 
 
