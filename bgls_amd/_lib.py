@@ -24,6 +24,10 @@ SIGNATURES = {
     "bgls_gt_size": (sz, [ci]),
     "bgls_verify_aggregate": (ci, [ci, u8p, u8p, u8p, u64p, sz, ci]),
     "bgls_verify_multi": (ci, [ci, u8p, u8p, sz, u8p, sz]),
+    "bgls_verify_multi_batch": (ci, [ci, u8p, u8p, u64p, sz, u8p, u64p, ci]),
+    "bgls_aggregate_sets": (ci, [ci, ci, u8p, u64p, sz, u8p]),
+    "bgls_verify_multi_batch_dev": (ci, [ci, vp, vp, vp, sz, sz, vp, sz, sz, ci, vp]),
+    "bgls_verify_multi_batch_submit_dev": (ci, [ci, vp, vp, vp, sz, sz, vp, sz, sz, ci, vp]),
     "bgls_pairing_product": (ci, [ci, u8p, u8p, sz, u8p]),
     "bgls_scale_generator": (ci, [ci, ci, u8p, sz, u8p]),
     "bgls_sign_batch": (ci, [ci, u8p, u8p, u64p, sz, u8p]),

@@ -39,10 +39,13 @@ class KeySet:
     def __init__(self, curve, keys, devices=None, check=True):
         raw = b"".join(k.raw for k in keys) if keys and isinstance(keys[0], Point) else bytes(keys)
         n = len(raw) // (4 * curve.fp_bytes)
-        devs = list(devices) if devices else [0]
         h = ctypes.c_uint64()
-        rc = _lib.load().bgls_keys_upload(curve.id, _lib.buf(raw), n, (ctypes.c_int * len(devs))(*devs), len(devs), 1 if check else 0,
-                                          ctypes.byref(h))
+        if devices:
+            devs = list(devices)
+            rc = _lib.load().bgls_keys_upload(curve.id, _lib.buf(raw), n, (ctypes.c_int * len(devs))(*devs), len(devs), 1 if check else 0,
+                                              ctypes.byref(h))
+        else:                                         # NULL + one shard: the process' default device (bgls_init / bgls_select_device), as in the C++ and Go mirrors
+            rc = _lib.load().bgls_keys_upload(curve.id, _lib.buf(raw), n, None, 1, 1 if check else 0, ctypes.byref(h))
         if rc != 0:
             raise ValueError("bgls_keys_upload: %d %s" % (rc, _lib.last_error()))
         self.curve, self.n, self.handle = curve, n, h.value
@@ -125,6 +128,28 @@ def KoskVerifySingleSignature(curve, sig, pubkey, msg):       # bgls/blsKosk.go:
 
 def KoskVerifyMultiSignature(curve, aggsig, keys, msg):       # bgls/blsKosk.go:117-120
     return _verify_multi(curve, aggsig, keys, b"\x01" + bytes(msg))
+
+
+def KoskVerifyBatchMultiSignature(curve, aggsigs, pubkeys, msgs):      # bgls/blsKosk.go:126-133
+    """aggsigs: one multi-signature per message, pubkeys[i]: the signers of message i.  One call: the key sums of all sets
+    in one launch, then ONE aggregate verification over len(msgs) pairs (the reference: AggregateSignatures, len(msgs) x
+    AggregateKeys, KoskVerifyAggregateSignature)."""
+    if len(aggsigs) != len(pubkeys) or len(pubkeys) != len(msgs) or not msgs:
+        return False
+    if any(s.curve is not curve or s.group != G1 for s in aggsigs):
+        return False
+    if any(k.curve is not curve or k.group != G2 for ks in pubkeys for k in ks):
+        return False
+    koff = (ctypes.c_uint64 * (len(pubkeys) + 1))()
+    for i, ks in enumerate(pubkeys):
+        koff[i + 1] = koff[i] + len(ks)
+    pm = [b"\x01" + bytes(m) for m in msgs]
+    moff = (ctypes.c_uint64 * (len(pm) + 1))()
+    for i, m in enumerate(pm):
+        moff[i + 1] = moff[i] + len(m)
+    rc = _lib.load().bgls_verify_multi_batch(curve.id, _lib.buf(b"".join(s.raw for s in aggsigs)), _lib.buf(b"".join(k.raw for ks in pubkeys for k in ks)),
+                                             koff, len(msgs), _lib.buf(b"".join(pm)), moff, 1)
+    return rc == 1
 
 
 class AggSig:                                                 # bgls/bgls.go:22-26,73-75
@@ -277,7 +302,7 @@ def CheckAuthentication(curve, pubkey, authentication):      # bgls/blsKosk.go:5
     return VerifySingleSignature(curve, authentication, pubkey, pubkey.Marshal())
 
 
-def KoskVerifyBatchMultiSignature(curve, aggsigs, pubkeys, msgs):    # bgls/blsKosk.go:126-133
+def KoskVerifyBatchMultiSignatureStepwise(curve, aggsigs, pubkeys, msgs):    # bgls/blsKosk.go:126-133, call by call as the reference writes it
     aggsig = AggregateSignatures(aggsigs)
     keys = [AggregateKeys(ks) for ks in pubkeys]
     return KoskVerifyAggregateSignature(curve, aggsig, keys, msgs)

@@ -224,6 +224,21 @@ BGLS_FN bool g2_in_subgroup(const Aff<F2<C>>& q) {
   }
 }
 
+// G1 membership.  alt-bn128's G1 is the whole curve (cofactor 1).  BLS12-381's E(Fp) has cofactor (x-1)^2/3 and the
+// reference validates G1 points exactly like G2 points when they are constructed (MakeG1Point with check, UnmarshalG1:
+// curves/bls12_381.go:196-264 -> pt.Check()): a point sigma + T with T of cofactor order must not become a signature
+// (it would verify like sigma: malleability, and scalars reduced mod r would act wrongly on it).  Decided by the
+// definition, [r]P = infinity -- construction-time work, one 255-bit scalar multiplication in Fp.
+template <class C>
+BGLS_FN bool g1_in_subgroup(const Aff<F1<C>>& p) {
+  if constexpr (C::CURVE_ID == 0) {
+    return true;
+  } else {
+    if (p.inf) return true;
+    return jac_is_inf<F1<C>>(jac_mul<F1<C>>(p, C::ORDER, 255));
+  }
+}
+
 // ---- (de)serialisation of affine points at the seam (uncompressed wire formats) ----
 //  G1: x || y big-endian (curves/altbn128.go:42-57; bls12G1Hash.dat)
 //  G2: x_im || x_re || y_im || y_re (curves/altbn128.go:157-179, altbn128_test.go:26-38;

@@ -20,7 +20,11 @@
 #include <memory>
 #include <unordered_map>
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+// RCCL is reached through dlopen only (see struct Rccl): the few types and constants it needs are declared here, so the
+// library also builds where the RCCL development headers are not installed.  Values follow nccl.h's ABI.
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 
 #include "dev_common.hpp"
 #include "coop.hpp"
@@ -60,7 +64,7 @@ constexpr size_t MAX_BATCH = (size_t)1 << 30;
 constexpr size_t LAT_MAX = 128;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_SEG_OFF, WS_SEG_KEYS, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -569,6 +573,42 @@ struct Engine {
     HIPCHK(hipGetLastError());
     return 0;
   }
+  // nsets sums in one pass: set b = points d_off[b] .. d_off[b+1] (d_off: nsets + 1 offsets on the device, max_set = the
+  // largest set); wire bytes of the nsets sums to d_out.  One main launch for all sets (P partials per set), then the
+  // usual tree levels over the flat array of nsets * P partials -- P is a power of two, so no level pairs two sets.
+  static int sum_sets(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint64_t* d_off, size_t nsets, size_t max_set,
+                      uint8_t* d_out, uint32_t* d_flags) {
+    if (nsets == 0) return 0;
+    size_t P = 64;
+    while (P < 8192 && P * 4 <= max_set && nsets * P * 2 <= (size_t)131072) P *= 2;     // >= 4 points per partial, <= 2048 waves in all
+    void *ja, *jb;
+    int rc;
+    Scope sc(c, st, ST_SUM);
+    const size_t JB = kl::jac_bytes<C>(group);
+    if ((rc = c.get(WS_JAC_A, (nsets * P + 1) * JB, &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (nsets * P / 2 + 2) * JB, &jb))) return rc;
+    kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    void *a = ja, *b = jb;
+    size_t p = P, cnt = nsets * P;
+    while (p > 1) {
+      if (group == BGLS_G2 && cnt <= 8192) {
+        kl::sum_coop<C>(st, a, cnt, b);
+        p /= 2; cnt /= 2;
+      } else if (cnt > 4096 || p < 64) {
+        kl::sum_pair<C>(st, group, a, cnt, b);
+        p /= 2; cnt /= 2;
+      } else {
+        kl::sum_wave<C>(st, group, a, cnt, b);
+        p /= 64; cnt /= 64;
+      }
+      void* t = a;
+      a = b;
+      b = t;
+    }
+    kl::jac_to_bytes<C>(st, group, a, nsets, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   // the same sum left in Jacobian form at d_jac (multi-device key sums exchange projective partials);
   // n == 0 gives the point at infinity (all-zero record: Z = 0)
   static int sum_points_jac(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, void* d_jac, uint32_t* d_flags,
@@ -614,6 +654,8 @@ struct Engine {
 
 int flags_to_rc(uint32_t f) {
   if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+  if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "point outside the order-r subgroup");
+  if (f & FLAG_DEGENERATE) return fail(BGLS_ERR_ENCODING, "degenerate point step (small-order key)");
   if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
   return 0;
 }
@@ -684,6 +726,101 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
   if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
   return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+// KoskVerifyBatchMultiSignature's body (bgls/blsKosk.go:126-133): aggsig = sum(sigs), key_b = sum(set b), then ONE aggregate
+// verification over the nsets pairs (key_b, msg_b) -- one Miller launch, one final exponentiation for all the sets.
+template <class C>
+int verify_multi_batch_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sigs, const uint8_t* d_keys, const uint64_t* d_key_off, size_t nsets,
+                             size_t max_set, MsgView mv, int allow_dups, bool submit_only) {
+  typedef Engine<C> E;
+  int rc;
+  void *d_flags, *d_akeys, *d_sig, *d_part;
+  if (nsets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  if ((rc = c.get(WS_SEG_KEYS, (nsets + 1) * E::G2B, &d_akeys))) return rc;
+  if ((rc = c.get(WS_TMP2, 2 * E::G2B, &d_sig))) return rc;
+  if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if ((rc = E::sum_sets(c, st, BGLS_G2, d_keys, d_key_off, nsets, max_set, (uint8_t*)d_akeys, (uint32_t*)d_flags))) return rc;   // AggregateKeys x nsets
+  if ((rc = E::sum_points(c, st, BGLS_G1, d_sigs, nsets, (uint8_t*)d_sig, (uint32_t*)d_flags))) return rc;                          // AggregateSignatures
+  if ((rc = E::miller_product(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_akeys, mv, nsets, !allow_dups, (uint8_t*)d_part, (uint32_t*)d_flags)))
+    return rc;
+  if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+  return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
+}
+
+template <class C>
+int verify_multi_batch_t(const uint8_t* sigs, const uint8_t* keys, const uint64_t* key_off, size_t nsets, const uint8_t* blob, const uint64_t* off,
+                         int allow_dups) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  size_t max_set = 0;
+  for (size_t i = 0; i < nsets; ++i) {
+    if (off[i + 1] < off[i]) return fail(BGLS_ERR_ARG, "msg_off not monotone");
+    if (key_off[i + 1] < key_off[i]) return fail(BGLS_ERR_ARG, "key_off not monotone");
+    if (key_off[i + 1] - key_off[i] > max_set) max_set = key_off[i + 1] - key_off[i];
+  }
+  const size_t nkeys = nsets ? key_off[nsets] - key_off[0] : 0, k0 = nsets ? key_off[0] : 0;
+  if (nkeys >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  const size_t blob_len = nsets ? off[nsets] : 0;
+  void *d_sigs, *d_keys, *d_blob, *d_off, *d_koff;
+  if ((rc = c.get(WS_IN_A, (nsets + 1) * E::G1B, &d_sigs))) return rc;
+  if ((rc = c.get(WS_IN_B, (nkeys + 1) * E::G2B, &d_keys))) return rc;
+  if ((rc = c.get(WS_IN_C, blob_len, &d_blob))) return rc;
+  if ((rc = c.get(WS_IN_D, (nsets + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_SEG_OFF, (nsets + 1) * 8, &d_koff))) return rc;
+  std::vector<uint64_t> rel(nsets + 1);
+  for (size_t i = 0; i <= nsets; ++i) rel[i] = nsets ? key_off[i] - k0 : 0;
+  if (nsets) HIPCHK(hipMemcpyAsync(d_sigs, sigs, nsets * E::G1B, hipMemcpyHostToDevice, st));
+  if (nkeys) HIPCHK(hipMemcpyAsync(d_keys, keys + k0 * E::G2B, nkeys * E::G2B, hipMemcpyHostToDevice, st));
+  if (blob_len) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_len, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, off, (nsets + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_koff, rel.data(), (nsets + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));                       // rel goes out of scope
+  MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
+  return verify_multi_batch_dev_t<C>(c, st, (const uint8_t*)d_sigs, (const uint8_t*)d_keys, (const uint64_t*)d_koff, nsets, max_set, mv, allow_dups, false);
+}
+
+// AggregatePoints over nsets sets in one pass (host buffers): out = nsets points
+template <class C>
+int aggregate_sets_t(int group, const uint8_t* pts, const uint64_t* set_off, size_t nsets, uint8_t* out) {
+  typedef Engine<C> E;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = c.stream;
+  const size_t PB = group == BGLS_G1 ? E::G1B : E::G2B;
+  size_t max_set = 0;
+  for (size_t i = 0; i < nsets; ++i) {
+    if (set_off[i + 1] < set_off[i]) return fail(BGLS_ERR_ARG, "set_off not monotone");
+    if (set_off[i + 1] - set_off[i] > max_set) max_set = set_off[i + 1] - set_off[i];
+  }
+  if (nsets == 0) return 0;
+  const size_t k0 = set_off[0], n = set_off[nsets] - k0;
+  if (n >= MAX_BATCH || nsets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  void *d_pts, *d_off, *d_out, *d_flags;
+  if ((rc = c.get(WS_IN_B, (n + 1) * PB, &d_pts))) return rc;
+  if ((rc = c.get(WS_SEG_OFF, (nsets + 1) * 8, &d_off))) return rc;
+  if ((rc = c.get(WS_SEG_KEYS, (nsets + 1) * PB, &d_out))) return rc;
+  if ((rc = c.get(WS_FLAGS, 16, &d_flags))) return rc;
+  std::vector<uint64_t> rel(nsets + 1);
+  for (size_t i = 0; i <= nsets; ++i) rel[i] = set_off[i] - k0;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+  if (n) HIPCHK(hipMemcpyAsync(d_pts, pts + k0 * PB, n * PB, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off, rel.data(), (nsets + 1) * 8, hipMemcpyHostToDevice, st));
+  if ((rc = E::sum_sets(c, st, group, (const uint8_t*)d_pts, (const uint64_t*)d_off, nsets, max_set, (uint8_t*)d_out, (uint32_t*)d_flags))) return rc;
+  uint32_t f = 0;
+  HIPCHK(hipMemcpyAsync(out, d_out, nsets * PB, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c.collect();
+  return flags_to_rc(f);
 }
 
 template <class C>
@@ -996,6 +1133,19 @@ int verify_multi_dev_entry_t(const void* d_sig, const void* d_keys, size_t n, co
   if ((rc = c.enter())) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c.stream;
   return verify_multi_dev_t<C>(c, st, (const uint8_t*)d_sig, (const uint8_t*)d_keys, n, (const uint8_t*)d_msg, msg_len, submit_only);
+}
+
+template <class C>
+int verify_multi_batch_sub_t(const void* d_sigs, const void* d_keys, const void* d_key_off, size_t nsets, size_t max_set, const void* d_msgs,
+                             size_t msg_len, size_t msg_stride, int allow_dups, void* stream, bool submit_only) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  return verify_multi_batch_dev_t<C>(c, st, (const uint8_t*)d_sigs, (const uint8_t*)d_keys, (const uint64_t*)d_key_off, nsets, max_set, mv, allow_dups,
+                                     submit_only);
 }
 
 // ---- hashed aggregation exponents / weighted sums: host flows -------------------------------------------------
@@ -1638,6 +1788,8 @@ int for_each_shard(KeySet& ks, Fn&& fn) {
 
 int merged_flags_rc(uint32_t f) {
   if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
+  if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "point outside the order-r subgroup");
+  if (f & FLAG_DEGENERATE) return fail(BGLS_ERR_ENCODING, "degenerate point step (small-order key)");
   if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
   return 0;
 }
@@ -1818,6 +1970,31 @@ int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
+}
+
+int bgls_verify_multi_batch(int curve, const uint8_t* sigs, const uint8_t* keys, const uint64_t* key_off, size_t n_sets, const uint8_t* msg_blob,
+                            const uint64_t* msg_off, int allow_duplicates) {
+  if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if (!key_off || !msg_off || (n_sets && (!sigs || !msg_blob)) || (n_sets && key_off[n_sets] > key_off[0] && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_batch_t<CV>(sigs, keys, key_off, n_sets, msg_blob, msg_off, allow_duplicates));
+}
+
+int bgls_aggregate_sets(int curve, int group, const uint8_t* pts, const uint64_t* set_off, size_t n_sets, uint8_t* out) {
+  if (!group_ok(group) || !set_off || (n_sets && !out) || (n_sets && set_off[n_sets] > set_off[0] && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
+  DISPATCH(curve, aggregate_sets_t<CV>(group, pts, set_off, n_sets, out));
+}
+
+int bgls_verify_multi_batch_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
+                                const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) {
+  if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if (n_sets && (!d_sigs || !d_keys || !d_key_off || !d_msgs)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_batch_sub_t<CV>(d_sigs, d_keys, d_key_off, n_sets, max_set, d_msgs, msg_len, msg_stride, allow_duplicates, stream, false));
+}
+int bgls_verify_multi_batch_submit_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
+                                       const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) {
+  if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if (n_sets && (!d_sigs || !d_keys || !d_key_off || !d_msgs)) return fail(BGLS_ERR_ARG, "NULL argument");
+  DISPATCH(curve, verify_multi_batch_sub_t<CV>(d_sigs, d_keys, d_key_off, n_sets, max_set, d_msgs, msg_len, msg_stride, allow_duplicates, stream, true));
 }
 
 int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {

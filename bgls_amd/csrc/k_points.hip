@@ -55,6 +55,30 @@ __global__ void __launch_bounds__(64, 2) k_sum_main(const uint8_t* pts, size_t n
   out[t] = acc;
 }
 
+// B sums in one launch (the key sets of KoskVerifyBatchMultiSignature, bgls/blsKosk.go:126-133): set b = points off[b] .. off[b+1],
+// P partials per set (P a power of two, a multiple of 64: the pairwise / 64-to-1 levels above then never straddle two
+// sets), block = 64 consecutive partials of one set.
+template <class C, class F, int PT_BYTES>
+__global__ void __launch_bounds__(64, 2) k_sumseg_main(const uint8_t* pts, const uint64_t* off, unsigned P, Jac<F>* out, uint32_t* flags) {
+  const unsigned per = P / 64;
+  const size_t b = blockIdx.x / per;
+  const size_t t = (size_t)(blockIdx.x % per) * 64 + threadIdx.x;
+  const size_t lo = off[b], hi = off[b + 1];
+  const bool aligned = (reinterpret_cast<uintptr_t>(pts) & 15) == 0;       // uniform
+  Jac<F> acc = jac_inf<F>();
+  bool bad = false;
+#pragma unroll 1
+  for (size_t k = lo + t; k < hi; k += P) {
+    Aff<F> p;
+    bool ok = aligned ? aff_from_bytes16<F, C>(p, pts + k * PT_BYTES) : aff_from_bytes<F>(p, pts + k * PT_BYTES);
+    ok = ok && aff_on_curve_inl<F>(p);
+    bad = bad || !ok;
+    acc = jac_madd_inl<F>(acc, p);
+  }
+  if (bad) atomicOr(flags, FLAG_ENC);
+  out[b * P + t] = acc;
+}
+
 // one partial per wave from up to 64 Jacobian partials per wave (the upper levels of the tree: few elements, latency-bound)
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_wave(const Jac<F>* in, size_t n, Jac<F>* out) {      // lone waves: full register budget, no spills
@@ -248,8 +272,8 @@ __global__ void __launch_bounds__(64) k_scale_aff(const Aff<F>* pts, const uint8
   aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul<F>(p, k, top + 1)));
 }
 
-// validity of n points: canonical coordinates, on the curve and, for G2, in the order-r subgroup (what the reference
-// checks when a Point is constructed, see g2_in_subgroup).  ok == nullptr: failures only set flags; else ok[i] = 1 / 0.
+// validity of n points: canonical coordinates, on the curve and in the order-r subgroup (G2 on both curves, G1 on
+// BLS12-381: what the reference checks when a Point is constructed, see g2_in_subgroup / g1_in_subgroup).  ok == nullptr: failures only set flags; else ok[i] = 1 / 0.
 template <class C, class F, int PT_BYTES>
 __global__ void __launch_bounds__(64) k_check(const uint8_t* pts, size_t n, uint32_t* flags, uint8_t* ok_out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -260,6 +284,8 @@ __global__ void __launch_bounds__(64) k_check(const uint8_t* pts, size_t n, uint
   uint32_t f = ok ? 0u : FLAG_ENC;
   if constexpr (F::NFP == 2) {
     if (ok && !g2_in_subgroup<C>(p)) { ok = false; f = FLAG_SUBGROUP; }
+  } else {
+    if (ok && !g1_in_subgroup<C>(p)) { ok = false; f = FLAG_SUBGROUP; }     // BLS12-381 only: alt-bn128's G1 has cofactor 1
   }
   if (f) atomicOr(flags, f);
   if (ok_out) ok_out[i] = ok ? 1 : 0;
@@ -328,6 +354,12 @@ void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t
     if (parsed) k_sum_main<C, F2<C>, 4 * C::FP_BYTES, true><<<waves, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
     else k_sum_main<C, F2<C>, 4 * C::FP_BYTES, false><<<waves, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
   }
+}
+template <class C>
+void sumseg_main(hipStream_t st, int group, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags) {
+  const unsigned blocks = (unsigned)(nsets * (P / 64));
+  if (group == BGLS_G1) k_sumseg_main<C, F1<C>, 2 * C::FP_BYTES><<<blocks, 64, 0, st>>>(pts, off, P, (Jac<F1<C>>*)out, flags);
+  else k_sumseg_main<C, F2<C>, 4 * C::FP_BYTES><<<blocks, 64, 0, st>>>(pts, off, P, (Jac<F2<C>>*)out, flags);
 }
 template <class C>
 void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out) {
@@ -410,6 +442,7 @@ void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed,
   template void g1_to_bytes<C>(hipStream_t, const Aff<F1<C>>*, size_t, uint8_t*);                                                \
   template void g1_parse<C>(hipStream_t, const uint8_t*, size_t, int, Aff<F1<C>>*, uint32_t*);                                   \
   template void sum_main<C>(hipStream_t, int, bool, const uint8_t*, size_t, unsigned, void*, uint32_t*);                         \
+  template void sumseg_main<C>(hipStream_t, int, const uint8_t*, const uint64_t*, size_t, unsigned, void*, uint32_t*);                     \
   template void sum_wave<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
   template void sum_pair<C>(hipStream_t, int, const void*, size_t, void*);                                                       \
   template void sum_coop<C>(hipStream_t, const void*, size_t, void*);                                                            \

@@ -493,6 +493,35 @@ func HipVerifyMultiWithMultiplicity(curve CurveSystem, aggsig Point, keys []Poin
 	return C.bgls_verify_multi_multiplicity(c.id, p(s.raw), p(kb), (*C.int64_t)(&multiplicity[0]), C.size_t(len(keys)), p(msg), C.size_t(len(msg))) == 1
 }
 
+// HipVerifyBatchMulti is the body of bgls.KoskVerifyBatchMultiSignature (bgls/blsKosk.go:126-133) in one call: the key sums of
+// all sets in one launch, then one aggregate verification over len(msgs) pairs.  msgs must already carry the Kosk 0x01 prefix.
+func HipVerifyBatchMulti(curve CurveSystem, aggsigs []Point, pubkeys [][]Point, msgs [][]byte) bool {
+	c, ok := curve.(*hipCurve)
+	if !ok || len(aggsigs) != len(pubkeys) || len(pubkeys) != len(msgs) || len(msgs) == 0 {
+		return false
+	}
+	sb := make([]byte, 0, len(aggsigs)*int(c.size(C.BGLS_G1)))
+	var kb, blob []byte
+	koff := make([]C.uint64_t, len(msgs)+1)
+	moff := make([]C.uint64_t, len(msgs)+1)
+	for i := range msgs {
+		s, isHip := aggsigs[i].(*hipPoint)
+		if !isHip || s.group != C.BGLS_G1 {
+			return false
+		}
+		sb = append(sb, s.raw...)
+		one, ok3 := hipKeyBytes(c, pubkeys[i])
+		if !ok3 {
+			return false
+		}
+		kb = append(kb, one...)
+		koff[i+1] = koff[i] + C.uint64_t(len(pubkeys[i]))
+		blob = append(blob, msgs[i]...)
+		moff[i+1] = C.uint64_t(len(blob))
+	}
+	return C.bgls_verify_multi_batch(c.id, p(sb), p(kb), &koff[0], C.size_t(len(msgs)), p(blob), &moff[0], 1) == 1
+}
+
 // HipUnmarshalG2Batch decodes n compressed or uncompressed alt-bn128 keys in one call (the batch form of UnmarshalG2 for
 // key sets arriving over the wire); ok[i] mirrors the per-point (Point, bool).
 func HipUnmarshalG2Batch(curve CurveSystem, data []byte, n int) ([]Point, []bool) {

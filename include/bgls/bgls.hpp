@@ -168,6 +168,25 @@ inline bool VerifyMultiSignatureWithHAE(const CurveSystem* curve, const Point& a
   if (aggsig.curve != curve || aggsig.group != BGLS_G1 || !detail::g2_bytes(curve, pubkeys, kb)) return false;
   return bgls_verify_multi_hae(curve->id, aggsig.raw.data(), kb.data(), pubkeys.size(), msg.data(), msg.size()) == 1;
 }
+// KoskVerifyBatchMultiSignature, bgls/blsKosk.go:126-133: one call -- every key set summed in one launch, ONE aggregate verification
+inline bool KoskVerifyBatchMultiSignature(const CurveSystem* curve, const std::vector<Point>& aggsigs, const std::vector<std::vector<Point>>& pubkeys,
+                                          const std::vector<Bytes>& msgs) {
+  if (aggsigs.size() != pubkeys.size() || pubkeys.size() != msgs.size() || msgs.empty()) return false;
+  Bytes sb, kb, blob;
+  std::vector<uint64_t> koff(pubkeys.size() + 1, 0), moff(msgs.size() + 1, 0);
+  for (size_t i = 0; i < msgs.size(); ++i) {
+    if (aggsigs[i].curve != curve || aggsigs[i].group != BGLS_G1) return false;
+    sb.insert(sb.end(), aggsigs[i].raw.begin(), aggsigs[i].raw.end());
+    Bytes one;
+    if (!detail::g2_bytes(curve, pubkeys[i], one)) return false;
+    kb.insert(kb.end(), one.begin(), one.end());
+    koff[i + 1] = koff[i] + pubkeys[i].size();
+    blob.push_back(1);                                   // the Kosk prefix (blsKosk.go:100-106)
+    blob.insert(blob.end(), msgs[i].begin(), msgs[i].end());
+    moff[i + 1] = blob.size();
+  }
+  return bgls_verify_multi_batch(curve->id, sb.data(), kb.data(), koff.data(), msgs.size(), blob.data(), moff.data(), 1) == 1;
+}
 // KoskVerifyMultiSignatureWithMultiplicity, bgls/blsKosk.go:137-150 (multiplicity == nullptr: plain KoskVerifyMultiSignature)
 inline bool KoskVerifyMultiSignatureWithMultiplicity(const CurveSystem* curve, const Point& aggsig, const std::vector<Point>& keys,
                                                      const std::vector<int64_t>* multiplicity, const Bytes& msg) {

@@ -45,7 +45,7 @@ extern "C" {
 #define BGLS_G2 2
 
 #define BGLS_ERR_ARG (-1)       /* bad curve/group id, NULL pointer, inconsistent offsets */
-#define BGLS_ERR_ENCODING (-2)  /* a coordinate >= q, a point not on its curve, or (where checked) a G2 point outside the subgroup */
+#define BGLS_ERR_ENCODING (-2)  /* a coordinate >= q, a point not on its curve, or (where checked) a point outside the order-r subgroup */
 #define BGLS_ERR_HASH (-3)      /* try-and-increment exhausted 256 counters (probability 2^-256) */
 #define BGLS_ERR_NO_DEVICE (-4) /* no usable HIP device */
 #define BGLS_ERR_HIP (-5)       /* a HIP runtime call failed; see bgls_last_error() */
@@ -87,6 +87,17 @@ int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, co
  * KoskVerifyMultiSignature (bgls/blsKosk.go:117-120) is this call with 0x01 prepended to msg. */
 int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg,
                       size_t msg_len);
+
+/* KoskVerifyBatchMultiSignature's body (bgls/blsKosk.go:126-133): aggsig = AggregateSignatures(sigs) (n_sets G1 points),
+ * key_b = AggregateKeys(set b) with set b = keys[key_off[b] .. key_off[b+1]) (counts of points, n_sets + 1 offsets), then
+ * verifyAggSig(aggsig, key_0 .. key_{n_sets-1}, msgs, allow_duplicates) -- ONE launch for all key sums, one Miller launch and
+ * one final exponentiation for all the sets.  The Go function prepends 0x01 to every message and passes
+ * allow_duplicates = true (KoskVerifyAggregateSignature, bgls/blsKosk.go:100-106); the host mirrors do the same. */
+int bgls_verify_multi_batch(int curve, const uint8_t* sigs, const uint8_t* keys, const uint64_t* key_off, size_t n_sets,
+                            const uint8_t* msg_blob, const uint64_t* msg_off, int allow_duplicates);
+/* AggregatePoints (curves/curve.go:73-121) over n_sets sets in one pass: out[b] = sum of pts[set_off[b] .. set_off[b+1])
+ * (an empty set gives the point at infinity).  What the n_sets AggregateKeys calls of blsKosk.go:128-131 cost. */
+int bgls_aggregate_sets(int curve, int group, const uint8_t* pts, const uint64_t* set_off, size_t n_sets, uint8_t* out);
 
 /* CurveSystem.PairingProduct (curves/altbn128.go:143-145, curves/bls12_381.go:238-240 ->
  * concurrentPairingProduct, curves/curve.go:125-170): gt_out = prod_i e(g1s[i], g2s[i]). */
@@ -163,14 +174,16 @@ int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, ui
 /* Point.Add (curves/altbn128.go:59-66,181-188; curves/bls12_381.go:33-41,94-102) */
 int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out);
 /* MakeG1Point/MakeG2Point/Unmarshal* validation (curves/altbn128.go:42-57,157-179;
- * curves/bls12_381.go:196-226): 1 if canonical and on the curve, 0 otherwise. */
+ * curves/bls12_381.go:196-264 pt.Check()): 1 if the coordinates are canonical, the point is on the curve AND in the
+ * order-r subgroup (G2 on both curves; G1 on BLS12-381, whose E(Fp) has cofactor (x-1)^2/3 -- alt-bn128's G1 is the whole
+ * curve), 0 otherwise. */
 int bgls_point_check(int curve, int group, const uint8_t* a);
 /* The same validation over a batch (what constructing n Points costs in the reference: MakeG1Point / MakeG2Point with
  * check, UnmarshalG1 / UnmarshalG2; curves/altbn128.go:149-179,296-376, curves/bls12_381.go:196-264): ok_out[i] = 1 iff
- * point i has canonical coordinates, lies on its curve and -- G2 -- in the order-r subgroup.  G1 points are tested for the
- * curve only: alt-bn128's G1 is the whole curve, and a BLS12-381 G1 point's component outside the order-r subgroup is
- * annihilated by the reduced pairing (its order divides the cofactor, coprime to r: e(P + T, Q) = e(P, Q)), so no verdict
- * depends on it; what upstream's G1 Check() tests beyond the curve equation is unpinned (the library is not vendored).
+ * point i has canonical coordinates, lies on its curve and in the order-r subgroup: G2 on both curves (endomorphism
+ * criterion, exact), G1 on BLS12-381 ([r]P = infinity; alt-bn128's G1 is the whole curve).  The pairing value itself does
+ * not see a G1 point's cofactor-order component (e(P + T, Q) = e(P, Q)), which is exactly why such points must be refused
+ * at construction: sigma + T would be a second valid encoding of a signature, and scalars reduced mod r act wrongly on it.
  * Returns 0 or < 0. */
 int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out);
 /* GetG1 / GetG2 (curves/altbn128.go:423-429, curves/bls12_381.go:275-281) */
@@ -236,6 +249,12 @@ int bgls_select_context(int index);
  * serialised as affine G2 bytes (bgls_g2_size).  Shards combine with bgls_aggregate_points. */
 int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream);
 
+/* bgls_verify_multi_batch with everything on the device: d_key_off = n_sets + 1 uint64 offsets (from 0), max_set = the
+ * largest set's size, messages at a fixed stride.  _submit_dev enqueues only (collect with bgls_final_verify_collect). */
+int bgls_verify_multi_batch_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
+                                const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream);
+int bgls_verify_multi_batch_submit_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
+                                       const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream);
 /* verify_multi with keys already on the device. */
 int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg,
                           size_t msg_len, void* stream);

@@ -530,3 +530,15 @@ int FN(g2_in_subgroup)(const uint8_t* pt) {
   g2_mul(&r, &p, ORDER, 256);
   return r.inf ? 1 : 0;
 }
+/* G1 membership by the DEFINITION: canonical coordinates, on the curve y^2 = x^3 + b, and [r]P = infinity (what the reference
+ * gets when a G1 Point is constructed with a check: curves/bls12_381.go:196-264 pt.Check(); alt-bn128's G1 has cofactor 1, so
+ * every curve point is a member).  1 = member, 0 = not, -2 = non-canonical encoding. */
+int FN(g1_in_subgroup)(const uint8_t* pt) {
+  g1a p, r; if (!g1_read(&p, pt)) return -2;
+  if (p.inf) return 1;
+  fp l, rr, b; fp_set(&b, CB);
+  fp_sqr(&l, &p.y); fp_sqr(&rr, &p.x); fp_mul(&rr, &rr, &p.x); fp_add(&rr, &rr, &b);
+  if (!fp_eq(&l, &rr)) return 0;
+  g1_mul(&r, &p, ORDER, 256);
+  return r.inf ? 1 : 0;
+}

@@ -8,7 +8,7 @@
   int p##_aggregate_points(int, const uint8_t*, size_t, uint8_t*); int p##_verify_multi(const uint8_t*, const uint8_t*, size_t, const uint8_t*, size_t, int); \
   int p##_scale_point(int, const uint8_t*, const uint8_t*, int, uint8_t*); \
   int p##_miller_product(const uint8_t*, const uint8_t*, size_t, uint8_t*, int); int p##_gt_mul(const uint8_t*, const uint8_t*, uint8_t*); \
-  int p##_g2_in_subgroup(const uint8_t*);
+  int p##_g2_in_subgroup(const uint8_t*); int p##_g1_in_subgroup(const uint8_t*);
 DECL(bn) DECL(bls)
 #define D(name, ...) (curve == 0 ? bn_##name(__VA_ARGS__) : curve == 1 ? bls_##name(__VA_ARGS__) : -1)
 int oracle_hash_to_g1(int curve, const uint8_t* m, size_t l, uint8_t* o) { return D(hash_to_g1, m, l, o); }
@@ -22,3 +22,4 @@ int oracle_scale_point(int curve, int g, const uint8_t* p, const uint8_t* k, int
 int oracle_miller_product(int curve, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* o, int threads) { return D(miller_product, a, b, n, o, threads); }
 int oracle_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* o) { return D(gt_mul, a, b, o); }
 int oracle_g2_in_subgroup(int curve, const uint8_t* p) { return D(g2_in_subgroup, p); }
+int oracle_g1_in_subgroup(int curve, const uint8_t* p) { return D(g1_in_subgroup, p); }

@@ -89,6 +89,11 @@ def g2_in_subgroup(curve, pt):
     return lib().oracle_g2_in_subgroup(curve, _b(pt))
 
 
+def g1_in_subgroup(curve, pt):
+    """1 = on the curve and [r]P = infinity, 0 = not, -2 = non-canonical coordinates"""
+    return lib().oracle_g1_in_subgroup(curve, _b(pt))
+
+
 def miller_product(curve, g1s, g2s, n, threads=1):
     o = (ctypes.c_uint8 * (12 * FP[curve]))()
     rc = lib().oracle_miller_product(curve, _b(g1s), _b(g2s), ctypes.c_size_t(n), o, threads)

@@ -69,6 +69,14 @@ def kosk_verify_aggregate_signature(curve, aggsig, keys, msgs):
     return verify_agg(curve, aggsig, keys, [b"\x01" + m for m in msgs], True)
 
 
+def kosk_verify_batch_multi_signature(curve, aggsigs, pubkeys, msgs):
+    """bgls/blsKosk.go:126-133: AggregateSignatures, one AggregateKeys per set, KoskVerifyAggregateSignature"""
+    PR = pairing_for(curve)
+    aggsig = PR.G.g1_sum(aggsigs)
+    keys = [PR.G.g2_sum(ks) for ks in pubkeys]
+    return kosk_verify_aggregate_signature(curve, aggsig, keys, msgs)
+
+
 # ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---------------
 def hash_pubkeys_to_exponents(curve, keys):
     """blsHAE.go:80-93: t_i = i-th 16-byte big-endian chunk of BLAKE2Xb(MarshalUncompressed(pk_0) || ... , 16 n)."""

@@ -37,6 +37,38 @@ for cv in (BN254, BLS381):
     for r in rows:      # the endomorphism criterion agrees with the definition on every row
         if r["on_twist"]:
             assert S.in_subgroup_fast(G.g2_from_bytes(bytes.fromhex(r["pt"]))) == r["in_subgroup"], r["note"]
-    json.dump({"curve": cv.name, "twist_order_bits": N.bit_length(), "cofactor_factors": [str(q) for q in fs], "points": rows},
+    # G1: the same question on E(Fp).  alt-bn128 has cofactor 1 (every curve point is a member); BLS12-381 has cofactor
+    # (x-1)^2/3 and the reference checks G1 points like G2 points (curves/bls12_381.go:196-264)
+    g1rows = []
+    p = cv.p
+
+    def g1_random_curve_point():
+        while True:
+            x = rnd.randrange(p)
+            y2 = (x * x * x + cv.b) % p
+            y = pow(y2, (p + 1) // 4, p)
+            if y * y % p == y2:
+                return (x, y if rnd.random() < 0.5 else p - y)
+
+    def add1(P, note):
+        on = G.g1_on_curve(P)
+        g1rows.append({"pt": G.g1_bytes(P).hex(), "on_curve": on, "in_subgroup": bool(on and G.g1_mul(P, cv.r) is None), "note": note})
+
+    add1(None, "infinity")
+    for k in (1, 2, 0xC0FFEE, cv.r - 1, rnd.randrange(cv.r)):
+        add1(G.g1_mul(cv.g1, k), "[k]g1")
+    for _ in range(3):
+        add1(g1_random_curve_point(), "random point of E(Fp)")
+    for _ in range(3):
+        T = G.g1_mul(g1_random_curve_point(), cv.r)
+        add1(T, "[r] random: in the cofactor part")
+        add1(G.g1_add(G.g1_mul(cv.g1, rnd.randrange(1, cv.r)), T), "subgroup point + cofactor-part point")
+    bad = bytearray(G.g1_bytes(G.g1_mul(cv.g1, 7))); bad[-1] ^= 1
+    g1rows.append({"pt": bytes(bad).hex(), "on_curve": False, "in_subgroup": False, "note": "off the curve"})
+    if cv.name == "bls12":
+        assert any(r["on_curve"] and not r["in_subgroup"] for r in g1rows)
+    else:
+        assert all(r["in_subgroup"] == r["on_curve"] for r in g1rows)
+    json.dump({"curve": cv.name, "twist_order_bits": N.bit_length(), "cofactor_factors": [str(q) for q in fs], "points": rows, "g1_points": g1rows},
               open(os.path.join(ROOT, "tests", "golden", "subgroup_%s.json" % cv.name), "w"), indent=1)
     print(cv.name, len(rows), "points;", sum(r["in_subgroup"] for r in rows), "in the subgroup")

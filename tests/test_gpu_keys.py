@@ -56,6 +56,31 @@ def test_g2_subgroup_fixture(gpu_lib, curve):
     assert gpu_lib.bgls_check_points(cid, 1, B(bytes(g1) + bytes(2 * fp)), 2, ok1) == 0 and bytes(ok1) == b"\x01\x01"
 
 
+def test_g1_subgroup_fixture(gpu_lib, curve):
+    """G1 points are validated like G2 points when they are constructed (curves/bls12_381.go:196-264 Check()): on BLS12-381
+    a curve point outside the order-r subgroup -- e.g. a signature plus a point of cofactor order, which would verify like
+    the signature itself -- is refused by bgls_point_check / bgls_check_points and by MakeG1Point / UnmarshalG1 of the host
+    mirror; alt-bn128's G1 is the whole curve."""
+    from bgls_amd import Altbn128, Bls12
+    cid, n_fp = curve["id"], curve["fp"]
+    rows = load_golden("subgroup_%s.json" % curve["name"])["g1_points"]
+    pts = b"".join(bytes.fromhex(r["pt"]) for r in rows)
+    ok = (ctypes.c_uint8 * len(rows))()
+    assert gpu_lib.bgls_check_points(cid, 1, B(pts), len(rows), ok) == 0
+    cs = Altbn128 if cid == 0 else Bls12
+    for r, got in zip(rows, ok):
+        raw = bytes.fromhex(r["pt"])
+        assert bool(got) == r["in_subgroup"], r["note"]
+        assert gpu_lib.bgls_point_check(cid, 1, B(raw)) == (1 if r["in_subgroup"] else 0), r["note"]
+        assert coracle.g1_in_subgroup(cid, raw) == (1 if r["in_subgroup"] else 0), r["note"]
+        pt, good = cs.UnmarshalG1(raw)
+        assert good == r["in_subgroup"] and (pt is not None) == r["in_subgroup"], r["note"]
+        coords = [int.from_bytes(raw[:n_fp], "big"), int.from_bytes(raw[n_fp:], "big")]
+        if r["note"] != "infinity":
+            assert cs.MakeG1Point(coords, True)[1] == r["in_subgroup"], r["note"]
+            assert cs.MakeG1Point(coords, False)[1] is True or not r["on_curve"]      # check=False skips the validation, as the reference does
+
+
 def test_g2_subgroup_random_vs_oracle(gpu_lib, curve):
     """Random G2 points, and the same points with one coordinate bit flipped (almost never on the twist; those that are,
     are outside G2): identical verdicts from the HIP criterion and the oracle's [r]Q test."""

@@ -186,8 +186,11 @@ def test_authentication_and_batch_multisig(curve):
             s_, v_, _ = KeyGen(curve)
             ks.append(v_); ss.append(KoskSign(curve, s_, m))
         groups.append(ks); aggsigs.append(AggregateSignatures(ss)); msgs.append(m)
+    from bgls_amd.bgls import KoskVerifyBatchMultiSignatureStepwise
     assert KoskVerifyBatchMultiSignature(curve, aggsigs, groups, msgs)
+    assert KoskVerifyBatchMultiSignatureStepwise(curve, aggsigs, groups, msgs)
     assert not KoskVerifyBatchMultiSignature(curve, aggsigs, groups, msgs[::-1])
+    assert not KoskVerifyBatchMultiSignature(curve, aggsigs, groups[1:] + groups[:1], msgs)
     plain = [AggregateSignatures([Sign(curve, s_, m) for s_ in sks_]) for sks_, m in
              (([11, 12], b"a" * 32), ([13, 14, 15], b"b" * 32))]
     apks = [AggregateKeys([curve.GetG2().Mul(s_) for s_ in sks_]) for sks_ in ([11, 12], [13, 14, 15])]

@@ -146,3 +146,24 @@ def test_subgroup_fixture_and_criterion():
         exact, report = criterion_is_exact(cv)
         assert exact, report
         assert sorted(str(q) for q in fx["cofactor_factors"]) == sorted(fx["cofactor_factors"]) and len(report) == len(set(fx["cofactor_factors"]))
+
+
+def test_g1_subgroup_fixture(curve):
+    """G1 rows of tests/golden/make_subgroup.py (definition: on the curve and [r]P = infinity) against the C oracle and the
+    Python oracle: BLS12-381 has cofactor-order points on E(Fp) that must be refused (curves/bls12_381.go:196-264 Check());
+    on alt-bn128 every curve point is a member."""
+    from oracle.pyref.groups import Groups
+    from tests.conftest import load_golden
+    cid = curve["id"]
+    c = CURVES[curve["name"]]
+    G = Groups(c)
+    rows = load_golden("subgroup_%s.json" % curve["name"])["g1_points"]
+    assert any(r["in_subgroup"] for r in rows) and any(not r["on_curve"] for r in rows)
+    if cid == 1:
+        assert sum(1 for r in rows if r["on_curve"] and not r["in_subgroup"]) >= 6
+    for r in rows:
+        pt = bytes.fromhex(r["pt"])
+        assert coracle.g1_in_subgroup(cid, pt) == (1 if r["in_subgroup"] else 0), r["note"]
+        P = G.g1_from_bytes(pt)
+        on = G.g1_on_curve(P)
+        assert on == r["on_curve"] and bool(on and G.g1_mul(P, c.r) is None) == r["in_subgroup"], r["note"]
