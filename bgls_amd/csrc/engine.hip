@@ -192,7 +192,7 @@ int miller_shape() {
     v = e ? atoi(e) : 0;
     if (v < 0 || v > 5) v = 0;
     const char* r = getenv("BGLS_X60_ROT");
-    if (r) g_x60_rot.store(atoi(r) & 15);
+    if (r) g_x60_rot.store(atoi(r) & 31);
     g_shape.store(v);
   }
   return v;
@@ -405,7 +405,8 @@ struct Engine {
     // when the neighbours fill that round.
     const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX && (throughput_mode() || npairs <= 61440 || npairs > 65536);
     if ((miller_shape() == 4 || x60_auto) && npairs >= 1) {
-      const size_t nb60 = (npairs + 59) / 60, groups = nb60 * 10;
+      const int xmode = g_x60_rot.load();
+      const size_t nb60 = (npairs + 59) / 60, groups = nb60 * ((xmode & 16) ? 20 : 10);
       constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take 57 / 68 KB per block)
       void* park;
       if ((rc = c.get(WS_QP, kl::miller_x60_park_bytes<C>(nb60 < XB ? nb60 : XB), &park))) return rc;
@@ -416,7 +417,7 @@ struct Engine {
         for (size_t blk0 = 0; blk0 < nb60; blk0 += XB) {
           const size_t nblocks = nb60 - blk0 < XB ? nb60 - blk0 : XB;
           const size_t p0 = blk0 * 60;
-          kl::miller_x60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, (uint32_t*)park, g_x60_rot.load());
+          kl::miller_x60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * ((xmode & 16) ? 120 : 60), d_flags, (uint32_t*)park, xmode);
         }
         HIPCHK(hipGetLastError());
       }
@@ -2276,7 +2277,7 @@ int bgls_set_throughput_mode(int on) {
 int bgls_set_miller_shape(int shape, int pairings_per_group) {
   if (shape < 0 || shape > 5 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
   if (shape >= 4) {                       // 4: k_miller_x60 always (second argument: role / priority mode); 5: the 32-bit fused kernels always
-    if (shape == 4) g_x60_rot.store(pairings_per_group & 15);
+    if (shape == 4) g_x60_rot.store(pairings_per_group & 31);
     g_shape.store(shape);
     return 0;
   }

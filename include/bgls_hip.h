@@ -162,8 +162,12 @@ int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, cons
 /* ---- compressed wire formats ------------------------------------------------------------- */
 /* Point.Marshal of alt-bn128 (curves/altbn128.go:81-89 G1, :203-221 G2): out = n compressed points -- G1: x (32-byte
  * big-endian) with the top bit of byte 0 set iff 2y > q; G2: x_im || x_re with the top bits set iff 2 y_im > q / 2 y_re > q;
- * infinity = zeros.  Inputs are validated like every other point (BGLS_ERR_ENCODING).  alt-bn128 only: the BLS12-381
- * compressed layout is the un-vendored dis2/bls12's and unpinned (curves/bls12_381.go:55,60,116,121). */
+ * infinity = zeros.  Inputs are validated like every other point (BGLS_ERR_ENCODING).
+ * alt-bn128 ONLY, by decision: BLS12-381 compressed encodings are NOT part of this ABI (both calls return BGLS_ERR_ARG for
+ * curve 1).  The reference's layout there is whatever the un-vendored, unpinned github.com/dis2/bls12 emits, and the
+ * reference itself carries TODOs that it does not match the ebfull/pairing (ZCash) layout (curves/bls12_381.go:55,60,116,121):
+ * there is no vector to pin an implementation against, so Marshal() on BLS12-381 returns the uncompressed bytes in the host
+ * mirrors (stated in the Go shim) rather than bytes that might silently disagree with upstream. */
 int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out);
 /* UnmarshalG1 / UnmarshalG2, compressed branches (curves/altbn128.go:296-327, :329-376): square roots by calcQuadRes /
  * calcComplexQuadRes (curves/hash.go:178-223), the component-wise sign rule, then the MakeG*Point validation.

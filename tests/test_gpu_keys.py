@@ -214,6 +214,24 @@ def test_key_set_multisig_any_sharding(gpu_lib, curve):
             assert lib.bgls_verify_multi_multi(cid, B(sig), keys, n - 1, B(msg), len(msg), devs(2), 2) == 0
 
 
+def test_scale_selfcheck(gpu_lib, curve):
+    """tools/scale_selfcheck.py: one key set over devices 0..N-1 inside the C ABI -- identical GT bytes for N = 1, 2, 4, 8 and
+    the RCCL exchange (bgls_last_exchange() == 2) once the devices are distinct.  On a one-GPU box the distinct-device runs
+    are reported as skipped and the cut itself is exercised with every shard on device 0."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("scale_selfcheck", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "scale_selfcheck.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    shared = mod.run(curve["name"], 600, share=True)
+    assert shared["ok"] and len(shared["runs"]) == 4 and all(r["same_gt_bytes"] for r in shared["runs"]), shared
+    real = mod.run(curve["name"], 600, share=False)
+    assert real["ok"], real
+    if real["devices"] < 2:
+        assert [r.get("skipped") is not None for r in real["runs"]] == [False, True, True, True]
+        pytest.skip("one GPU: the distinct-device (RCCL) runs need hipGetDeviceCount() >= 2; the shared-device cut passed")
+    assert any(r.get("exchange") == 2 for r in real["runs"] if r.get("rccl_expected")), real
+
+
 def test_rccl_is_loadable(gpu_lib):
     """The exchange uses RCCL when the devices of a key set are distinct; on a one-GPU box only its loading can be checked."""
     assert gpu_lib.bgls_rccl_available() == 1
@@ -241,6 +259,12 @@ def test_prepared_key_set_gives_the_same_gt(gpu_lib, curve):
                 ref_gt = bytes(gt)
             assert bytes(gt) == ref_gt, (n, flags, shards)
             assert lib.bgls_keys_free(h) == 0
+        if n <= 400:
+            # ... and the oracle's bytes for the same product: prod e(H(m_i), pk_i) * e(-sigma', g2)
+            g2 = out(4 * fp)
+            lib.bgls_generator(cid, 2, g2)
+            g1s = b"".join(coracle.hash_to_g1(cid, m) for m in msgs) + coracle.scale_point(cid, 1, wrong_sig, -1)
+            assert ref_gt == coracle.pairing_product(cid, g1s, bytes(keys) + bytes(g2), n + 1, threads=8), n
     # a key at infinity contributes e(H, inf) = 1 on both paths
     n = 40
     sks, keys, msgs, sigs, agg = make_instance(lib, cid, fp, n, 8899 + cid)
