@@ -37,7 +37,7 @@ struct MX {
   static constexpr int GROUP_DW = (NC * 12 + 18) * ES + 4;   // +4: the ten groups start on different banks
   static constexpr int THREADS = 64 * (2 + NC);
   static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
-  static constexpr int NPARK = (C::CURVE_ID == 0 ? 8 : 4) + 3;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP + the step's three line coefficients  (NL dwords each)
+  static constexpr int NPARK = C::CURVE_ID == 0 ? 8 : 4;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP  (HS dwords each)
   static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * HS * 4; }
 };
 
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
     const size_t idx = (size_t)blockIdx.x * 60 + pi;
     const int tg = pi / 6, m = pi % 6;
     u32* const mypark = park + ((size_t)blockIdx.x * 128 + (role * 64 + lane)) * (K::NPARK * K::HS);
-    constexpr int P_NYP = K::NPARK - 5, P_XP = K::NPARK - 4, P_LINE = K::NPARK - 3;
+    constexpr int P_NYP = K::NPARK - 2, P_XP = K::NPARK - 1;
     bool valid = owner && idx < n;
     PointX<C> T;
     {
@@ -263,20 +263,14 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       T.Z = sx_select<C>(odd, ux_to_sx<C>(ux_zero<C>()), sx_const<C>(C::RX_ONE));
     }
     const int rl_off = tg * K::GROUP_DW + K::RL + (3 * m) * K::ES + (odd ? K::HS : 0);
-    // The three line coefficients of a step are parked in the lane's workspace as they appear (they are ready long before
-    // the hand-over and would hold 3 NL registers through the rest of the step) and fetched back before barrier A.
+    // the three line coefficients of a step: computed last in the step, held in registers over barrier A
+    Ux<C> e[3];
     auto emit = [&](int which, const auto& v) __attribute__((always_inline)) {
       const int entry = which == 1 ? 1 : ((which == 0) == C::TWIST_D ? 0 : 2);     // D-type: c0 yP, c1 xP, c2;  M-type: c2, c1 xP, c0 yP
-      MxPark<C>::st_u(mypark, P_LINE + entry, sx_to_ux<C>(v));
+      e[entry] = sx_to_ux<C>(v);
     };
     auto hand_over = [&]() __attribute__((always_inline)) {
-      Ux<C> e[3];
-      {
-        const u32* pk = MxPark<C>::launder(mypark);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) e[k] = MxPark<C>::ld_u(pk, P_LINE + k);
-      }
-      if (!valid) {                       // the constant line 1
+      if (DBG == 2 || !valid) {           // the constant line 1
         e[0] = odd ? ux_zero<C>() : ux_load<C>(C::RX_ONE);
         e[1] = ux_zero<C>();
         e[2] = ux_zero<C>();
@@ -293,8 +287,8 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       const u32* pk;
       int xs, ys;
       bool neg_y;
-      __device__ __forceinline__ Sx<C, SX_T> nyP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 5); }
-      __device__ __forceinline__ Sx<C, SX_T> xP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 4); }
+      __device__ __forceinline__ Sx<C, SX_T> nyP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 2); }
+      __device__ __forceinline__ Sx<C, SX_T> xP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 1); }
       __device__ __forceinline__ Sx<C, SX_T> xq() const { return MxPark<C>::ld(MxPark<C>::launder(pk), xs); }
       __device__ __forceinline__ Sx<C, SX_T> yq() const {
         const Sx<C, SX_T> y = MxPark<C>::ld(MxPark<C>::launder(pk), ys);

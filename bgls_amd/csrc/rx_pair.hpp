@@ -91,15 +91,15 @@ RX_DEV Sx<C, SX_T> pair_muls(const Sx<C, LA>& a, const Sx<C, LS>& s) {
   const i32* const cols[1] = {s.v};
   return sx_montr<C, 1, LA * LS>(cols, [&](int, int i) { return a.v[i]; });
 }
-// own half of a b - c d, one reduction
+// own half of a b - c d, one reduction (the subtracted products enter with negated ROW factors: one instruction per row
+// instead of NL registers of negated columns)
 template <class C, int LA, int LB, int LC, int LD>
 RX_DEV Sx<C, SX_T> pair_mulsub(const Sx<C, LA>& a, const Sx<C, LB>& b, const Sx<C, LC>& c, const Sx<C, LD>& d, bool odd) {
   const Sx<C, LA> pa = pair_swap_neg_even<C>(a, odd);
-  const Sx<C, LC> nc = sx_neg<C>(c);
-  const Sx<C, LC> npc = sx_neg<C>(pair_swap_neg_even<C>(c, odd));
-  const i32* const cols[4] = {a.v, pa.v, nc.v, npc.v};
+  const Sx<C, LC> pc = pair_swap_neg_even<C>(c, odd);
+  const i32* const cols[4] = {a.v, pa.v, c.v, pc.v};
   return sx_montr<C, 4, 2 * LA * LB + 2 * LC * LD>(cols, [&](int k, int i) {
-    return k == 0 ? pair_even1(b.v[i], odd) : (k == 1 ? pair_odd1(b.v[i], odd) : (k == 2 ? pair_even1(d.v[i], odd) : pair_odd1(d.v[i], odd)));
+    return k == 0 ? pair_even1(b.v[i], odd) : (k == 1 ? pair_odd1(b.v[i], odd) : (k == 2 ? -pair_even1(d.v[i], odd) : -pair_odd1(d.v[i], odd)));
   });
 }
 // own half of g^2 - e f, one reduction
@@ -109,11 +109,10 @@ RX_DEV Sx<C, SX_T> pair_sqrsub(const Sx<C, LG>& g, const Sx<C, LE>& e, const Sx<
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
   const i32 even = odd ? 0 : -1;
-  const Sx<C, LE> ne = sx_neg<C>(e);
-  const Sx<C, LE> npe = sx_neg<C>(pair_swap_neg_even<C>(e, odd));
-  const i32* const cols[3] = {u.v, ne.v, npe.v};
+  const Sx<C, LE> pe = pair_swap_neg_even<C>(e, odd);
+  const i32* const cols[3] = {u.v, e.v, pe.v};
   return sx_montr<C, 3, 4 * LG * LG + 2 * LE * LF>(cols, [&](int k, int i) {
-    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? pair_even1(f.v[i], odd) : pair_odd1(f.v[i], odd));
+    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -pair_even1(f.v[i], odd) : -pair_odd1(f.v[i], odd));
   });
 }
 // 3 b' z of the doubling step: a product by the constant on both curves.  (BLS12-381's 3 b' = 12 (1 + i) could be formed with
@@ -138,15 +137,18 @@ RX_DEV void dbl_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_T> Cc = pair_sqr<C>(R.Z, odd);
   const auto H = sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(R.Y, R.Z)), odd), sx_add<C>(B, Cc));      // 2 Y Z
   const Sx<C, SX_T> E = pair_mul_3b<C>(Cc, odd);
-  emit(2, sx_sub<C>(E, B));                                  // I = E - B
-  emit(0, pair_muls<C>(H, env.nyP()));                       // (-H) yP
-  R.Z = pair_mul<C>(B, H, odd);
-  emit(1, pair_muls<C>(sx_mulc<3, C>(pair_sqr<C>(R.X, odd)), env.xP()));   // 3 X^2 xP
+  const auto J3 = sx_mulc<3, C>(pair_sqr<C>(R.X, odd));      // 3 X^2
   const auto A = sx_half<C>(pair_mul<C>(R.X, R.Y, odd));
   const Sx<C, SX_F> Fv = sx_normf<C>(sx_mulc<3, C>(E));
   R.X = pair_mul<C>(A, sx_sub<C>(B, Fv), odd);
   const Sx<C, SX_F> G = sx_normf<C>(sx_half<C>(sx_add<C>(B, Fv)));
-  R.Y = pair_sqrsub<C>(G, E, Fv, odd);                       // G^2 - 3 E^2
+  R.Y = pair_sqrsub<C>(G, E, Fv, odd);                       // G^2 - 3 E^2   (the step's register peak: Z3 and I come after it)
+  const auto I = sx_sub<C>(E, B);
+  R.Z = pair_mul<C>(B, H, odd);
+  // the line, last: its coefficients go straight from registers to the hand-over
+  emit(2, I);                                                // I = E - B
+  emit(0, pair_muls<C>(H, env.nyP()));                       // (-H) yP
+  emit(1, pair_muls<C>(J3, env.xP()));                       // 3 X^2 xP
 }
 
 // Mixed addition step with the affine point (env.xq(), env.yq()) (own halves, tight).
@@ -154,9 +156,6 @@ template <class C, class Env, class Emit>
 RX_DEV void add_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_F> th = sx_normf<C>(sx_sub<C>(R.Y, pair_mul<C>(env.yq(), R.Z, odd)));
   const Sx<C, SX_F> la = sx_normf<C>(sx_sub<C>(R.X, pair_mul<C>(env.xq(), R.Z, odd)));
-  emit(2, pair_mulsub<C>(th, env.xq(), la, env.yq(), odd));  // th xq - la yq
-  emit(0, pair_muls<C>(sx_neg<C>(la), env.nyP()));           // la yP
-  emit(1, pair_muls<C>(sx_neg<C>(th), env.xP()));            // (-th) xP
   const Sx<C, SX_T> D = pair_sqr<C>(la, odd);
   const Sx<C, SX_T> G = pair_mul<C>(R.X, D, odd);
   const Sx<C, SX_T> E = pair_mul<C>(la, D, odd);
@@ -165,6 +164,10 @@ RX_DEV void add_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   R.X = pair_mul<C>(la, Hh, odd);
   R.Z = pair_mul<C>(R.Z, E, odd);
   R.Y = pair_mulsub<C>(th, sx_sub<C>(G, Hh), E, R.Y, odd);
+  // the line, last (la and th are live to the end anyway)
+  emit(2, pair_mulsub<C>(th, env.xq(), la, env.yq(), odd));  // th xq - la yq
+  emit(0, pair_muls<C>(sx_neg<C>(la), env.nyP()));           // la yP
+  emit(1, pair_muls<C>(sx_neg<C>(th), env.xP()));            // (-th) xP
 }
 
 }  // namespace bgls
