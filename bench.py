@@ -414,11 +414,11 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     # (every other stage's time included -- the conservative reading); the exclusive figure is the kernel by itself.
     shared_launch_s = med / launches_per_step
     cname = "BN254" if cid == 0 else "BLS381"
-    # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 unless a lone launch of
-    # 61 441 .. 65 536 pairings (one at a time), which takes k_miller_ab64
+    # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 unless the launch is
+    # 61 441 .. 65 536 pairings: k_miller_ab64 one at a time; in flight k_miller_s60 (alt-bn128) / k_miller_x60 (BLS12-381)
     legacy_alone = 61440 < n <= 65536
     kernel_excl = "k_miller_ab64<%s>" % cname if legacy_alone else "k_miller_x60<%s>" % cname
-    kernel_timed = "k_miller_x60<%s>" % cname if (use_tp or not legacy_alone) else kernel_excl
+    kernel_timed = ("k_miller_s60<BN254>" if cid == 0 else "k_miller_x60<BLS381>") if (use_tp and legacy_alone) else kernel_excl
     if prepared:
         kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])
@@ -532,6 +532,83 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
     }
 
 
+def bench_multisig_batch(lib, dev, inst, n, nsets, steps, warmup, reps, in_flight):
+    """KoskVerifyBatchMultiSignature (bgls/blsKosk.go:126-133) at BASELINE config 4's size: `nsets` multi-signatures of n signers
+    each, every one on its own message, checked by ONE call (bgls_verify_multi_batch_submit_dev): the nsets key sums in one
+    launch, then one aggregate verification over nsets pairs (one Miller launch, one final exponentiation).  The key array
+    holds the same n keys nsets times over (nsets * n * 128 bytes resident); every set is read and summed."""
+    cid, fp = inst["cid"], inst["fp"]
+    rnd = random.Random(0xB6150000 + 44)
+    msgs = [b"\x01" + rnd.randbytes(63) for _ in range(nsets)]             # 64 bytes each with the Kosk prefix
+    off = (ctypes.c_uint64 * (nsets + 1))(*range(0, 64 * (nsets + 1), 64))
+    hs = (ctypes.c_uint8 * (nsets * 2 * fp))()
+    check(lib.bgls_hash_to_g1(cid, B(b"".join(msgs)), off, nsets, hs), "hash_to_g1")
+    sk = (sum(inst["sks"][:n]) % ORDER[cid]).to_bytes(32, "big")
+    sigs = (ctypes.c_uint8 * (nsets * 2 * fp))()
+    check(lib.bgls_scale_points(cid, 1, hs, B(sk * nsets), None, nsets, sigs), "scale_points(sigs)")
+    one = torch.frombuffer(bytearray(inst["keys"][:n * 4 * fp]), dtype=torch.uint8).to(dev)
+    t_keys = one.repeat(nsets)
+    t_sigs = torch.frombuffer(bytearray(bytes(sigs)), dtype=torch.uint8).to(dev)
+    t_msgs = torch.frombuffer(bytearray(b"".join(msgs)), dtype=torch.uint8).to(dev)
+    t_off = torch.tensor([i * n for i in range(nsets + 1)], dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+
+    def one_call(n_sets=nsets, msgs_t=t_msgs):
+        return check(lib.bgls_verify_multi_batch_dev(cid, t_sigs.data_ptr(), t_keys.data_ptr(), t_off.data_ptr(), n_sets, n, msgs_t.data_ptr(), 64, 64, 1, stream),
+                     "verify_multi_batch_dev")
+
+    bad = t_msgs.clone()
+    bad[64 * (nsets // 2) + 7] ^= 1
+    torch.cuda.synchronize()
+    if one_call() != 1 or one_call(msgs_t=bad) != 0:
+        raise RuntimeError("batched multisig correctness gate failed")
+    L = max(1, min(16, in_flight))
+    lanes = Lanes(lib, dev, cid, L, 12 * fp)
+    torch.cuda.synchronize()
+
+    def submit(k):
+        check(lib.bgls_select_context(k), "select_context")
+        check(lib.bgls_verify_multi_batch_submit_dev(cid, t_sigs.data_ptr(), t_keys.data_ptr(), t_off.data_ptr(), nsets, n, t_msgs.data_ptr(), 64, 64, 1,
+                                                     lanes.lanes[k]["stream"].cuda_stream), "verify_multi_batch_submit_dev")
+
+    lib.bgls_profile_enable(1)
+    seq = []
+    for _ in range(max(1, warmup)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one_call()
+        torch.cuda.synchronize()
+        seq.append((time.perf_counter() - t0) * 1e3)
+    stages_excl = {s_: stage(lib, s_) for s_ in ("sum_points", "h2c", "miller", "reduce", "final_exp")}
+    lanes.run(L, submit, L > 1)
+    regions = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lanes.run(steps, submit, L > 1)
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    lib.bgls_profile_enable(0)
+    peak = pinned_peak(lib)
+    per_step = sorted(r / steps for r in regions)
+    med = statistics.median(per_step)
+    ex_ms, ex_cnt = stages_excl["sum_points"]
+    sum_s = ex_ms / max(ex_cnt, 1) * 1e-3
+    macs = nsets * n * MULTISIG_FPMUL * MAC_PER_FPMUL[cid]
+    return {
+        "metric": "multisig-verify signers/sec", "value": nsets * n / med, "unit": "signers/s", "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3,
+        "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s KoskVerifyBatchMultiSignature, %d multi-signatures of %d signers each in one call, keys resident in HBM" % (CNAME[cid], nsets, n),
+                   "in_flight": L, "sets": nsets, "signers_per_set": n},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sumseg_main + tree (the key sums of all sets: sum_points stage, includes the %d-point signature sum)" % nsets,
+                     "peak": peak / 1e12, "unit": "TMAC/s", "achieved": macs / sum_s / 1e12, "frac": macs / sum_s / peak, "launch_ms": sum_s * 1e3, "traffic": None,
+                     "hbm_side": {"achieved": nsets * n * 4 * fp / sum_s / 1e9, "peak": 8000.0, "unit": "GB/s", "note": "key bytes read once / stage time"}},
+        "sequential": {"ms_per_step_median": statistics.median(seq), "ms_per_step_min": min(seq), "value": nsets * n / (statistics.median(seq) * 1e-3)},
+        "stage_ms_exclusive": {k: (v[0] / max(v[1], 1)) for k, v in stages_excl.items()},
+    }
+
+
 def bench_multisig_sharded(lib, dev, inst, n_total, rank, world, steps, warmup, reps):
     """BASELINE config 4 over N GPUs (multisig variant): every rank adds its contiguous range of the n_total keys
     (AggregatePoints on n_total / N of them), ONE all-gather of the 128 / 192-byte partial key sums, then every rank adds the
@@ -633,7 +710,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="verifications kept in flight (1 = strictly sequential, max 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="keep the 64-pairing Miller kernel also when launches overlap")
-    ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "small"], help="run ONE record (profiling runs): --curve, --n apply")
+    ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "multisig_batch", "small"], help="run ONE record (profiling runs): --curve, --n apply")
     ap.add_argument("--no-records", action="store_true", help="headline only")
     ap.add_argument("--prepared", action="store_true", help="with --only aggregate: verify against a prepared key set")
     args = ap.parse_args()
@@ -665,6 +742,10 @@ def main():
     if args.only == "multisig":
         inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000 + 4)
         print(json.dumps(bench_multisig(lib, dev, inst, args.n, args.steps, args.warmup, args.reps, args.in_flight)), flush=True)
+        return
+    if args.only == "multisig_batch":
+        inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000 + 4)
+        print(json.dumps(bench_multisig_batch(lib, dev, inst, args.n, 16, args.steps, args.warmup, args.reps, args.in_flight)), flush=True)
         return
     if args.only == "small":
         inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000)
@@ -698,6 +779,7 @@ def main():
                                                                                         tp, CNAME[c_] + " prepared", with_h2d=False, prepared=True)
             bn = inst if cid == 0 else oinst
             records["altbn128_multisig_%d" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16)
+            records["altbn128_multisig_batch_16x%d" % bn["n"]] = bench_multisig_batch(lib, dev, bn, bn["n"], 16, 8, 2, args.reps, 4)
             records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)
             if not args.no_cpu_baseline:
                 for c_, i_ in ((cid, inst), (other, oinst)):

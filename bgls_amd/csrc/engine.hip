@@ -184,7 +184,7 @@ bool throughput_mode() {
 // 0 also means "automatic": k_miller_x60 (carry-free 28-bit limbs, both curves) wherever it wins, see Engine::miller.
 // 4 = k_miller_x60 always (the second argument is then its role / priority mode), 5 = the 32-bit fused kernels always.
 // BGLS_MILLER_SHAPE / BGLS_X60_ROT preset them from the environment.
-std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{8};
+std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{-1};      // x60 mode -1: automatic (see Engine::miller)
 int miller_shape() {
   int v = g_shape.load();
   if (v < 0) {
@@ -400,12 +400,17 @@ struct Engine {
     }
     // k_miller_x60 (60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes to
     // the epilogue kernel) is the default above the latency shape.  One exception: 1024 blocks are resident at a time, and a
-    // lone launch of slightly more (61 441 .. 65 536 pairings, e.g. exactly 2^16) would pay a second, nearly empty round
-    // of blocks, where k_miller_ab64's 1024 blocks of 64 pairings need one -- unless launches overlap (throughput mode),
-    // when the neighbours fill that round.
-    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX && (throughput_mode() || npairs <= 61440 || npairs > 65536);
+    // launch of slightly more (61 441 .. 65 536 pairings, e.g. exactly 2^16) pays a second, nearly empty round of blocks
+    // where the 32-bit kernels' 1024 blocks of 64 pairings need one: those batches keep k_miller_ab64 -- and k_miller_s60 on
+    // alt-bn128 in throughput mode (measured with four 2^16 verifications in flight: 5.5 vs 6.4 ms a step); BLS12-381 in
+    // throughput mode takes k_miller_x60 also there (10.1 vs 11.8 ms: the neighbours fill the second round).
+    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX &&
+                          (npairs <= 61440 || npairs > 65536 || (throughput_mode() && C::CURVE_ID != 0));
     if ((miller_shape() == 4 || x60_auto) && npairs >= 1) {
-      const int xmode = g_x60_rot.load();
+      // role / priority mode: consumers placed by SIMD; the producers get issue priority only when the whole batch is one round of
+      // resident blocks with the machine to itself (there the slowest block is the launch: 5.8 instead of 7.4 ms for 61 440
+      // BLS12-381 pairings), in steady state it costs 3-6 % (measured at 2^20, four verifications in flight)
+      const int xmode = g_x60_rot.load() >= 0 ? g_x60_rot.load() : ((npairs <= 61440 && !throughput_mode()) ? 8 : 0);
       const size_t nb60 = (npairs + 59) / 60, groups = nb60 * ((xmode & 16) ? 20 : 10);
       constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take 57 / 68 KB per block)
       void* park;
@@ -2282,6 +2287,7 @@ int bgls_set_miller_shape(int shape, int pairings_per_group) {
     return 0;
   }
   if (pairings_per_group < 1) return fail(BGLS_ERR_ARG, "bad Miller shape");
+  if (shape == 0) g_x60_rot.store(-1);    // back to the automatic role / priority mode
   g_shape.store(shape);
   g_ng.store(pairings_per_group);
   return 0;
