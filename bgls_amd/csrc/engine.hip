@@ -198,6 +198,12 @@ int miller_shape() {
   return v;
 }
 
+// G2 key sums run on the carry-free 28-bit-limb form (k_sumx.hip); BGLS_SUMX=0 keeps the 32-bit kernels (A/B measurements)
+bool sumx_enabled() {
+  static const bool v = [] { const char* e = getenv("BGLS_SUMX"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 #ifdef BGLS_DEV
 // development builds only: BGLS_MILLER_DBG=1/2 times the producer / consumer half of the fused Miller kernels (WRONG results)
 int miller_dbg() {
@@ -593,7 +599,8 @@ struct Engine {
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (nsets * P + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (nsets * P / 2 + 2) * JB, &jb))) return rc;
-    kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    if (group == BGLS_G2 && sumx_enabled()) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    else kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     void *a = ja, *b = jb;
     size_t p = P, cnt = nsets * P;
     while (p > 1) {
@@ -633,7 +640,8 @@ struct Engine {
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (waves * 64 + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (waves * 32 + 2) * JB, &jb))) return rc;
-    kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
+    if (group == BGLS_G2 && sumx_enabled()) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags);     // carry-free limbs (rx_jac.hpp)
+    else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
     void *a = ja, *b = jb;
     size_t cnt = waves * 64;
     while (cnt > 1) {

@@ -434,3 +434,33 @@ static int rx_miller_check(const uint8_t* g1, const uint8_t* g2) {
 extern "C" int ht_rx_miller(int curve, const uint8_t* g1, const uint8_t* g2) {
   return curve == 0 ? rx_miller_check<BN254>(g1, g2) : rx_miller_check<BLS381>(g1, g2);
 }
+
+// ---- rx_jac.hpp: a G2 key sum on the carry-free arithmetic (jacx_madd over the wire-format points, in order) against the
+// library's own Jacobian mixed additions; exceptional cases included by the caller's choice of points.  out = the sum's
+// wire bytes; returns 0, -2 on a non-canonical / off-curve point, -3 on a column overflow.
+#include "../../bgls_amd/csrc/rx_jac.hpp"
+template <class C>
+static int rx_sum(const uint8_t* pts, int n, uint8_t* out, uint8_t* out_ref) {
+  typedef F2<C> F;
+  g_rx_overflow = 0;
+  JacX<C> acc = jacx_inf<C>();
+  Jac<F> ref = jac_inf<F>();
+  for (int i = 0; i < n; ++i) {
+    AffX<C> q;
+    if (!affx_from_bytes<C>(q, pts + (size_t)i * 4 * C::FP_BYTES) || !affx_on_curve<C>(q)) return -2;
+    acc = jacx_madd<C>(acc, q);
+    Aff<F> a;
+    if (!g2_from_bytes<C>(a, pts + (size_t)i * 4 * C::FP_BYTES) || !aff_on_curve<F>(a)) return -2;
+    ref = jac_add_aff<F>(ref, a);
+    // also through the resident (Montgomery) form of a key set
+    const AffX<C> q2 = affx_from_mont<C>(a);
+    for (int k = 0; k < C::RX_NL; ++k)
+      if (q2.x.c0.v[k] != q.x.c0.v[k] || q2.y.c1.v[k] != q.y.c1.v[k]) return -4;
+  }
+  g2_to_bytes<C>(out, jac_to_aff<F>(jacx_to_mont<C>(acc)));
+  g2_to_bytes<C>(out_ref, jac_to_aff<F>(ref));
+  return g_rx_overflow ? -3 : 0;
+}
+extern "C" int ht_rx_sum(int curve, const uint8_t* pts, int n, uint8_t* out, uint8_t* out_ref) {
+  return curve == 0 ? rx_sum<BN254>(pts, n, out, out_ref) : rx_sum<BLS381>(pts, n, out, out_ref);
+}

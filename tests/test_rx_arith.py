@@ -137,3 +137,36 @@ def test_lane_pair_point_steps_match_the_library_steps(host_harness, cname, cid)
         g2 = G.g2_bytes(G.g2_mul(c.g2, k2))
         rc = host_harness.ht_rx_miller(cid, (ctypes.c_uint8 * len(g1)).from_buffer_copy(g1), (ctypes.c_uint8 * len(g2)).from_buffer_copy(g2))
         assert rc == 0, "lane-pair point steps differ from pairing.hpp (code %d: 1 + first differing step, -3 = column overflow)" % rc
+
+
+@pytest.mark.parametrize("cname,cid", [("altbn128", 0), ("bls12", 1)])
+def test_key_sum_on_carry_free_limbs(host_harness, cname, cid):
+    """rx_jac.hpp (the G2 key sum of AggregatePoints, curves/curve.go:73-121, as Jacobian mixed additions on signed 28-bit limbs)
+    against the library's 32-bit additions and the Python oracle: random keys, the same key twice in a row (the doubling
+    branch), a key followed by its negative (the sum passes through infinity), keys at infinity, an off-curve key."""
+    c = CURVES[cname]
+    G = Groups(c)
+    rnd = random.Random(91 + cid)
+    n_fp = 32 if cid == 0 else 48
+    base = [G.g2_mul(c.g2, rnd.randrange(1, c.r)) for _ in range(6)]
+    cases = [
+        [base[0]],
+        [base[0], base[1], base[2]],
+        [base[0], base[0]],                                   # P + P
+        [base[0], G.g2_neg(base[0])],                         # P - P = infinity
+        [base[0], G.g2_neg(base[0]), base[1]],                # ... and on from infinity
+        [None, base[2], None, base[3]],                       # keys at infinity
+        [base[0], base[1], G.g2_add(base[0], base[1])],       # running sum equals the next key: doubling in mid-sum
+        [base[0], base[1], G.g2_neg(G.g2_add(base[0], base[1])), base[4], base[5]],
+        [G.g2_mul(c.g2, rnd.randrange(1, c.r)) for _ in range(25)],
+    ]
+    for pts in cases:
+        raw = b"".join(G.g2_bytes(p) for p in pts)
+        got, ref = (ctypes.c_uint8 * (4 * n_fp))(), (ctypes.c_uint8 * (4 * n_fp))()
+        rc = host_harness.ht_rx_sum(cid, (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw), len(pts), got, ref)
+        assert rc == 0, rc
+        want = G.g2_bytes(G.g2_sum([p for p in pts]))
+        assert bytes(ref) == want and bytes(got) == want, len(pts)
+    bad = bytearray(G.g2_bytes(base[0])); bad[-1] ^= 1
+    got, ref = (ctypes.c_uint8 * (4 * n_fp))(), (ctypes.c_uint8 * (4 * n_fp))()
+    assert host_harness.ht_rx_sum(cid, (ctypes.c_uint8 * len(bad)).from_buffer_copy(bytes(bad)), 1, got, ref) == -2

@@ -227,6 +227,9 @@ def main():
         o += "  static constexpr uint64_t RX_BIAS_S6[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b6))
         if b2x3 is not None:
             o += arr("RX_B2X3_RE", lim(b2x3[0] * Rp % p)) + arr("RX_B2X3_IM", lim(b2x3[1] * Rp % p))
+            inv3 = pow(3, -1, p)
+            o += arr("RX_B2_RE", lim(b2x3[0] * inv3 % p * Rp % p)) + arr("RX_B2_IM", lim(b2x3[1] * inv3 % p * Rp % p))   # b' of the twist
+        o += arr("RX_PK", sum((lim(k * p) for k in range(9)), []))    # tight limbs of 0, p, 2p .. 8p (exact zero test of a lazy value)
         return o
 
     def bn_extra(M, limbs, L):
