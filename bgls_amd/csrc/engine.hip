@@ -198,10 +198,15 @@ int miller_shape() {
   return v;
 }
 
-// G2 key sums run on the carry-free 28-bit-limb form (k_sumx.hip); BGLS_SUMX=0 keeps the 32-bit kernels (A/B measurements)
+// G2 key sums on the carry-free 28-bit-limb form (k_sumx.hip).  Measured (2^20 keys, main pass + tree): BLS12-381 1.20 vs
+// 1.30 ms -- taken; alt-bn128 0.66 vs 0.60 ms -- NOT taken: one lane cannot hold the three piles of a Karatsuba Fp2 product
+// next to a Jacobian point, so the carry-free form needs 6 NL^2 multiplier instructions per product (10 limbs) where the
+// 32-bit form needs 3 (8 limbs), and with no long dot product to amortise a reduction over that outweighs its cheaper
+// instruction mix.  BGLS_SUMX=1 / 0 forces it on / off for both curves (A/B measurements).
+template <class C>
 bool sumx_enabled() {
-  static const bool v = [] { const char* e = getenv("BGLS_SUMX"); return !(e && e[0] == '0'); }();
-  return v;
+  static const int v = [] { const char* e = getenv("BGLS_SUMX"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  return v < 0 ? C::CURVE_ID != 0 : v == 1;
 }
 
 #ifdef BGLS_DEV
@@ -599,7 +604,7 @@ struct Engine {
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (nsets * P + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (nsets * P / 2 + 2) * JB, &jb))) return rc;
-    if (group == BGLS_G2 && sumx_enabled()) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    if (group == BGLS_G2 && sumx_enabled<C>()) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     else kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     void *a = ja, *b = jb;
     size_t p = P, cnt = nsets * P;
@@ -640,7 +645,7 @@ struct Engine {
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (waves * 64 + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (waves * 32 + 2) * JB, &jb))) return rc;
-    if (group == BGLS_G2 && sumx_enabled()) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags);     // carry-free limbs (rx_jac.hpp)
+    if (group == BGLS_G2 && sumx_enabled<C>()) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags);     // carry-free limbs (rx_jac.hpp)
     else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
     void *a = ja, *b = jb;
     size_t cnt = waves * 64;

@@ -85,11 +85,13 @@ __device__ __forceinline__ void mx_publish(int rbo, int j, const Ux2<C>& v, bool
 template <class C>
 __device__ __forceinline__ Ux2<C> mx_fold(int rlo, int rbo, int m, int j) {
   typedef MX<C> K;
-  const int* sh = C::TWIST_D ? COOP_SH_D : COOP_SH_M;
+  // powers of w the line's three entries sit at: {0, 1, 3} (D-type twist) / {0, 2, 3} (M-type), as arithmetic on t: a table in
+  // constant memory costs a scalar load and a wait for it in front of every operand fetch
+  auto sh = [](int t) { return C::TWIST_D ? t + (t == 2 ? 1 : 0) : t + (t >= 1 ? 1 : 0); };
   return ux_dot_k2p<C, 3, (C::RX_NL <= 10)>(
       [&](int t, int h) { return mx_ld_half<C>(rlo + (3 * m + t) * K::ES + h * K::HS); },
       [&](int t, int h) {
-        int k = j - sh[t];
+        int k = j - sh(t);
         const int wrap = k < 0 ? 1 : 0;
         k += 6 * wrap;
         return mx_ld_half<C>(rbo + (2 * k + wrap) * K::ES + h * K::HS);

@@ -39,8 +39,8 @@ extern int g_rx_overflow;
 // v_mov_b64 per column and iteration) and schedules every operand load of a loop body up front, which costs a copy per
 // multiplier instruction and pushed the kernels hundreds of registers over their budget.  The statements are volatile, so
 // the multiplier instructions issue in program order: consecutive ones write different columns and a column is revisited
-// NL - 1 instructions later, far beyond the instruction's latency.  A row of limb products goes out as blocks of up to
-// seven instructions per asm statement (rx_row_*): the compiler separates two adjacent asm statements by an s_nop.
+// NL - 1 instructions later, far beyond the instruction's latency.  A row of limb products goes out as ONE asm statement
+// (rx_rows_gen.hpp): the compiler separates two adjacent asm statements by an s_nop.
 BGLS_HD void rx_macu(u64& c, u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
@@ -67,32 +67,10 @@ BGLS_HD void rx_macs(i64& c, i32 a, i32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RX_M1(OP, k, A, B) OP " %" #k ", vcc, %" #A ", %" #B ", %" #k "\n\t"
 // K accumulators c[0..K), one left factor a, K right factors b[0..K) (BC = "v": registers, "s": scalar constants)
-#define RX_ROW2(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 2, 3) RX_M1(OP, 1, 2, 4) : "+v"((c)[0]), "+v"((c)[1]) : "v"(a), BC((b)[0]), BC((b)[1]) : "vcc")
-#define RX_ROW3(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 3, 4) RX_M1(OP, 1, 3, 5) RX_M1(OP, 2, 3, 6) \
-  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]) : "vcc")
-#define RX_ROW4(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 4, 5) RX_M1(OP, 1, 4, 6) RX_M1(OP, 2, 4, 7) RX_M1(OP, 3, 4, 8) \
-  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]) : "vcc")
-#define RX_ROW5(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 5, 6) RX_M1(OP, 1, 5, 7) RX_M1(OP, 2, 5, 8) RX_M1(OP, 3, 5, 9) RX_M1(OP, 4, 5, 10) \
-  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]) : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]) : "vcc")
-#define RX_ROW6(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 6, 7) RX_M1(OP, 1, 6, 8) RX_M1(OP, 2, 6, 9) RX_M1(OP, 3, 6, 10) RX_M1(OP, 4, 6, 11) RX_M1(OP, 5, 6, 12) \
-  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]), "+v"((c)[5]) \
-  : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]), BC((b)[5]) : "vcc")
-#define RX_ROW7(OP, BC, c, a, b) asm volatile(RX_M1(OP, 0, 7, 8) RX_M1(OP, 1, 7, 9) RX_M1(OP, 2, 7, 10) RX_M1(OP, 3, 7, 11) RX_M1(OP, 4, 7, 12) RX_M1(OP, 5, 7, 13) RX_M1(OP, 6, 7, 14) \
-  : "+v"((c)[0]), "+v"((c)[1]), "+v"((c)[2]), "+v"((c)[3]), "+v"((c)[4]), "+v"((c)[5]), "+v"((c)[6]) \
-  : "v"(a), BC((b)[0]), BC((b)[1]), BC((b)[2]), BC((b)[3]), BC((b)[4]), BC((b)[5]), BC((b)[6]) : "vcc")
-#define RX_ROW_DISPATCH(OP, BC, K, c, a, b)            \
-  do {                                                 \
-    if constexpr (K == 7) RX_ROW7(OP, BC, c, a, b);    \
-    else if constexpr (K == 6) RX_ROW6(OP, BC, c, a, b); \
-    else if constexpr (K == 5) RX_ROW5(OP, BC, c, a, b); \
-    else if constexpr (K == 4) RX_ROW4(OP, BC, c, a, b); \
-    else if constexpr (K == 3) RX_ROW3(OP, BC, c, a, b); \
-    else if constexpr (K == 2) RX_ROW2(OP, BC, c, a, b); \
-    else { static_assert(K >= 2 && K <= 7, "row block"); } \
-  } while (0)
+#include "rx_rows_gen.hpp"
 #endif
 
-// c[0..K) += a * b[0..K)   (2 <= K <= 7; CONST: the b are compile-time constants, held in scalar registers)
+// c[0..K) += a * b[0..K)   (2 <= K <= 14; CONST: the b are compile-time constants, held in scalar registers)
 template <int K, bool CONST>
 BGLS_HD void rx_rowu_blk(u64* c, u32 a, const u32* b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -111,19 +89,11 @@ BGLS_HD void rx_rows_blk(i64* c, i32 a, const i32* b) {
   for (int j = 0; j < K; ++j) rx_macs(c[j], a, b[j]);
 #endif
 }
-// c[0..K) += a * b[0..K) for any K >= 4, in blocks of at most seven
+// c[0..K) += a * b[0..K): one asm statement per row (K <= 14)
 template <int K, bool CONST>
-BGLS_HD void rx_rowu(u64* c, u32 a, const u32* b) {
-  if constexpr (K <= 7) rx_rowu_blk<K, CONST>(c, a, b);
-  else if constexpr (K <= 11) { rx_rowu_blk<K - K / 2, CONST>(c, a, b); rx_rowu_blk<K / 2, CONST>(c + (K - K / 2), a, b + (K - K / 2)); }
-  else { rx_rowu_blk<7, CONST>(c, a, b); rx_rowu<K - 7, CONST>(c + 7, a, b + 7); }
-}
+BGLS_HD void rx_rowu(u64* c, u32 a, const u32* b) { rx_rowu_blk<K, CONST>(c, a, b); }
 template <int K, bool CONST>
-BGLS_HD void rx_rows(i64* c, i32 a, const i32* b) {
-  if constexpr (K <= 7) rx_rows_blk<K, CONST>(c, a, b);
-  else if constexpr (K <= 11) { rx_rows_blk<K - K / 2, CONST>(c, a, b); rx_rows_blk<K / 2, CONST>(c + (K - K / 2), a, b + (K - K / 2)); }
-  else { rx_rows_blk<7, CONST>(c, a, b); rx_rows<K - 7, CONST>(c + 7, a, b + 7); }
-}
+BGLS_HD void rx_rows(i64* c, i32 a, const i32* b) { rx_rows_blk<K, CONST>(c, a, b); }
 
 // ===================================================================================================== unsigned, tight
 template <class C>
