@@ -36,7 +36,12 @@ struct MX {
   static constexpr int RL = NC * 12 * ES;             // [6 lines][3] entries
   static constexpr int GROUP_DW = (NC * 12 + 18) * ES + 4;   // +4: the ten groups start on different banks
   static constexpr int THREADS = 64 * (2 + NC);
-  static constexpr int BLOCK_BYTES = 10 * GROUP_DW * 4;
+  // the hash points' coordinates (-yP, xP per pairing, read by both lanes of its pair at every step) live in LDS where a
+  // quarter of a CU's 160 KB has room for them next to the groups (alt-bn128: 34.7 KB per block), else in the lanes' global
+  // workspace (BLS12-381: the groups alone take 38.6 of the 40 KB)
+  static constexpr int PQ = 10 * GROUP_DW;            // [60 pairings][2] halves
+  static constexpr bool P_IN_LDS = (10 * GROUP_DW + 60 * 2 * HS) * 4 <= 40960;
+  static constexpr int BLOCK_BYTES = (10 * GROUP_DW + ((10 * GROUP_DW + 60 * 2 * HS) * 4 <= 40960 ? 60 * 2 * HS : 0)) * 4;
   static constexpr int NPARK = C::CURVE_ID == 0 ? 8 : 4;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP  (HS dwords each)
   static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * HS * 4; }
 };
@@ -228,38 +233,51 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
     bool valid = owner && idx < n;
     PointX<C> T;
     {
-      Aff<F2<C>> Q;
-      Aff<F1<C>> P;
-      if (valid) {
-        bool ok = g2_from_bytes<C>(Q, g2s + idx * 4 * C::FP_BYTES);
-        ok = ok && aff_on_curve<F2<C>>(Q);
-        if (!ok) atomicOr(flags, FLAG_ENC);
-        P = g1s[idx];
-        valid = !P.inf && !Q.inf;
+      // Setup, all in the carry-free form on the lane pair (no out-of-line 32-bit helper: the kernel has no stack frame besides
+      // its spills): the even lane parses the real parts of the key (x_re, y_re), the odd lane the imaginary parts; canonical
+      // encoding, the curve equation y^2 = x^3 + b' and the point at infinity are decided jointly.
+      constexpr int NB = C::FP_BYTES;
+      const uint8_t* kb = g2s + (valid ? idx : 0) * 4 * NB;
+      const Fp<C> xw = fp_from_be<C>(kb + (odd ? 0 : NB)), yw = fp_from_be<C>(kb + (odd ? 2 * NB : 3 * NB));     // wire order: x_im x_re y_im y_re
+      const bool canon_own = !fp_geq_p<C>(xw) && !fp_geq_p<C>(yw);
+      const bool zero_own = fp_is_zero<C>(xw) && fp_is_zero<C>(yw);
+      const bool canon = canon_own && pair_swap1(canon_own ? 1 : 0) != 0;
+      const bool qinf = zero_own && pair_swap1(zero_own ? 1 : 0) != 0;
+      Sx<C, SX_T> xq = sx_from_plain<C>(xw), yq = sx_from_plain<C>(yw);
+      {
+        const Sx<C, SX_T> b2 = sx_const<C>(odd ? C::RX_B2_IM : C::RX_B2_RE);
+        const auto d = sx_sub<C>(pair_sqr<C>(yq, odd), sx_add<C>(pair_mul<C>(pair_sqr<C>(xq, odd), xq, odd), b2));
+        const bool on_own = sx_is_zero_mod_p<C>(d);
+        const bool on_curve = on_own && pair_swap1(on_own ? 1 : 0) != 0;
+        if (valid && !(canon && (qinf || on_curve))) atomicOr(flags, FLAG_ENC);
       }
-      if (!valid) {
-        Q.x = f2_load<C>(C::G2);
-        Q.y = f2_load<C>(C::G2 + 2 * C::L);
+      Aff<F1<C>> P = g1s[valid ? idx : 0];
+      valid = valid && !P.inf && !qinf;
+      if (!valid) {                         // harmless stand-ins: the generators (the lane's line is replaced by the constant 1)
+        xq = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + (odd ? C::L : 0))));
+        yq = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + 2 * C::L + (odd ? C::L : 0))));
         P.x = fp_load<C>(C::G1X);
         P.y = fp_load<C>(C::G1Y);
       }
-      const Sx<C, SX_T> xq = ux_to_sx<C>(to_ux<C>(odd ? Q.x.c1 : Q.x.c0));
-      const Sx<C, SX_T> yq = ux_to_sx<C>(to_ux<C>(odd ? Q.y.c1 : Q.y.c0));
       MxPark<C>::st(mypark, 0, xq);
       MxPark<C>::st(mypark, 1, yq);
       if constexpr (C::CURVE_ID == 0) {
-        // Q1 = pi(Q), -Q2 = -pi^2(Q) on the twist (pairing.hpp miller_loop)
-        const Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
-        const Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-        const Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
-        const Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-        MxPark<C>::st(mypark, 2, ux_to_sx<C>(to_ux<C>(odd ? x1.c1 : x1.c0)));
-        MxPark<C>::st(mypark, 3, ux_to_sx<C>(to_ux<C>(odd ? y1.c1 : y1.c0)));
-        MxPark<C>::st(mypark, 4, ux_to_sx<C>(to_ux<C>(odd ? x2.c1 : x2.c0)));
-        MxPark<C>::st(mypark, 5, ux_to_sx<C>(to_ux<C>(odd ? y2.c1 : y2.c0)));
+        // Q1 = pi(Q) = (conj(x) g12, conj(y) g13), -Q2 = -pi^2(Q) = (x g22, -y g23) on the twist (pairing.hpp miller_loop)
+        const Sx<C, SX_T> cx = sx_select<C>(odd, sx_neg<C>(xq), xq), cy = sx_select<C>(odd, sx_neg<C>(yq), yq);
+        constexpr int N2 = 2 * C::RX_NL;
+        MxPark<C>::st(mypark, 2, pair_mul_const<C>(cx, C::RX_GAMMA + 0 * N2, C::RX_GAMMA + 0 * N2 + C::RX_NL, odd));
+        MxPark<C>::st(mypark, 3, pair_mul_const<C>(cy, C::RX_GAMMA + 1 * N2, C::RX_GAMMA + 1 * N2 + C::RX_NL, odd));
+        MxPark<C>::st(mypark, 4, pair_mul_const<C>(xq, C::RX_GAMMA + 2 * N2, C::RX_GAMMA + 2 * N2 + C::RX_NL, odd));
+        // -y g23: negate, then one carry pass so that the parked limbs are tight again
+        MxPark<C>::st(mypark, 5, sx_norm<C>(sx_neg<C>(pair_mul_const<C>(yq, C::RX_GAMMA + 3 * N2, C::RX_GAMMA + 3 * N2 + C::RX_NL, odd))));
       }
-      MxPark<C>::st(mypark, P_NYP, ux_to_sx<C>(to_ux<C>(fp_neg<C>(P.y))));
-      MxPark<C>::st(mypark, P_XP, ux_to_sx<C>(to_ux<C>(P.x)));
+      if constexpr (K::P_IN_LDS) {          // the even lane stores -yP, the odd lane xP; both read both (same wave: no barrier)
+        if (owner) mx_st_half<C>(K::PQ + (2 * pi + (odd ? 1 : 0)) * K::HS, odd ? to_ux<C>(P.x) : to_ux<C>(fp_neg<C>(P.y)));
+        wave_sync();
+      } else {
+        MxPark<C>::st(mypark, P_NYP, ux_to_sx<C>(to_ux<C>(fp_neg<C>(P.y))));
+        MxPark<C>::st(mypark, P_XP, ux_to_sx<C>(to_ux<C>(P.x)));
+      }
       T.X = xq;
       T.Y = yq;
       T.Z = sx_select<C>(odd, ux_to_sx<C>(ux_zero<C>()), sx_const<C>(C::RX_ONE));
@@ -289,8 +307,15 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       const u32* pk;
       int xs, ys;
       bool neg_y;
-      __device__ __forceinline__ Sx<C, SX_T> nyP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 2); }
-      __device__ __forceinline__ Sx<C, SX_T> xP() const { return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 1); }
+      int pq;                             // LDS offset of this pairing's (-yP, xP)
+      __device__ __forceinline__ Sx<C, SX_T> nyP() const {
+        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C>(pq));
+        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 2);
+      }
+      __device__ __forceinline__ Sx<C, SX_T> xP() const {
+        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C>(pq + K::HS));
+        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 1);
+      }
       __device__ __forceinline__ Sx<C, SX_T> xq() const { return MxPark<C>::ld(MxPark<C>::launder(pk), xs); }
       __device__ __forceinline__ Sx<C, SX_T> yq() const {
         const Sx<C, SX_T> y = MxPark<C>::ld(MxPark<C>::launder(pk), ys);
@@ -299,18 +324,18 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      if constexpr (DBG != 2) dbl_step_x<C>(T, Env{mypark, 0, 1, false}, odd, emit);
+      if constexpr (DBG != 2) dbl_step_x<C>(T, Env{mypark, 0, 1, false, K::PQ + 2 * pi * K::HS}, odd, emit);
       hand_over();
       const int d = C::LOOP_NAF[i];
       if (d != 0) {
-        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 0, 1, d < 0}, odd, emit);
+        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 0, 1, d < 0, K::PQ + 2 * pi * K::HS}, odd, emit);
         hand_over();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
 #pragma unroll 1
       for (int s = 0; s < 2; ++s) {
-        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 2 + 2 * s, 3 + 2 * s, false}, odd, emit);
+        if constexpr (DBG != 2) add_step_x<C>(T, Env{mypark, 2 + 2 * s, 3 + 2 * s, false, K::PQ + 2 * pi * K::HS}, odd, emit);
         hand_over();
       }
     }
@@ -362,7 +387,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       }
     }
     if (live) {
-      Fp2<C> r = from_ux<C>(fj);
+      Fp2<C> r = {from_ux_inl<C>(fj.c0), from_ux_inl<C>(fj.c1)};
       if constexpr (C::CURVE_ID != 0) {
         if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w
       }

@@ -519,6 +519,29 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
   return r;
 }
 
+// value == 0 (mod p)?  a: limbs below 2^30, value in (-3 p, 5 p) (differences of a few reductions' outputs).  v + 3p lies in
+// (0, 8p): after a full carry it equals one of 0, p, .. 8p limb for limb iff v is a multiple of p.
+template <class C, int LA>
+BGLS_HD bool sx_is_zero_mod_p(const Sx<C, LA>& a) {
+  constexpr int N = C::RX_NL;
+  Sx<C, LA + 32> t;
+#pragma unroll
+  for (int i = 0; i < N; ++i) t.v[i] = a.v[i] + (i32)C::RX_PK[3 * N + i];   // + 3p (tight limbs)
+  const Sx<C, SX_T> n = sx_norm<C>(t);
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d |= (u32)n.v[i] ^ C::RX_PK[k * N + i];
+    hit = hit || d == 0;
+  }
+  return hit;
+}
+// plain integer (canonical, < p, 32-bit limbs) -> R' form, tight: split into 28-bit limbs, one product by R'^2
+template <class C>
+BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y);
+
 // signed, bounded  ->  tight and NON-NEGATIVE (the form LDS holds): add the fat multiple of p that dominates every limb,
 // then carry.  |value| must be below K RX_FAT_VB p with K = ceil(LA / 16) (the point steps hand over reductions' outputs
 // and one difference of two: |value| < 2.2 p, K <= 2); the result is below (2 K RX_FAT_VB + 2) p + |value| <= 21 p.
@@ -544,6 +567,59 @@ BGLS_HD Sx<C, SX_T> sx_const(const u32* k) {
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) r.v[i] = (i32)k[i];
   return r;
+}
+
+template <class C>
+BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y) {
+  constexpr int N = C::RX_NL;
+  i32 s[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int lo = 28 * i, q = lo >> 5, r = lo & 31;
+    u64 two = q < C::L ? (u64)y.v[q] : 0;
+    if (q + 1 < C::L) two |= (u64)y.v[q + 1] << 32;
+    s[i] = (i32)((u32)(two >> r) & RX_MASK);
+  }
+  const Sx<C, SX_T> k = sx_const<C>(C::RX_R2);
+  const i32* const cols[1] = {k.v};
+  return sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int i) { return s[i]; });
+}
+
+// x R' (tight, value < 4 p) -> x R in the library's form, everything expanded in place (no call, no stack: the Miller kernel's
+// epilogue must not drag a scratch frame along)
+template <class C>
+BGLS_HD Fp<C> from_ux_inl(const Ux<C>& a) {
+  constexpr int N = C::RX_NL;
+  constexpr int L = C::L;
+  u32 w[L + 1];
+#pragma unroll
+  for (int k = 0; k <= L; ++k) {
+    const int lo = 32 * k;
+    const int i = lo / 28, r = lo % 28;
+    u64 acc = 0;
+    if (i < N) acc = (u64)a.v[i] >> r;
+    int have = 28 - r;
+    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += 28; }
+    if (have < 32 && i + 2 < N) acc |= (u64)a.v[i + 2] << have;
+    w[k] = (u32)acc;
+  }
+#pragma unroll
+  for (int sh = 1; sh >= 0; --sh) {
+    u32 d[L + 1];
+    u32 bw = 0;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) {
+      const u32 pk = (k < L ? (C::P[k] << sh) : 0u) | ((sh && k >= 1) ? (C::P[k - 1] >> (32 - sh)) : 0u);
+      d[k] = subb(w[k], pk, bw);
+    }
+    const u32 keep = bw ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) w[k] = (d[k] & keep) | (w[k] & ~keep);
+  }
+  Fp<C> y;
+#pragma unroll
+  for (int k = 0; k < L; ++k) y.v[k] = w[k];
+  return fp_mul_inl<C>(y, fp_load<C>(C::RX_BACK));
 }
 
 }  // namespace bgls

@@ -74,44 +74,9 @@ BGLS_HD X2<C, SX_T> x2_mulsub(const X2<C, LA>& a, const X2<C, LB>& b, const X2<C
   return r;
 }
 
-// value == 0 (mod p)?  a: limbs below 2^30, value in (-3 p, 5 p) (differences of a few reductions' outputs).  v + 3p lies in
-// (0, 8p): after a full carry it equals one of 0, p, .. 8p limb for limb iff v is a multiple of p.
-template <class C, int LA>
-BGLS_HD bool sx_is_zero_mod_p(const Sx<C, LA>& a) {
-  constexpr int N = C::RX_NL;
-  Sx<C, LA + 32> t;
-#pragma unroll
-  for (int i = 0; i < N; ++i) t.v[i] = a.v[i] + (i32)C::RX_PK[3 * N + i];   // + 3p (tight limbs)
-  const Sx<C, SX_T> n = sx_norm<C>(t);
-  bool hit = false;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    u32 d = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) d |= (u32)n.v[i] ^ C::RX_PK[k * N + i];
-    hit = hit || d == 0;
-  }
-  return hit;
-}
 template <class C, int LA>
 BGLS_HD bool x2_is_zero(const X2<C, LA>& a) { return sx_is_zero_mod_p<C>(a.c0) && sx_is_zero_mod_p<C>(a.c1); }
 
-// plain integer (canonical, < p, 32-bit limbs) -> R' form, tight: split into 28-bit limbs, one product by R'^2
-template <class C>
-BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y) {
-  constexpr int N = C::RX_NL;
-  i32 s[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int lo = 28 * i, q = lo >> 5, r = lo & 31;
-    u64 two = q < C::L ? (u64)y.v[q] : 0;
-    if (q + 1 < C::L) two |= (u64)y.v[q + 1] << 32;
-    s[i] = (i32)((u32)(two >> r) & RX_MASK);
-  }
-  const Sx<C, SX_T> k = sx_const<C>(C::RX_R2);
-  const i32* const cols[1] = {k.v};
-  return sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int i) { return s[i]; });
-}
 // x R (the library's Montgomery form) -> R' form
 template <class C>
 BGLS_HD Sx<C, SX_T> sx_from_mont(const Fp<C>& y) { return ux_to_sx<C>(to_ux<C>(y)); }

@@ -229,6 +229,12 @@ def main():
             o += arr("RX_B2X3_RE", lim(b2x3[0] * Rp % p)) + arr("RX_B2X3_IM", lim(b2x3[1] * Rp % p))
             inv3 = pow(3, -1, p)
             o += arr("RX_B2_RE", lim(b2x3[0] * inv3 % p * Rp % p)) + arr("RX_B2_IM", lim(b2x3[1] * inv3 % p * Rp % p))   # b' of the twist
+        f2x = F2(p)
+        gam = []
+        for (j, k) in ((1, 2), (1, 3), (2, 2), (2, 3)):          # the Frobenius constants of the two extra alt-bn128 line steps (pairing.hpp)
+            gv = f2x.pow(xi, k * (p ** j - 1) // 6)
+            gam += lim(gv[0] * Rp % p) + lim(gv[1] * Rp % p)
+        o += arr("RX_GAMMA", gam)                                 # [(1,2), (1,3), (2,2), (2,3)][re, im][N]
         o += arr("RX_PK", sum((lim(k * p) for k in range(9)), []))    # tight limbs of 0, p, 2p .. 8p (exact zero test of a lazy value)
         return o
 
