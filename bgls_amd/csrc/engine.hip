@@ -1633,6 +1633,7 @@ struct KeySet {
   bool prepared = false;
   std::vector<ncclComm_t> comms;     // one per shard when the RCCL exchange is usable, else empty
   std::mutex mu;                     // one verification at a time per key set (the shards' buffers are part of it)
+  int base_ctx = 0;                  // context of shard 0 in the verification in flight (the caller's bgls_select_context)
   ~KeySet() {
     for (auto cm : comms) if (cm) (void)rccl().CommDestroy(cm);
     for (auto& sh : shards) {
@@ -1757,7 +1758,7 @@ int exchange_records(KeySet& ks) {
     for (int s = 0; s < S && good; ++s) {
       KeyShard& sh = ks.shards[s];
       good = hipSetDevice(sh.device) == hipSuccess &&
-             rccl().AllGather(sh.d_rec, sh.d_all, REC, ncclUint8, ks.comms[s], ctx_of(sh.device, s % NCTX).stream) == ncclSuccess;
+             rccl().AllGather(sh.d_rec, sh.d_all, REC, ncclUint8, ks.comms[s], ctx_of(sh.device, (ks.base_ctx + s) % NCTX).stream) == ncclSuccess;
     }
     good = (rccl().GroupEnd() == ncclSuccess) && good;
     if (good) {
@@ -1768,7 +1769,7 @@ int exchange_records(KeySet& ks) {
   KeyShard& root = ks.shards[0];
   for (int s = 0; s < S; ++s) {
     KeyShard& sh = ks.shards[s];
-    hipStream_t st = ctx_of(sh.device, s % NCTX).stream;
+    hipStream_t st = ctx_of(sh.device, (ks.base_ctx + s) % NCTX).stream;
     HIPCHK(hipSetDevice(sh.device));
     uint8_t* dst = (uint8_t*)root.d_all + (size_t)s * REC;
     if (sh.device == root.device) HIPCHK(hipMemcpyAsync(dst, sh.d_rec, REC, hipMemcpyDeviceToDevice, st));
@@ -1784,9 +1785,11 @@ int for_each_shard(KeySet& ks, Fn&& fn) {
   const int S = (int)ks.shards.size();
   std::vector<int> rcs(S, 0);
   std::vector<std::string> errs(S);
+  const int base = g_sel;                 // the context the caller selected (bgls_select_context): shard s takes (base + s) mod NCTX,
+  ks.base_ctx = base;                     // so a one-shard key set runs on the caller's context and threads on distinct contexts do not serialise
   auto body = [&](int s) {
     g_dev = ks.shards[s].device;
-    g_sel = s % NCTX;
+    g_sel = (base + s) % NCTX;
     rcs[s] = fn(s);
     if (rcs[s] < 0) errs[s] = g_err;
   };
@@ -1865,7 +1868,7 @@ int verify_aggregate_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* blob, co
   KeyShard& root = ks.shards[0];
   const int pd = g_dev, ps = g_sel;
   g_dev = root.device;
-  g_sel = 0;
+  g_sel = ks.base_ctx % NCTX;             // shard 0's context
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   rc = [&]() -> int {
@@ -1922,7 +1925,7 @@ int verify_multi_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* msg, size_t 
   KeyShard& root = ks.shards[0];
   const int pd = g_dev, ps = g_sel;
   g_dev = root.device;
-  g_sel = 0;
+  g_sel = ks.base_ctx % NCTX;
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   rc = [&]() -> int {

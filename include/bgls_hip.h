@@ -303,6 +303,8 @@ int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const vo
 /* verifyMultiSignature (bgls/bgls.go:89-92) against a resident key set: per-device partial key sums (projective G2
  * points) are gathered on the first device, added, and the two-pairing check runs there. */
 int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len);
+/* Contexts: a key-set verification runs shard s on context (selected + s) mod 16 of the shard's device, `selected` being the
+ * calling thread's bgls_select_context (default 0); the final product / exponentiation runs on shard 0's context. */
 /* The same two calls with host keys, for callers without a resident set: upload, verify, free. */
 int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
                                 size_t n, int allow_duplicates, const int* devices, int n_devices);
