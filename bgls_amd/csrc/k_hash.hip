@@ -3,6 +3,7 @@
 #include "dev_common.hpp"
 #include "h2c.hpp"
 #include "launch.hpp"
+#include "rx_pow.hpp"
 
 using namespace bgls;
 
@@ -90,6 +91,25 @@ __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const
   }
 }
 
+// a^((p + 1) / 4) (M1 = false) or a^((p - 3) / 4) (M1 = true) on the carry-free limbs (rx_pow.hpp); `tab` is the wave's
+// LDS table, RXP_W-bit sliding windows.  Same field element as fp_pow_w4 on the same exponent.
+constexpr int RXP_W = 3;
+template <class C>
+constexpr int rxp_lds_words() { return (1 << (RXP_W - 1)) * C::RX_NL * 64; }
+template <class C, bool M1>
+__device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
+  constexpr int N = C::RX_NL;
+  const int lane = threadIdx.x & 63;
+  auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
+  auto st = [&](int e, int i, i32 v) { tab[(e * N + i) * 64 + lane] = v; };
+  auto word = [&](int k) { return C::EXP_SQRT[k] - ((M1 && k == 0) ? 1u : 0u); };   // the low word of (p + 1) / 4 is odd
+  const Sx<C, SX_T> r = sx_pow_sw<C, RXP_W, 32 * C::L>(ux_to_sx<C>(to_ux<C>(a)), word, ld, st);
+  Ux<C> u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];
+  return from_ux<C>(u);
+}
+
 // second half of the Legendre-symbol rounds: y = sqrt(x^3+3) with the reference's sign rule, once per message
 __global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<F1<BN254>>* out) {
   typedef BN254 C;
@@ -97,7 +117,8 @@ __global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<
   if (i >= n) return;
   Aff<F1<C>> p = out[i];
   if (p.inf) return;
-  Fp<C> r = fp_sqrt_candidate<C>(p.y);
+  __shared__ i32 tab[rxp_lds_words<C>()];
+  Fp<C> r = rx_sqrt_pow<C, false>(p.y, tab);
   if (bn_h2c_sign(mv.ptr(i), mv.size(i))) r = fp_neg<C>(r);
   out[i].y = r;
 }
@@ -178,12 +199,9 @@ __global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items
       G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), fp_mul<C>(b, D3));
     }
   }
-  u32 e[C::L];                                              // (p - 3) / 4 = (p + 1) / 4 - 1 (the low limb is odd)
-#pragma unroll
-  for (int k = 0; k < C::L; ++k) e[k] = C::EXP_SQRT[k];
-  e[0] -= 1u;
   const Fp<C> D9 = fp_mul<C>(fp_sqr<C>(D3), D3);
-  Fp<C> y = fp_mul<C>(fp_mul<C>(fp_pow_w4<C, C::L>(fp_mul<C>(G, D9), e), G), D3);
+  __shared__ i32 tab[rxp_lds_words<C>()];
+  Fp<C> y = fp_mul<C>(fp_mul<C>(rx_sqrt_pow<C, true>(fp_mul<C>(G, D9), tab), G), D3);   // exponent (p - 3) / 4
   if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
   pts[item] = {fp_mul<C>(N, D), fp_mul<C>(y, D3), D};
 }

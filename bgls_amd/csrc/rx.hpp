@@ -66,6 +66,7 @@ BGLS_HD void rx_macs(i64& c, i32 a, i32 b) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RX_M1(OP, k, A, B) OP " %" #k ", vcc, %" #A ", %" #B ", %" #k "\n\t"
+#define RX_M0(OP, k, A, B) OP " %" #k ", vcc, %" #A ", %" #B ", 0\n\t"
 // K accumulators c[0..K), one left factor a, K right factors b[0..K) (BC = "v": registers, "s": scalar constants)
 #include "rx_rows_gen.hpp"
 #endif
@@ -87,6 +88,50 @@ BGLS_HD void rx_rows_blk(i64* c, i32 a, const i32* b) {
   else RX_ROW_DISPATCH("v_mad_i64_i32", "v", K, c, a, b);
 #else
   for (int j = 0; j < K; ++j) rx_macs(c[j], a, b[j]);
+#endif
+}
+// MODE 1: c[0..K) = a * b[0..K) (every column written for the first time); MODE 2: c[0..K-1) += .., c[K-1] = a * b[K-1].
+// A product's columns start life in these rows, so that no register is zeroed in front of a product (a 64-bit move per
+// column: 7 % of the Miller kernel's vector instructions).
+template <int K, int MODE>
+BGLS_HD void rx_rows_new(i64* c, i32 a, const i32* b) {
+  static_assert(MODE == 1 || MODE == 2, "mode");
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (MODE == 1) RX_ROWF_DISPATCH("v_mad_i64_i32", "v", K, c, a, b);
+  else RX_ROWL_DISPATCH("v_mad_i64_i32", "v", K, c, a, b);
+#else
+  for (int j = 0; j < K; ++j) {
+    if (MODE == 1 || j == K - 1) c[j] = 0;
+    rx_macs(c[j], a, b[j]);
+  }
+#endif
+}
+template <int K, int MODE>
+BGLS_HD void rx_rowu_new(u64* c, u32 a, const u32* b) {
+  static_assert(MODE == 1 || MODE == 2, "mode");
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (MODE == 1) RX_ROWF_DISPATCH("v_mad_u64_u32", "v", K, c, a, b);
+  else RX_ROWL_DISPATCH("v_mad_u64_u32", "v", K, c, a, b);
+#else
+  for (int j = 0; j < K; ++j) {
+    if (MODE == 1 || j == K - 1) c[j] = 0;
+    rx_macu(c[j], a, b[j]);
+  }
+#endif
+}
+// c = a * b (first write of the column)
+BGLS_HD void rx_muls(i64& c, i32 a, i32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b) : "vcc");
+#else
+  c = (i64)a * b;
+#endif
+}
+BGLS_HD void rx_mulu(u64& c, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b) : "vcc");
+#else
+  c = (u64)a * b;
 #endif
 }
 // c[0..K) += a * b[0..K): one asm statement per row (K <= 14)
@@ -125,6 +170,17 @@ template <class C>
 BGLS_HD void ux_acc(u64 (&c)[2 * C::RX_NL], const Ux<C>& a, const Ux<C>& b) {
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) rx_rowu<C::RX_NL, false>(c + i, a.v[i], b.v);
+}
+
+// columns = a * b, every column written for the first time by its first product (no zeroing; the top column, which no
+// product reaches, is set)
+template <class C>
+BGLS_HD void ux_acc_new(u64 (&c)[2 * C::RX_NL], const Ux<C>& a, const Ux<C>& b) {
+  constexpr int N = C::RX_NL;
+  rx_rowu_new<N, 1>(c, a.v[0], b.v);
+#pragma unroll
+  for (int i = 1; i < N; ++i) rx_rowu_new<N, 2>(c + i, a.v[i], b.v);
+  c[2 * N - 1] = 0;
 }
 
 // Montgomery reduction of the columns by R': returns T / R' mod p, tight, value < T / R' + p.
@@ -196,22 +252,35 @@ BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
   constexpr int N = C::RX_NL;
   static_assert(NT >= 1 && NT <= 3, "column budget");
   u64 d[2 * N], e[2 * N];
-#pragma unroll
-  for (int k = 0; k < 2 * N; ++k) d[k] = e[k] = 0;
+  // the first term's products create the columns (ux_acc_new), the others accumulate
   if constexpr (PF) {
     // software-pipelined fetches: the operands of the next pile's products are requested before this pile's multiplier
     // instructions are issued (2 NL more live registers: alt-bn128 has them, BLS12-381 at 168 registers does not)
     Ux<C> a0 = lda(0, 0), b0 = ldb(0, 0);
+    {
+      const Ux<C> a1 = lda(0, 1), b1 = ldb(0, 1);
+      ux_acc_new<C>(d, a0, b0);
+      if (NT > 1) { a0 = lda(1, 0); b0 = ldb(1, 0); }
+      ux_acc_new<C>(e, a1, b1);
+    }
 #pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 1; t < NT; ++t) {
       const Ux<C> a1 = lda(t, 1), b1 = ldb(t, 1);
       ux_acc<C>(d, a0, b0);
       if (t + 1 < NT) { a0 = lda(t + 1, 0); b0 = ldb(t + 1, 0); }
       ux_acc<C>(e, a1, b1);
     }
   } else {
+    {
+      const Ux<C> a0 = lda(0, 0), b0 = ldb(0, 0);
+      ux_acc_new<C>(d, a0, b0);
+    }
+    {
+      const Ux<C> a1 = lda(0, 1), b1 = ldb(0, 1);
+      ux_acc_new<C>(e, a1, b1);
+    }
 #pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 1; t < NT; ++t) {
       {
         const Ux<C> a0 = lda(t, 0), b0 = ldb(t, 0);
         ux_acc<C>(d, a0, b0);
@@ -267,8 +336,6 @@ template <class C, class KD, class LA, class LB>
 BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
   constexpr int N = C::RX_NL;
   u64 d[2 * N], e[2 * N];
-#pragma unroll
-  for (int k = 0; k < 2 * N; ++k) d[k] = e[k] = 0;
   auto scaled = [&](int t, int h) __attribute__((always_inline)) {       // left operand: doubled or masked out
     const int kd = kind(t);
     const u32 keep = kd ? 0xFFFFFFFFu : 0u;
@@ -278,8 +345,17 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
     for (int q = 0; q < N; ++q) a.v[q] = (a.v[q] << sh) & keep;
     return a;
   };
+  // slot 0 creates the columns (ux_acc_new: no zeroing), slots 1..3 accumulate
+  {
+    const Ux<C> a0 = scaled(0, 0), b0 = ldb(0, 0);
+    ux_acc_new<C>(d, a0, b0);
+  }
+  {
+    const Ux<C> a1 = scaled(0, 1), b1 = ldb(0, 1);
+    ux_acc_new<C>(e, a1, b1);
+  }
 #pragma unroll 1
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 1; t < 4; ++t) {
     {
       const Ux<C> a0 = scaled(t, 0), b0 = ldb(t, 0);
       ux_acc<C>(d, a0, b0);
@@ -293,10 +369,16 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
   for (int k = 0; k < 2 * N; ++k) d[k] = d[k] + C::RX_BIAS_S6[k] - e[k];
   Ux2<C> r;
   r.c0 = ux_redc<C>(d);
-#pragma unroll
-  for (int k = 0; k < 2 * N; ++k) e[k] = 0;
+  {
+    const Ux<C> a0 = scaled(0, 0), b1 = ldb(0, 1);
+    ux_acc_new<C>(e, a0, b1);
+  }
+  {
+    const Ux<C> a1 = scaled(0, 1), b0 = ldb(0, 0);
+    ux_acc<C>(e, a1, b0);
+  }
 #pragma unroll 1
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 1; t < 4; ++t) {
     {
       const Ux<C> a0 = scaled(t, 0), b1 = ldb(t, 1);
       ux_acc<C>(e, a0, b1);
@@ -324,9 +406,7 @@ BGLS_HD Ux<C> to_ux(const Fp<C>& y) {
     s.v[i] = (u32)(two >> r) & RX_MASK;
   }
   u64 c[2 * N];
-#pragma unroll
-  for (int k = 0; k < 2 * N; ++k) c[k] = 0;
-  ux_acc<C>(c, s, ux_load<C>(C::RX_TO));
+  ux_acc_new<C>(c, s, ux_load<C>(C::RX_TO));
   return ux_redc<C>(c);
 }
 template <class C>
@@ -492,20 +572,23 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
   (void)sizeof(MontAcc<C, BUDGET>);
   // t[i .. i+N) are the live columns of row i (column k is dead once row k is done): written as one array of 2 N columns so
   // that no value ever moves between registers -- a shifting window of N + 1 columns cost a v_mov_b64 per column and row.
+  // Columns are written for the first time by the products themselves (row 0: all of them, row i: its last one), never zeroed.
   i64 t[2 * N];
-#pragma unroll
-  for (int k = 0; k < 2 * N; ++k) t[k] = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     i32 r[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) r[k] = row(k, i);
     // column 0 first: the row's Montgomery factor m depends on it and is ready by the time the row's other products are issued
+    if (i == 0) rx_muls(t[0], r[0], cols[0][0]);
+    else rx_macs(t[i], r[0], cols[0][0]);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) rx_macs(t[i], r[k], cols[k][0]);
+    for (int k = 1; k < NP; ++k) rx_macs(t[i], r[k], cols[k][0]);
     const i32 m = (i32)(((u32)t[i] * C::RX_NP) & RX_MASK);
+    if (i == 0) rx_rows_new<N - 1, 1>(t + 1, r[0], cols[0] + 1);
+    else rx_rows_new<N - 1, 2>(t + i + 1, r[0], cols[0] + 1);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) rx_rows<N - 1, false>(t + i + 1, r[k], cols[k] + 1);
+    for (int k = 1; k < NP; ++k) rx_rows<N - 1, false>(t + i + 1, r[k], cols[k] + 1);
     rx_rows<N, true>(t + i, m, (const i32*)C::RX_P);
     t[i + 1] += t[i] >> 28;
   }
@@ -513,9 +596,9 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
 #pragma unroll
   for (int k = N; k < 2 * N - 1; ++k) {
     r.v[k - N] = (i32)((u32)t[k] & RX_MASK);
-    t[k + 1] += t[k] >> 28;
+    if (k + 1 < 2 * N - 1) t[k + 1] += t[k] >> 28;
   }
-  r.v[N - 1] = (i32)t[2 * N - 1];
+  r.v[N - 1] = (i32)(t[2 * N - 2] >> 28);     // column 2 NL - 1 receives this carry and nothing else
   return r;
 }
 

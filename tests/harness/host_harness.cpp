@@ -9,6 +9,7 @@
 #include "../../bgls_amd/csrc/wire.hpp"
 #include "../../bgls_amd/csrc/r28.hpp"
 #include "../../bgls_amd/csrc/rx_pair.hpp"
+#include "../../bgls_amd/csrc/rx_pow.hpp"
 
 namespace bgls { int g_rx_overflow = 0; }
 
@@ -320,6 +321,46 @@ static int rx_conv(int dir, uint8_t* bytes, u32* limbs) {
 }
 extern "C" int ht_rx_conv(int curve, int dir, uint8_t* bytes, u32* limbs) {
   return curve == 0 ? rx_conv<BN254>(dir, bytes, limbs) : rx_conv<BLS381>(dir, bytes, limbs);
+}
+
+// ---- rx_pow.hpp: sqrt exponent powers on the carry-free limbs.  op 0: sx_sqr of raw limbs (in/out: NL limbs, signed
+// top limb) -- the unit test feeds worst-case limbs; op 1: a^((p+1)/4) of canonical bytes, sliding windows W = 3 and 4 against
+// fp_sqrt_candidate (returns 0 when both agree, writes the result); op 2: a^((p-3)/4) against fp_pow_w4.
+template <class C>
+static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
+  constexpr int N = C::RX_NL;
+  g_rx_overflow = 0;
+  if (op == 0) {
+    Sx<C, SX_T> a;
+    for (int i = 0; i < N; ++i) a.v[i] = limbs[i];
+    const Sx<C, SX_T> r = sx_sqr<C>(a);
+    for (int i = 0; i < N; ++i) limbs[i] = r.v[i];
+    return g_rx_overflow ? -3 : 0;
+  }
+  const Fp<C> a = fp_to_mont<C>(fp_from_be<C>(bytes));
+  i32 tab[8 * N];
+  auto ld = [&](int e, int i) { return tab[e * N + i]; };
+  auto st = [&](int e, int i, i32 v) { tab[e * N + i] = v; };
+  u32 e[C::L];
+  for (int k = 0; k < C::L; ++k) e[k] = C::EXP_SQRT[k];
+  if (op == 2) e[0] -= 1u;
+  auto word = [&](int k) { return e[k]; };
+  const Sx<C, SX_T> x = ux_to_sx<C>(to_ux<C>(a));
+  const Sx<C, SX_T> r3 = sx_pow_sw<C, 3, 32 * C::L>(x, word, ld, st);
+  const Sx<C, SX_T> r4 = sx_pow_sw<C, 4, 32 * C::L>(x, word, ld, st);
+  auto back = [&](const Sx<C, SX_T>& v) {
+    Ux<C> u;
+    for (int i = 0; i < N; ++i) u.v[i] = (u32)v.v[i];
+    return from_ux<C>(u);
+  };
+  const Fp<C> want = op == 1 ? fp_sqrt_candidate<C>(a) : fp_pow_w4<C, C::L>(a, e);
+  fp_to_be<C>(bytes, fp_from_mont<C>(back(r4)));
+  if (g_rx_overflow) return -3;
+  for (int i = 0; i < N; ++i) if (r3.v[i] < 0 || r4.v[i] < 0 || (i + 1 < N && ((u32)r3.v[i] > RX_MASK || (u32)r4.v[i] > RX_MASK))) return -2;
+  return (fp_eq<C>(back(r3), want) ? 0 : 1) + (fp_eq<C>(back(r4), want) ? 0 : 2);
+}
+extern "C" int ht_rx_pow(int curve, int op, uint8_t* bytes, i32* limbs) {
+  return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs);
 }
 
 // ---- rx_pair.hpp: the whole sequence of point steps of one Miller loop on an emulated lane pair, every line (as handed

@@ -170,3 +170,31 @@ def test_key_sum_on_carry_free_limbs(host_harness, cname, cid):
     bad = bytearray(G.g2_bytes(base[0])); bad[-1] ^= 1
     got, ref = (ctypes.c_uint8 * (4 * n_fp))(), (ctypes.c_uint8 * (4 * n_fp))()
     assert host_harness.ht_rx_sum(cid, (ctypes.c_uint8 * len(bad)).from_buffer_copy(bytes(bad)), 1, got, ref) == -2
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_sqrt_powers_on_carry_free_limbs(host_harness, cid):
+    """rx_pow.hpp: the symmetric squaring on worst-case limbs stays inside the 64-bit columns; the sliding-window
+    powers (W = 3, 4) give the same field elements as fp.hpp's exponentiations (hash-to-G1 square roots)."""
+    c, p, N, Rp = geom(cid)
+    Rinv = pow(Rp, -1, p)
+    rnd = random.Random(77 + cid)
+    host_harness.ht_rx_pow.restype = ctypes.c_int
+    top_p = p >> (W * (N - 1))
+    cases = [[MASK] * (N - 1) + [2 * top_p + 1], limbs_of(p - 1, N), limbs_of(0, N), limbs_of(1, N)]
+    cases += [limbs_of(rnd.randrange(2 * p), N) for _ in range(8)]
+    for l in cases:
+        lim = (ctypes.c_int32 * N)(*l)
+        assert host_harness.ht_rx_pow(cid, 0, None, lim) == 0, "column overflow in the squaring"
+        out = list(lim)
+        assert all(0 <= x <= MASK for x in out[:-1])
+        v = val(l)
+        got = sum(x << (W * i) for i, x in enumerate(out))
+        assert got % p == v * v * Rinv % p and 0 <= got < v * v // Rp + p + 1
+    n = 32 if cid == 0 else 48
+    for op, e in [(1, (p + 1) // 4), (2, (p - 3) // 4)]:
+        for x in [0, 1, 2, p - 1, rnd.randrange(p), rnd.randrange(p), rnd.randrange(p)]:
+            buf = (ctypes.c_uint8 * n)(*x.to_bytes(n, "big"))
+            rc = host_harness.ht_rx_pow(cid, op, buf, None)
+            assert rc == 0, (op, x, rc)
+            assert int.from_bytes(bytes(buf), "big") == pow(x, e, p)
