@@ -293,16 +293,58 @@ static void g2_add(g2a* r, const g2a* P, const g2a* Q) {
   g2a o; o.inf = 0; f2_sqr(&o.x, &m); f2_sub(&o.x, &o.x, &P->x); f2_sub(&o.x, &o.x, &Q->x);
   f2_sub(&t, &P->x, &o.x); f2_mul(&o.y, &m, &t); f2_sub(&o.y, &o.y, &P->y); *r = o;
 }
-static void g1_mul(g1a* r, const g1a* P, const uint64_t* k, int nbits) {
-  g1a acc; memset(&acc, 0, sizeof acc); acc.inf = 1;
-  for (int i = nbits - 1; i >= 0; i--) { g1_add(&acc, &acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) g1_add(&acc, &acc, P); }
-  *r = acc;
-}
-static void g2_mul(g2a* r, const g2a* P, const uint64_t* k, int nbits) {
-  g2a acc; memset(&acc, 0, sizeof acc); acc.inf = 1;
-  for (int i = nbits - 1; i >= 0; i--) { g2_add(&acc, &acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) g2_add(&acc, &acc, P); }
-  *r = acc;
-}
+/* k P by double-and-add in Jacobian coordinates (a = 0), ONE inversion at the end: the point is the one the affine chord-and-
+ * tangent chain gives (curves/curve.go:190-214 scales through the curve library), 30x cheaper than an inversion per step.
+ * F: field type, PA: affine point type, the f_* are that field's operations. */
+#define JAC_MUL(NAME, F, PA, f_add, f_sub, f_mul, f_sqr, f_inv, f_is_zero)                                                  \
+  static void NAME(PA* r, const PA* P, const uint64_t* k, int nbits) {                                                      \
+    F X, Y, Z, A, B, C, D, E, T, U; int inf = 1;                                                                            \
+    if (P->inf) { memset(r, 0, sizeof *r); r->inf = 1; return; }                                                            \
+    for (int i = nbits - 1; i >= 0; i--) {                                                                                  \
+      if (!inf) {                                                                                                           \
+        if (f_is_zero(&Y)) inf = 1;                                                                                         \
+        else {  /* dbl-2009-l */                                                                                            \
+          f_sqr(&A, &X); f_sqr(&B, &Y); f_sqr(&C, &B);                                                                      \
+          f_add(&D, &X, &B); f_sqr(&D, &D); f_sub(&D, &D, &A); f_sub(&D, &D, &C); f_add(&D, &D, &D);                        \
+          f_add(&E, &A, &A); f_add(&E, &E, &A);                                                                             \
+          f_mul(&Z, &Y, &Z); f_add(&Z, &Z, &Z);                                                                             \
+          f_sqr(&T, &E); f_sub(&T, &T, &D); f_sub(&X, &T, &D);                                                              \
+          f_add(&C, &C, &C); f_add(&C, &C, &C); f_add(&C, &C, &C);                                                          \
+          f_sub(&T, &D, &X); f_mul(&T, &E, &T); f_sub(&Y, &T, &C);                                                          \
+        }                                                                                                                   \
+      }                                                                                                                     \
+      if ((k[i >> 6] >> (i & 63)) & 1) {                                                                                    \
+        if (inf) { X = P->x; Y = P->y; memset(&Z, 0, sizeof Z); f_one_of(&Z); inf = 0; }                                    \
+        else {  /* madd-2007-bl */                                                                                          \
+          f_sqr(&A, &Z); f_mul(&B, &P->x, &A); f_mul(&C, &P->y, &Z); f_mul(&C, &C, &A);                                     \
+          f_sub(&D, &B, &X); f_sub(&E, &C, &Y);                                                                             \
+          if (f_is_zero(&D)) {                                                                                              \
+            if (f_is_zero(&E)) {   /* same point: double (affine input, Z = 1 after this) */                                \
+              PA d2; NAME##_aff_dbl(&d2, P); X = d2.x; Y = d2.y; memset(&Z, 0, sizeof Z); f_one_of(&Z); inf = d2.inf;       \
+            } else inf = 1;                                                                                                 \
+          } else {                                                                                                          \
+            f_add(&E, &E, &E); f_sqr(&T, &D); f_add(&U, &T, &T); f_add(&U, &U, &U);       /* r = 2(S2-Y1), HH, I = 4 HH */ \
+            F J, V; f_mul(&J, &D, &U); f_mul(&V, &X, &U);                                                                   \
+            f_add(&Z, &Z, &D); f_sqr(&Z, &Z); f_sub(&Z, &Z, &A); f_sub(&Z, &Z, &T);                                         \
+            f_sqr(&X, &E); f_sub(&X, &X, &J); f_sub(&X, &X, &V); f_sub(&X, &X, &V);                                         \
+            f_sub(&V, &V, &X); f_mul(&V, &E, &V); f_mul(&J, &Y, &J); f_add(&J, &J, &J); f_sub(&Y, &V, &J);                  \
+          }                                                                                                                 \
+        }                                                                                                                   \
+      }                                                                                                                     \
+    }                                                                                                                       \
+    if (inf || f_is_zero(&Z)) { memset(r, 0, sizeof *r); r->inf = 1; return; }                                              \
+    f_inv(&A, &Z); f_sqr(&B, &A); f_mul(&r->x, &X, &B); f_mul(&B, &B, &A); f_mul(&r->y, &Y, &B); r->inf = 0;                \
+  }
+static void fp_one_of(fp* r) { fp_set(r, ONE); }
+static void f2_one_of(fp2* r) { memset(r, 0, sizeof *r); fp_set(&r->c0, ONE); }
+static void g1_mul_aff_dbl(g1a* r, const g1a* P) { g1_add(r, P, P); }
+static void g2_mul_aff_dbl(g2a* r, const g2a* P) { g2_add(r, P, P); }
+#define f_one_of fp_one_of
+JAC_MUL(g1_mul, fp, g1a, fp_add, fp_sub, fp_mul, fp_sqr, fp_inv, fp_is_zero)
+#undef f_one_of
+#define f_one_of f2_one_of
+JAC_MUL(g2_mul, fp2, g2a, f2_add, f2_sub, f2_mul, f2_sqr, f2_inv, f2_is_zero)
+#undef f_one_of
 static int g1_read(g1a* p, const uint8_t* b) {
   int z = 1; for (int i = 0; i < 2 * FPB; i++) z &= (b[i] == 0);
   p->inf = z; return fp_read(&p->x, b) & fp_read(&p->y, b + FPB);
@@ -498,7 +540,8 @@ static void* pair_worker(void* arg) {
 }
 static int run_pairs(fp12* out, const uint8_t* g1s, const uint8_t* g2s, const uint8_t* blob, const uint64_t* off, size_t n,
                      int hash_first, int faithful, int threads) {
-  if (threads < 1) threads = 1; if (threads > 256) threads = 256;
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
   job_t* jobs = (job_t*)calloc((size_t)threads, sizeof(job_t)); pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
   for (int t = 0; t < threads; t++) {
     job_t j = {g1s, g2s, blob, off, n, hash_first, faithful, t, threads}; jobs[t] = j;
