@@ -423,10 +423,10 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     shared_launch_s = med / launches_per_step
     cname = "BN254" if cid == 0 else "BLS381"
     # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 unless the launch is
-    # 61 441 .. 65 536 pairings: k_miller_ab64 one at a time; in flight k_miller_s60 (alt-bn128) / k_miller_x60 (BLS12-381)
+    # 61 441 .. 65 536 pairings with one verification in flight (the exclusive measurement): k_miller_ab64
     legacy_alone = 61440 < n <= 65536
     kernel_excl = "k_miller_ab64<%s>" % cname if legacy_alone else "k_miller_x60<%s>" % cname
-    kernel_timed = ("k_miller_s60<BN254>" if cid == 0 else "k_miller_x60<BLS381>") if (use_tp and legacy_alone) else kernel_excl
+    kernel_timed = "k_miller_x60<%s>" % cname if use_tp else kernel_excl
     if prepared:
         kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])
@@ -780,7 +780,7 @@ def main():
             small_n = min(1 << 16, args.n)
             for c_, i_ in ((cid, inst), (other, oinst)):
                 i_["n_local"] = small_n
-                records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 20, 3, args.reps, args.in_flight, tp, CNAME[c_] + " 2^16")
+                records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 32, 8, args.reps, max(args.in_flight, 8), tp, CNAME[c_] + " 2^16")
                 i_["n_local"] = i_["n"]
             for c_, i_ in ((cid, inst), (other, oinst)):      # the same batches against prepared key sets (secondary records, labelled)
                 records["%s_%d_prepared_keys" % (CNAME[c_], args.n)] = bench_aggregate(lib, dev, i_, args.n, 0, 1, max(2, args.steps // 2), 1, args.reps, args.in_flight,

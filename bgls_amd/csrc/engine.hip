@@ -412,11 +412,10 @@ struct Engine {
     // k_miller_x60 (60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes to
     // the epilogue kernel) is the default above the latency shape.  One exception: 1024 blocks are resident at a time, and a
     // launch of slightly more (61 441 .. 65 536 pairings, e.g. exactly 2^16) pays a second, nearly empty round of blocks
-    // where the 32-bit kernels' 1024 blocks of 64 pairings need one: those batches keep k_miller_ab64 -- and k_miller_s60 on
-    // alt-bn128 in throughput mode (measured with four 2^16 verifications in flight: 5.5 vs 6.4 ms a step); BLS12-381 in
-    // throughput mode takes k_miller_x60 also there (10.1 vs 11.8 ms: the neighbours fill the second round).
-    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX &&
-                          (npairs <= 61440 || npairs > 65536 || (throughput_mode() && C::CURVE_ID != 0));
+    // where the 32-bit kernels' 1024 blocks of 64 pairings need one: a verification with the machine to itself keeps
+    // k_miller_ab64 there.  In throughput mode the neighbours' blocks fill the second round and k_miller_x60 stays (measured
+    // at 2^16 with 8 / 16 verifications in flight: alt-bn128 4.91 / 4.76 ms a step against 4.99 / 5.02).
+    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX && (npairs <= 61440 || npairs > 65536 || throughput_mode());
     if ((miller_shape() == 4 || x60_auto) && npairs >= 1) {
       // role / priority mode: consumers placed by SIMD; the producers get issue priority only when the whole batch is one round of
       // resident blocks with the machine to itself (there the slowest block is the launch: 5.8 instead of 7.4 ms for 61 440
