@@ -182,6 +182,70 @@ BGLS_FN Jac<F> jac_mul(const Aff<F>& p, const u32* k, int nbits) {
   return r;
 }
 
+// k * P for a per-lane scalar of up to 256 bits (Point.Mul at the seam, curves/curve.go:190-214: the reference hands the
+// scalar to the curve library): width-4 non-adjacent form.  One non-zero digit in five positions on average, digits in
+// {+-1, +-3, +-5, +-7}: nbits doublings + ~nbits / 5 additions against nbits / 2 for double-and-add -- a sixth fewer field
+// products on a 256-bit scalar.  Table P, 3P, 5P, 7P in Jacobian form (entry 0 is used through the cheaper mixed addition);
+// the digits are recoded LSB-first into private memory and consumed MSB-first.  Same point as jac_mul (the group law does not
+// care about the chain), so every golden vector stands.
+template <class F>
+BGLS_FN Jac<F> jac_mul_wnaf(const Aff<F>& p, const u32* k, int nbits) {
+  if (nbits <= 16 || p.inf) return jac_mul<F>(p, k, nbits);
+  signed char d[260];
+  u32 w[9];
+  const int nl = (nbits + 31) >> 5;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) w[j] = j < nl ? k[j] : 0u;
+  if (nbits & 31) w[nl - 1] &= (1u << (nbits & 31)) - 1u;
+  int len = 0;
+  for (;;) {
+    u32 any = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) any |= w[j];
+    if (!any) break;
+    int dg = 0;
+    if (w[0] & 1u) {
+      dg = (int)(w[0] & 15u);
+      if (dg > 8) dg -= 16;
+      // w -= dg
+      if (dg > 0) {
+        w[0] -= (u32)dg;                       // the low four bits hold at least dg: no borrow
+      } else {
+        u32 c = (u32)(-dg);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const u32 t = w[j] + c;
+          c = t < c ? 1u : 0u;
+          w[j] = t;
+        }
+      }
+    }
+    d[len++] = (signed char)dg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (w[j] >> 1) | (w[j + 1] << 31);
+    w[8] >>= 1;
+  }
+  Jac<F> tab[4];
+  tab[0] = jac_from_aff<F>(p);
+  const Jac<F> p2 = jac_dbl<F>(tab[0]);
+  tab[1] = jac_add_aff<F>(p2, p);
+  tab[2] = jac_add<F>(tab[1], p2);
+  tab[3] = jac_add<F>(tab[2], p2);
+  Jac<F> r = jac_inf<F>();
+  for (int i = len - 1; i >= 0; --i) {
+    r = jac_dbl<F>(r);
+    const int dg = d[i];
+    if (dg == 1) r = jac_add_aff<F>(r, p);
+    else if (dg == -1) r = jac_add_aff<F>(r, aff_neg<F>(p));
+    else if (dg != 0) {
+      Jac<F> q = tab[(dg > 0 ? dg : -dg) >> 1];
+      if (dg < 0) q.Y = F::neg(q.Y);
+      r = jac_add<F>(r, q);
+    }
+  }
+  return r;
+}
+
 // ---- G2 subgroup membership ------------------------------------------------------------------------------------------
 // The reference validates G2 inputs when a Point is constructed: alt-bn128 MakeG2Point / UnmarshalG2
 // (curves/altbn128.go:157-179,329-376) reach upstream bn256's G2.Unmarshal, which rejects twist points outside the

@@ -90,6 +90,19 @@ def test_miller_final_exp_and_groups_against_golden(host_harness, curve):
                 o = out(size)
                 lib.ht_group_op(cid, base + 1, B(bytes.fromhex(row["pt"])), None, B(k.to_bytes(32, "big")), o)
                 assert bytes(o).hex() == row["out"], k
+                w = out(size)                  # the scale kernels' chain (width-4 NAF): same golden point
+                lib.ht_group_op(cid, base + 4, B(bytes.fromhex(row["pt"])), None, B(k.to_bytes(32, "big")), w)
+                assert bytes(w).hex() == row["out"], k
+        # scalars that stress the recoding: runs of ones (carries across limbs), isolated top bits, all digits negative
+        pt = bytes.fromhex(v[key][0]["pt"])
+        rnd = random.Random(base + cid)
+        ks = [(1 << 256) - 1, (1 << 255) + 1, 1 << 255, (1 << 200) - (1 << 31), 0x77777777 << 100, 0x99999999 << 64 | 0x9, 65537, (1 << 17) - 1]
+        ks += [rnd.getrandbits(256) for _ in range(6)] + [rnd.getrandbits(130) for _ in range(3)]
+        for k in ks:
+            o, w = out(size), out(size)
+            lib.ht_group_op(cid, base + 1, B(pt), None, B(k.to_bytes(32, "big")), o)
+            lib.ht_group_op(cid, base + 4, B(pt), None, B(k.to_bytes(32, "big")), w)
+            assert bytes(o) == bytes(w), hex(k)
     for base, key, size in ((0, "sum_g1", 2 * n), (10, "sum_g2", 4 * n)):
         pts = [bytes.fromhex(x) for x in v[key]["pts"]]
         o = out(size)
