@@ -198,15 +198,15 @@ int miller_shape() {
   return v;
 }
 
-// G2 key sums on the carry-free 28-bit-limb form (k_sumx.hip).  Measured (2^20 keys, main pass + tree): BLS12-381 1.20 vs
-// 1.30 ms -- taken; alt-bn128 0.66 vs 0.60 ms -- NOT taken: one lane cannot hold the three piles of a Karatsuba Fp2 product
-// next to a Jacobian point, so the carry-free form needs 6 NL^2 multiplier instructions per product (10 limbs) where the
-// 32-bit form needs 3 (8 limbs), and with no long dot product to amortise a reduction over that outweighs its cheaper
-// instruction mix.  BGLS_SUMX=1 / 0 forces it on / off for both curves (A/B measurements).
+// G2 key sums on the carry-free 28-bit-limb form.  Mode 2 (default): one key sum partial per LANE PAIR (k_sumpair.hip,
+// rx_jacpair.hpp: half of every Fp2 value per lane, three waves per SIMD).  Mode 1: one partial per lane (k_sumx.hip; measured
+// at 2^20 keys, main pass + tree: BLS12-381 1.20 vs 1.30 ms for the 32-bit form, alt-bn128 0.66 vs 0.60 ms -- one lane cannot
+// hold the three piles of a Karatsuba Fp2 product next to a Jacobian point).  Mode 0: the 32-bit form (k_points.hip k_sum_main).
+// BGLS_SUMX=0 / 1 / 2 forces a mode for both curves (A/B measurements).
 template <class C>
-bool sumx_enabled() {
-  static const int v = [] { const char* e = getenv("BGLS_SUMX"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  return v < 0 ? C::CURVE_ID != 0 : v == 1;
+int sum_mode() {
+  static const int v = [] { const char* e = getenv("BGLS_SUMX"); return e ? atoi(e) : -1; }();
+  return v < 0 || v > 2 ? 2 : v;
 }
 
 #ifdef BGLS_DEV
@@ -603,7 +603,8 @@ struct Engine {
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (nsets * P + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (nsets * P / 2 + 2) * JB, &jb))) return rc;
-    if (group == BGLS_G2 && sumx_enabled<C>()) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    if (group == BGLS_G2 && sum_mode<C>() == 2) kl::sumpairseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
+    else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     else kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     void *a = ja, *b = jb;
     size_t p = P, cnt = nsets * P;
@@ -638,16 +639,23 @@ struct Engine {
     // are folded 64 at a time
     size_t waves = (n + 255) / 256;
     if (waves > 2048) waves = 2048;
+    const bool pairs = group == BGLS_G2 && sum_mode<C>() == 2;
+    if (pairs) {                      // one partial per lane pair: three waves per SIMD resident (3072), >= ~4 keys per pair
+      waves = (n + 127) / 128;
+      if (waves > 3072) waves = 3072;
+    }
+    const size_t partials = pairs ? waves * 32 : waves * 64;
     void *ja, *jb;
     int rc;
     Scope sc(c, st, ST_SUM);
     const size_t JB = kl::jac_bytes<C>(group);
-    if ((rc = c.get(WS_JAC_A, (waves * 64 + 1) * JB, &ja))) return rc;
-    if ((rc = c.get(WS_JAC_B, (waves * 32 + 2) * JB, &jb))) return rc;
-    if (group == BGLS_G2 && sumx_enabled<C>()) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags);     // carry-free limbs (rx_jac.hpp)
+    if ((rc = c.get(WS_JAC_A, (partials + 1) * JB, &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (partials / 2 + 2) * JB, &jb))) return rc;
+    if (pairs) kl::sumpair_main<C>(st, parsed, d_pts, n, (unsigned)partials, ja, d_flags);                                  // lane pairs, carry-free limbs (rx_jacpair.hpp)
+    else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags); // one lane, carry-free limbs (rx_jac.hpp)
     else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
     void *a = ja, *b = jb;
-    size_t cnt = waves * 64;
+    size_t cnt = partials;
     while (cnt > 1) {
       // halving launches while there is parallelism to speak of, then 64 -> 1 per wave with lane shuffles
       if (group == BGLS_G2 && cnt <= 8192) {

@@ -21,6 +21,8 @@ template <class C> void sumseg_main(hipStream_t st, int group, const uint8_t* pt
 // ---- k_sumx.hip   (G2 key sums on carry-free limbs, rx_jac.hpp)
 template <class C> void sumx_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
 template <class C> void sumxseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
+template <class C> void sumpair_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned partials, void* out, uint32_t* flags);
+template <class C> void sumpairseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
 template <class C> void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out);
 template <class C> void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out);
 template <class C> void sum_coop(hipStream_t st, const void* in, size_t n, void* out);        // G2, one wave per addition (jac_coop.hpp)

@@ -515,3 +515,69 @@ static int rx_sum(const uint8_t* pts, int n, uint8_t* out, uint8_t* out_ref) {
 extern "C" int ht_rx_sum(int curve, const uint8_t* pts, int n, uint8_t* out, uint8_t* out_ref) {
   return curve == 0 ? rx_sum<BN254>(pts, n, out, out_ref) : rx_sum<BLS381>(pts, n, out, out_ref);
 }
+
+// ---- rx_jacpair.hpp: the same key sum on an emulated LANE PAIR (two lock-stepped threads; jacp_madd over the wire-format
+// points, in order, and once more through the resident Montgomery form).  out = the sum's wire bytes as the two lanes write
+// them (sxp_to_mont halves of the Jacobian partial).  Returns 0, -2 bad point, -3 column overflow, -5 the two forms differ.
+#include "../../bgls_amd/csrc/rx_jacpair.hpp"
+template <class C>
+struct RxSumPair {
+  const uint8_t* pts;
+  int n;
+  Fp<C> part[2][6];            // [form][X.c0 X.c1 Y.c0 Y.c1 Z.c0 Z.c1]
+  bool inf[2];
+  int bad = 0;
+  void lane(int l) {
+    tl_pair_lane = l;
+    const bool odd = l == 1;
+    for (int form = 0; form < 2; ++form) {
+      JacP<C> acc = jacp_inf<C>();
+      for (int i = 0; i < n; ++i) {
+        AffP<C> q;
+        const uint8_t* b = pts + (size_t)i * 4 * C::FP_BYTES;
+        if (form == 0) {
+          const bool ok = affp_from_bytes<C>(q, b, odd);
+          if (!(affp_on_curve<C>(q, odd) && ok)) bad = 1;
+        } else {
+          Aff<F2<C>> a;
+          g2_from_bytes<C>(a, b);
+          q = affp_from_mont<C>(a, odd);
+        }
+        acc = jacp_madd<C>(acc, q, odd);
+      }
+      inf[form] = acc.inf;
+      if (!acc.inf) {
+        part[form][0 + l] = sxp_to_mont<C>(acc.X);
+        part[form][2 + l] = sxp_to_mont<C>(acc.Y);
+        part[form][4 + l] = sxp_to_mont<C>(acc.Z);
+      }
+    }
+  }
+};
+template <class C>
+static int rx_sumpair(const uint8_t* pts, int n, uint8_t* out) {
+  typedef F2<C> F;
+  g_rx_overflow = 0;
+  g_pair_cnt.store(0);
+  RxSumPair<C> run;
+  run.pts = pts;
+  run.n = n;
+  std::thread t1([&] { run.lane(1); });
+  run.lane(0);
+  t1.join();
+  if (run.bad) return -2;
+  if (g_rx_overflow) return -3;
+  Aff<F> got[2];
+  for (int form = 0; form < 2; ++form) {
+    Jac<F> j = jac_inf<F>();
+    if (!run.inf[form]) j = {{run.part[form][0], run.part[form][1]}, {run.part[form][2], run.part[form][3]}, {run.part[form][4], run.part[form][5]}};
+    got[form] = jac_to_aff<F>(j);
+  }
+  uint8_t other[4 * 48];
+  g2_to_bytes<C>(out, got[0]);
+  g2_to_bytes<C>(other, got[1]);
+  return memcmp(out, other, 4 * C::FP_BYTES) ? -5 : 0;
+}
+extern "C" int ht_rx_sumpair(int curve, const uint8_t* pts, int n, uint8_t* out) {
+  return curve == 0 ? rx_sumpair<BN254>(pts, n, out) : rx_sumpair<BLS381>(pts, n, out);
+}
