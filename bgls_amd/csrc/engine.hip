@@ -538,7 +538,10 @@ struct Engine {
     HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
     {
       Scope sc(c, st, ST_FINAL);
-      kl::final36<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      // finalx.hpp: the same 36-lane split on the carry-free limbs (BGLS_FINALX=0 keeps the 32-bit form of finalexp.hpp: A/B runs)
+      static const bool finalx = [] { const char* e = getenv("BGLS_FINALX"); return !(e && e[0] == '0'); }();
+      if (finalx) kl::finalx<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      else kl::final36<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
     }
     HIPCHK(hipGetLastError());
     c.h_res[0] = c.h_res[1] = c.h_res[2] = 0;

@@ -1,0 +1,265 @@
+// Latency-oriented final exponentiation on the carry-free 28-bit limbs: ONE Fp12 value, 36 lanes of each of TWO waves.
+//
+// Same job and same 36-lane split as finalexp.hpp (the final exponentiation happens once per verification, bgls/bgls.go:115-118
+// compares the product of ALL pairings with 1: a serial chain of ~300 Fp12 products that no batch dimension hides; lane 6j + t
+// computes term t of output coefficient j), different arithmetic: on a lone wave a 32-bit-limb product is a chain of dependent
+// multiply-adds and carries (~40 clocks per limb product, nothing to interleave with), while the rows of a carry-free product
+// are NL independent multiplier instructions into 64-bit columns that issue back to back.  Lane 6j + t of wave h computes half h
+// (real / imaginary) of the Fp2 product a_t b_(j-t) INCLUDING its reduction (two limb products, one reduction: sx_montr), so what
+// the lanes exchange through LDS are reduced values (NL limbs), not double-width piles, and the six terms of a coefficient are
+// added limb-wise by twelve lanes (coefficient, half) that also carry-normalise and form the xi multiple the next product's wrapped
+// terms need.  The block is 128 threads; the stages of a product are separated by block barriers.
+//
+// Squarings are plain products here: the Granger-Scott formulas add 2 z to three times a product without a reduction in
+// between, and in a redundant (non-reduced) representation that recurrence grows without bound; a product's 36 lanes already
+// run in parallel, so there is no latency to win from the cheaper formula.  Values: same Fp12 elements, same chains and exponent
+// (p^12 - 1) / r as pairing.hpp final_exp; the result leaves canonically, byte-identical to finalexp.hpp's.
+#pragma once
+#include "finalexp.hpp"
+#include "rx_jac.hpp"
+
+namespace bgls {
+
+template <class C>
+struct FX {
+  static constexpr int N = C::RX_NL;
+  static constexpr int HS = (N + 3) & ~3;             // one half (Fp), 16-byte granules
+  static constexpr int ES = 2 * HS;                   // one Fp2
+  static constexpr int SLOT = 12 * ES;                // 6 coefficients x {plain, xi multiple}
+  static constexpr int NSLOT = 16;
+  static constexpr int SCR = NSLOT * SLOT;
+  static constexpr int SCR_DW = 36 * ES;              // 36 lanes x one reduced Fp2 product
+  static constexpr int LDS_DW = SCR + SCR_DW;
+  static constexpr int LDS_BYTES = LDS_DW * 4;
+  __device__ static __forceinline__ int coef(int slot, int k, int xi) { return slot * SLOT + (2 * k + xi) * ES; }
+};
+
+template <class C>
+__device__ __forceinline__ Sx<C, SX_T> fx_ld(int off) {
+  extern __shared__ u32 lds[];
+  constexpr int N = C::RX_NL;
+  Sx<C, SX_T> r;
+  const uint4* p = reinterpret_cast<const uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) {
+    const uint4 v = p[k];
+    r.v[4 * k] = (i32)v.x; r.v[4 * k + 1] = (i32)v.y; r.v[4 * k + 2] = (i32)v.z; r.v[4 * k + 3] = (i32)v.w;
+  }
+  if constexpr (N % 4 == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(lds + off + (N & ~3));
+    r.v[N - 2] = (i32)v.x; r.v[N - 1] = (i32)v.y;
+  }
+  return r;
+}
+template <class C>
+__device__ __forceinline__ void fx_st(int off, const Sx<C, SX_T>& a) {
+  extern __shared__ u32 lds[];
+  constexpr int N = C::RX_NL;
+  uint4* p = reinterpret_cast<uint4*>(lds + off);
+#pragma unroll
+  for (int k = 0; k < N / 4; ++k) p[k] = make_uint4((u32)a.v[4 * k], (u32)a.v[4 * k + 1], (u32)a.v[4 * k + 2], (u32)a.v[4 * k + 3]);
+  if constexpr (N % 4 == 2) *reinterpret_cast<uint2*>(lds + off + (N & ~3)) = make_uint2((u32)a.v[N - 2], (u32)a.v[N - 1]);
+}
+template <class C>
+__device__ __forceinline__ X2<C, SX_T> fx_ld2(int off) {
+  return {fx_ld<C>(off), fx_ld<C>(off + FX<C>::HS)};
+}
+
+// this half of xi * (re + i im), carry-normalised: the real half is XI_RE re - im, the imaginary half XI_RE im + re
+// (alt-bn128: xi = 9 + i, BLS12-381: 1 + i).  `mine` is the own half, `other` the other one; tight in, tight out.
+template <class C>
+__device__ __forceinline__ Sx<C, SX_T> fx_mulxi_half(const Sx<C, SX_T>& mine, const Sx<C, SX_T>& other, bool is_im) {
+  constexpr int N = C::RX_NL;
+  const i32 sgn = is_im ? 1 : -1;
+  Sx<C, SX_T> r;
+  i64 c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    c += (i64)C::XI_RE * mine.v[i] + (i64)(sgn * other.v[i]);
+    r.v[i] = (i32)((u32)c & RX_MASK);
+    c >>= 28;
+  }
+  r.v[N - 1] = (i32)(c + (i64)C::XI_RE * mine.v[N - 1] + (i64)(sgn * other.v[N - 1]));
+  return r;
+}
+
+// write coefficient k of `slot` (plain) and its xi multiple; one lane holds both halves
+template <class C>
+__device__ __forceinline__ void fx_put(int slot, int k, const X2<C, SX_T>& v) {
+  typedef FX<C> E;
+  fx_st<C>(E::coef(slot, k, 0), v.c0);
+  fx_st<C>(E::coef(slot, k, 0) + E::HS, v.c1);
+  fx_st<C>(E::coef(slot, k, 1), fx_mulxi_half<C>(v.c0, v.c1, false));
+  fx_st<C>(E::coef(slot, k, 1) + E::HS, fx_mulxi_half<C>(v.c1, v.c0, true));
+}
+
+// dst <- a * b (all 128 threads must call).  Lane 6j + t of wave h: half h of the reduced product a_t * b_(j - t) (the xi multiple
+// of b's coefficient where the index wraps, w^6 = xi): real half a0 b0 - a1 b1, imaginary half a0 b1 + a1 b0, the same instruction
+// stream on both waves (column factors selected, the row factor's sign applied arithmetically).  Threads 2j + h of wave 0: half h
+// of coefficient j = the limb-wise sum of its six terms, carry-normalised, and its xi multiple (the other half comes from the
+// neighbour lane by a quad permute).
+// Magnitudes: a term is below (1 + eps) p, a coefficient below 6.1 p, its xi multiple below 61 p (alt-bn128) / 12.2 p
+// (BLS12-381); the next product of two such values is below 2^-3 p after the division by R' (R' / p = 2^26 / 2^11).
+template <class C>
+__device__ __noinline__ void fx_mul(int dst, int a, int b) {
+  typedef FX<C> E;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  if (lane < 36) {
+    const int j = lane / 6, t = lane % 6;
+    int k = j - t;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(a, t, 0));
+    const int yo = E::coef(b, k, wrap);
+    const Sx<C, SX_T> ya = fx_ld<C>(yo + (h ? E::HS : 0)), yb = fx_ld<C>(yo + (h ? 0 : E::HS));      // y0 y1 | y1 y0
+    const i32 sg = h ? 0 : -1;                                                                        // - a1 b1 on the real half
+    const i32* const cols[2] = {ya.v, yb.v};
+    const Sx<C, SX_T> p = sx_montr<C, 2, 2 * SX_T * SX_T>(cols, [&](int q, int i) { return q == 0 ? x.c0.v[i] : (x.c1.v[i] ^ sg) - sg; });
+    fx_st<C>(E::SCR + lane * E::ES + h * E::HS, p);
+  }
+  __syncthreads();
+  if (tid < 12) {
+    const int j = tid >> 1, hh = tid & 1;
+    const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
+    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
+    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
+    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
+    Sx<C, SX_T> other;
+#pragma unroll
+    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
+    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
+  }
+  __syncthreads();
+}
+
+template <class C>
+__device__ __forceinline__ void fx_conj(int dst, int a) {           // a^(p^6): w -> -w
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  if (lane < 24) {
+    const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
+    Sx<C, SX_T> v = fx_ld<C>(E::coef(a, k, xi) + h * E::HS);
+    if (k & 1) v = sx_neg<C>(v);
+    fx_st<C>(E::coef(dst, k, xi) + h * E::HS, v);
+  }
+  __syncthreads();
+}
+template <class C>
+__device__ __noinline__ void fx_frob(int dst, int a, int kk) {      // a^(p^kk), kk = 1..3
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  if (lane < 6) {
+    X2<C, SX_T> v = fx_ld2<C>(E::coef(a, lane, 0));
+    if (kk & 1) v.c1 = sx_neg<C>(v.c1);
+    if (lane != 0) {
+      const Fp2<C> g = gamma_const<C>(kk, lane);
+      const X2<C, SX_T> gx = {sx_from_mont<C>(g.c0), sx_from_mont<C>(g.c1)};
+      v = x2_mul<C>(v, gx);
+    }
+    fx_put<C>(dst, lane, v);
+  }
+  __syncthreads();
+}
+// dst <- a^-1 through norms (as finalexp.hpp fe_inv): four cooperative products, two Frobenius maps and ONE Fp2 inversion, taken
+// in the library's 32-bit form (binary Euclid) on the lanes that need it.  Uses FE_X, FE_Y5, FE_Y6 as scratch.
+template <class C>
+__device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  fx_conj<C>(sB, a);
+  fx_mul<C>(sN, a, sB);                   // N = a * conj(a): odd w-coefficients vanish
+  fx_frob<C>(sA, sN, 2);                  // N^(p^2)
+  fx_frob<C>(sB, sA, 2);                  // N^(p^4)
+  fx_mul<C>(sA, sA, sB);                  // M = N^(p^2) N^(p^4)
+  fx_mul<C>(sB, sN, sA);                  // Norm(N) in Fp2: only coefficient 0
+  if (lane < 6) {
+    const X2<C, SX_T> d = fx_ld2<C>(E::coef(sB, 0, 0));
+    const Fp2<C> dinv = f2_inv<C>(Fp2<C>{sx_to_mont<C>(d.c0), sx_to_mont<C>(d.c1)});
+    const X2<C, SX_T> di = {sx_from_mont<C>(dinv.c0), sx_from_mont<C>(dinv.c1)};
+    const X2<C, SX_T> m = fx_ld2<C>(E::coef(sA, lane, 0));
+    fx_put<C>(sA, lane, x2_mul<C>(m, di));                         // N^-1 (every lane touches its own coefficient only)
+  }
+  __syncthreads();
+  fx_conj<C>(sB, a);
+  fx_mul<C>(dst, sB, sA);
+}
+// dst <- a^e, public exponent with its top bit at nbits-1; dst != a
+template <class C>
+__device__ __noinline__ void fx_pow(int dst, int a, const u32* e, int nbits) {
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  if (lane < 24) {
+    const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
+    fx_st<C>(E::coef(dst, k, xi) + h * E::HS, fx_ld<C>(E::coef(a, k, xi) + h * E::HS));
+  }
+  __syncthreads();
+  for (int i = nbits - 2; i >= 0; --i) {
+    fx_mul<C>(dst, dst, dst);
+    if ((e[i >> 5] >> (i & 31)) & 1u) fx_mul<C>(dst, dst, a);
+  }
+}
+
+// slot FE_F <- FE_F ^ ((p^12 - 1) / r); slot numbers as in finalexp.hpp
+template <class C>
+__device__ __noinline__ void fx_final_exp() {
+  // easy part: (p^6 - 1)(p^2 + 1)
+  fx_conj<C>(FE_T, FE_F);
+  fx_inv<C>(FE_U, FE_F, FE_X, FE_Y5, FE_Y6);
+  fx_mul<C>(FE_T, FE_T, FE_U);
+  fx_frob<C>(FE_U, FE_T, 2);
+  fx_mul<C>(FE_F, FE_U, FE_T);
+  if constexpr (C::CURVE_ID == 0) {
+    // hard part, y0..y6 vectorial chain (pairing.hpp final_exp)
+    fx_pow<C>(FE_A, FE_F, C::U_ABS, C::U_BITS);     // ft1
+    fx_pow<C>(FE_B, FE_A, C::U_ABS, C::U_BITS);     // ft2
+    fx_pow<C>(FE_C, FE_B, C::U_ABS, C::U_BITS);     // ft3
+    fx_frob<C>(FE_Y0, FE_F, 1);
+    fx_frob<C>(FE_T, FE_F, 2);
+    fx_mul<C>(FE_Y0, FE_Y0, FE_T);
+    fx_frob<C>(FE_T, FE_F, 3);
+    fx_mul<C>(FE_Y0, FE_Y0, FE_T);
+    fx_conj<C>(FE_Y1, FE_F);
+    fx_frob<C>(FE_Y2, FE_B, 2);
+    fx_frob<C>(FE_Y3, FE_A, 1);
+    fx_conj<C>(FE_Y3, FE_Y3);
+    fx_frob<C>(FE_T, FE_B, 1);
+    fx_mul<C>(FE_Y4, FE_A, FE_T);
+    fx_conj<C>(FE_Y4, FE_Y4);
+    fx_conj<C>(FE_Y5, FE_B);
+    fx_frob<C>(FE_T, FE_C, 1);
+    fx_mul<C>(FE_Y6, FE_C, FE_T);
+    fx_conj<C>(FE_Y6, FE_Y6);
+    fx_mul<C>(FE_T0, FE_Y6, FE_Y6);
+    fx_mul<C>(FE_T0, FE_T0, FE_Y4);
+    fx_mul<C>(FE_T0, FE_T0, FE_Y5);
+    fx_mul<C>(FE_T1, FE_Y3, FE_Y5);
+    fx_mul<C>(FE_T1, FE_T1, FE_T0);
+    fx_mul<C>(FE_T0, FE_T0, FE_Y2);
+    fx_mul<C>(FE_T1, FE_T1, FE_T1);
+    fx_mul<C>(FE_T1, FE_T1, FE_T0);
+    fx_mul<C>(FE_T1, FE_T1, FE_T1);
+    fx_mul<C>(FE_T0, FE_T1, FE_Y1);
+    fx_mul<C>(FE_T1, FE_T1, FE_Y0);
+    fx_mul<C>(FE_T0, FE_T0, FE_T0);
+    fx_mul<C>(FE_F, FE_T1, FE_T0);
+  } else {
+    // (p^4 - p^2 + 1)/r = c (x + p)(x^2 + p^2 - 1) + 1,  c = (x-1)^2/3,  x < 0
+    fx_pow<C>(FE_A, FE_F, C::COFACTOR, C::COFACTOR_BITS);   // a = f^c
+    fx_pow<C>(FE_T, FE_A, C::U_ABS, C::U_BITS);
+    fx_conj<C>(FE_T, FE_T);                                 // a^x
+    fx_frob<C>(FE_U, FE_A, 1);
+    fx_mul<C>(FE_B, FE_T, FE_U);                            // b = a^x a^p
+    fx_pow<C>(FE_T, FE_B, C::U_ABS, C::U_BITS);
+    fx_conj<C>(FE_T, FE_T);                                 // b^x
+    fx_pow<C>(FE_U, FE_T, C::U_ABS, C::U_BITS);
+    fx_conj<C>(FE_U, FE_U);                                 // b^(x^2)
+    fx_frob<C>(FE_T, FE_B, 2);
+    fx_mul<C>(FE_U, FE_U, FE_T);
+    fx_conj<C>(FE_T, FE_B);
+    fx_mul<C>(FE_U, FE_U, FE_T);                            // d
+    fx_mul<C>(FE_F, FE_U, FE_F);
+  }
+}
+
+}  // namespace bgls

@@ -1,0 +1,50 @@
+// Final exponentiation of a verification on the carry-free limbs (finalx.hpp): product of `count` serialised partials, the
+// exponent (p^12 - 1) / r, comparison with one.  Same interface and results as k_final36 (k_tail.inc), which it replaces in
+// Engine::finish; own translation unit (both curves).
+#include "dev_common.hpp"
+#include "finalx.hpp"
+#include "launch.hpp"
+
+namespace bgls {
+
+template <class C>
+__global__ void __launch_bounds__(128) k_finalx(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict,
+                                               uint32_t* flags) {
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  const int order_pos[6] = {5, 2, 4, 1, 3, 0};
+  for (size_t k = 0; k < count; ++k) {
+    if (lane < 6) {
+      const uint8_t* b = partials + k * 12 * C::FP_BYTES + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+      const Fp<C> im = fp_from_be<C>(b), re = fp_from_be<C>(b + C::FP_BYTES);
+      if (fp_geq_p<C>(im) || fp_geq_p<C>(re)) atomicOr(flags, FLAG_ENC);
+      fx_put<C>(k == 0 ? FE_F : FE_X, lane, X2<C, SX_T>{sx_from_plain<C>(re), sx_from_plain<C>(im)});
+    }
+    __syncthreads();
+    if (k > 0) fx_mul<C>(FE_F, FE_F, FE_X);
+  }
+  if (do_final_exp) fx_final_exp<C>();
+  bool is_one = true;
+  if (lane < 6) {
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(FE_F, lane, 0));
+    const Fp2<C> v = {sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
+    is_one = lane == 0 ? f2_eq<C>(v, f2_one<C>()) : f2_is_zero<C>(v);
+    if (gt_out) {
+      uint8_t* o = gt_out + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+      fp_to_be<C>(o, fp_from_mont<C>(v.c1));
+      fp_to_be<C>(o + C::FP_BYTES, fp_from_mont<C>(v.c0));
+    }
+  }
+  const unsigned long long ball = __ballot(is_one);       // wave 0 holds the six coefficients (the other lanes vote "one")
+  if (lane == 0) verdict[0] = (ball == ~0ull) ? 1u : 0u;
+}
+
+namespace kl {
+template <class C>
+void finalx(hipStream_t st, const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict, uint32_t* flags) {
+  k_finalx<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(partials, count, do_final_exp, gt_out, verdict, flags);
+}
+template void finalx<BN254>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, uint32_t*, uint32_t*);
+template void finalx<BLS381>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, uint32_t*, uint32_t*);
+}  // namespace kl
+}  // namespace bgls

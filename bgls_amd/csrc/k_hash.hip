@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<
     out[i] = {fp_zero<C>(), fp_zero<C>(), true};
     return;
   }
-  Fp<C> r = fp_sqrt_candidate<C>(y2);
+  __shared__ i32 tab[rxp_lds_words<C>()];
+  Fp<C> r = rx_sqrt_pow<C, false>(y2, tab);       // carry-free limbs: a lone wave issues the independent limb products back to back
   if (bn_h2c_sign(msg, len)) r = fp_neg<C>(r);
   out[i] = {x, r, false};
 }

@@ -92,6 +92,7 @@ template <class C> void gen_lines(hipStream_t st, LineCoeffs<C>* table, int* nst
 template <class C> void reduce_coop(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out);
 template <class C> void w_to_bytes(hipStream_t st, const Fp2<C>* in, uint8_t* out);
 template <class C> void final36(hipStream_t st, const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict, uint32_t* flags);
+template <class C> void finalx(hipStream_t st, const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict, uint32_t* flags);
 template <class C>
 void miller_lat(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at, const LineCoeffs<C>* gen_lines, Fp2<C>* out,
                 uint32_t* flags);
