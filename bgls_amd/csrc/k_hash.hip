@@ -157,6 +157,66 @@ __global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<
   out[i] = {x, r, false};
 }
 
+// Small batches (n < 256: the reference's own n = 64 benchmark shape, the single message of a multi-signature): SIXTEEN lanes
+// per message.  With one lane per message a wave walks the counters for as long as its unluckiest message needs (7 tries
+// expected for 64 messages, ~50 us each on a lone wave: Keccak-f plus a Legendre symbol) and then hashes the sign byte; here
+// the first round tests counters 0..14 side by side while lane 15 hashes the 0xFF-prefixed sign input (the same instruction
+// stream: only the prefix byte differs), later rounds -- probability 2^-15 per message -- sixteen counters each.  The accepted
+// counter is the LOWEST one with x^3 + 3 a square, as in the sequential loop (curves/hash.go:53-77): same (x, y).
+__global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
+  typedef BN254 C;
+  const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
+  const size_t i = (size_t)blockIdx.x * 4 + grp;
+  const bool live = i < n;
+  const uint8_t* msg = mv.ptr(live ? i : 0);
+  const size_t len = mv.size(live ? i : 0);
+  __shared__ i32 tab[rxp_lds_words<C>()];
+  Fp<C> x, y2;
+  bool done = !live, mine = false;
+  u32 sign = 0;
+  u32 base = 0;
+  bool first = true;
+  for (;;) {
+    const u32 c = first ? (sub == 15 ? 255u : (u32)sub) : base + (u32)sub;
+    ByteSrc src;
+    src.msg = msg; src.len = len; src.pre[0] = (uint8_t)c; src.npre = 1; src.nsuf = 0;
+    u32 d[8];
+    keccak256_legacy(src, d);
+    Fp<C> h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
+    const Fp<C> xc = fp_to_mont<C>(h);
+    const Fp<C> yc = fp_add<C>(fp_mul<C>(fp_sqr<C>(xc), xc), fp_load<C>(C::B));
+    bool ok = fp_jacobi<C>(yc) >= 0 && c < 256u && !done;
+    if (first) {
+      sign = __shfl(d[7] & 1u, grp * 16 + 15);          // last digest byte of the 0xFF-prefixed hash, low bit
+      if (sub == 15) ok = false;                         // counter 255 is tried in its turn, not in round 0
+    }
+    const unsigned long long ball = __ballot(ok);
+    const u32 field = (u32)(ball >> (16 * grp)) & 0xFFFFu;
+    if (!done && field) {
+      mine = sub == (int)__builtin_ctz(field);
+      done = true;
+      if (mine) { x = xc; y2 = yc; }
+    }
+    base = first ? 15u : base + 16u;
+    first = false;
+    if (__ballot(!done) == 0ull || base >= 256u) break;
+  }
+  if (!done) {                                           // the reference would spin forever here (probability 2^-256)
+    if (sub == 0) {
+      atomicOr(flags, FLAG_HASH);
+      out[i] = {fp_zero<C>(), fp_zero<C>(), true};
+    }
+    return;
+  }
+  if (mine) {
+    Fp<C> r = rx_sqrt_pow<C, false>(y2, tab);
+    if (sign) r = fp_neg<C>(r);
+    out[i] = {x, r, false};
+  }
+}
+
 // BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
 // curves/hash.go:254-265), then exactly one square-root exponentiation -- and NO inversion.  The reference computes the
 // three Shallue-van de Woestijne candidates through 1 / (u v), u = t^2 + 1 + b, v = 3 t^2 (curves/hash.go:97-167); they
@@ -318,7 +378,7 @@ void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t m
 // probability 2^-37.  Acceptance test = Legendre symbol, square root once at the end (k_h2c_bn_finish).
 void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn, Aff<F1<BN254>>* out, uint32_t* flags, bool lean) {
   if (n < 256) {
-    k_h2c_bn_jacobi<<<nblk(n, 64), 64, 0, st>>>(mv, n, out, flags);
+    k_h2c_bn_wide<<<nblk(n, 4), 64, 0, st>>>(mv, n, out, flags);
     return;
   }
   uint32_t* L0 = lists;
