@@ -526,12 +526,12 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
     ex_ms, ex_cnt = stages_excl["sum_points"]
     sum_s = ex_ms / max(ex_cnt, 1) * 1e-3
     macs = n * MULTISIG_FPMUL * MAC_PER_FPMUL[cid]              # one G2 mixed addition ~ 29 m per signer
-    traffic, tdet = traffic_for("k_sum_main_" + CNAME[cid])
+    traffic, tdet = traffic_for("k_sumpair_main_" + CNAME[cid])
     return {
         "metric": "multisig-verify signers/sec", "value": n / med, "unit": "signers/s", "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3,
         "ms_per_step_all": [p * 1e3 for p in per_step], "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM" % (CNAME[cid], n), "in_flight": L},
-        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sum_main + k_sum_pair / k_sum_coop (the whole key-sum stage)", "peak": peak / 1e12, "unit": "TMAC/s",
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sumpair_main + k_sum_pair / k_sum_coop (the whole key-sum stage)", "peak": peak / 1e12, "unit": "TMAC/s",
                      "achieved": macs / sum_s / 1e12, "frac": macs / sum_s / peak, "launch_ms": sum_s * 1e3, "traffic": traffic, "traffic_detail": tdet,
                      "hbm_side": {"achieved": n * 4 * fp / sum_s / 1e9, "peak": 8000.0, "unit": "GB/s", "note": "key bytes read once / stage time"},
                      "note": "achieved = n x 29 Fp multiplications x %d MAC / the key-sum stage's time with one verification in flight (HIP events)" % MAC_PER_FPMUL[cid]},

@@ -45,7 +45,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (prof
                "at the fabric side of L2 (Infinity Cache hits included), per launch."}
 for key, name, kern, algo in (("k_miller_x60_altbn128", "bn_x60", "k_miller_x60<bgls::BN254", 1048576 * 192),
                               ("k_miller_x60_bls12", "bls_x60", "k_miller_x60<bgls::BLS381", 1048576 * 256),
-                              ("k_sum_main_altbn128", "multisig", "k_sum_main", 1048576 * 128)):
+                              ("k_sumpair_main_altbn128", "multisig", "k_sumpair_main", 1048576 * 128)):
     t = traffic(name, kern, algo)
     if t:
         out[key] = t
