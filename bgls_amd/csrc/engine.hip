@@ -2181,7 +2181,9 @@ int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* ke
                                 size_t n, int allow_duplicates, const int* devices, int n_devices) {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
-  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
+  // host keys arrive unvalidated here (no Point construction in between): the upload checks the order-r subgroup as the
+  // reference's constructors do, so a small-order twist point is an encoding error, not an unspecified verdict
+  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, BGLS_KEYS_CHECK, &h);
   if (rc) return rc;
   rc = bgls_verify_aggregate_h(h, sig, msg_blob, msg_off, n, allow_duplicates);
   const int ex = g_last_exchange;
@@ -2194,7 +2196,7 @@ int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, 
                             const int* devices, int n_devices) {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
-  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, 0, &h);
+  int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, BGLS_KEYS_CHECK, &h);
   if (rc) return rc;
   rc = bgls_verify_multi_h(h, sig, msg, msg_len);
   const int ex = g_last_exchange;

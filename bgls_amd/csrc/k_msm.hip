@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) k_scale_g1_inplace(Aff<F1<C>>* pts, const 
   }
   for (int j = 3; j >= 0 && top < 0; --j)
     if (k[j]) top = j * 32 + (31 - __clz(k[j]));
-  pts[i] = jac_to_aff<F1<C>>(jac_mul_wnaf<F1<C>>(pts[i], k, top + 1));
+  pts[i] = jac_to_aff<F1<C>>(jac_mul_w4<F1<C>>(pts[i], k, top + 1));
 }
 
 }  // namespace

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64) k_scale(const uint8_t* pts, const uint8_t*
   for (int j = 7; j >= 0 && top < 0; --j)
     if (k[j]) top = j * 32 + (31 - __clz(k[j]));
   if (sg == 1) p = aff_neg<F>(p);
-  Jac<F> r = jac_mul_wnaf<F>(p, k, top + 1);
+  Jac<F> r = jac_mul_w4<F>(p, k, top + 1);
   aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(r));
 }
 
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) k_wsum_first(const uint8_t* pts, const uin
     for (int j = 3; j >= 0 && top < 0; --j)
       if (k[j]) top = j * 32 + (31 - __clz(k[j]));
     if (signs && signs[i] == 1) p = aff_neg<F>(p);
-    acc = jac_add<F>(acc, jac_mul_wnaf<F>(p, k, top + 1));
+    acc = jac_add<F>(acc, jac_mul_w4<F>(p, k, top + 1));
   }
   out[t] = acc;
 }
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64) k_scale_aff(const Aff<F>* pts, const uint8
   }
   for (int j = 7; j >= 0 && top < 0; --j)
     if (k[j]) top = j * 32 + (31 - __clz(k[j]));
-  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul_wnaf<F>(p, k, top + 1)));
+  aff_to_bytes<F>(out + i * PT_BYTES, jac_to_aff<F>(jac_mul_w4<F>(p, k, top + 1)));
 }
 
 // validity of n points: canonical coordinates, on the curve and in the order-r subgroup (G2 on both curves, G1 on

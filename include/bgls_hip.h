@@ -305,7 +305,8 @@ int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const vo
 int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len);
 /* Contexts: a key-set verification runs shard s on context (selected + s) mod 16 of the shard's device, `selected` being the
  * calling thread's bgls_select_context (default 0); the final product / exponentiation runs on shard 0's context. */
-/* The same two calls with host keys, for callers without a resident set: upload, verify, free. */
+/* The same two calls with host keys, for callers without a resident set: upload (with BGLS_KEYS_CHECK: the keys have not been
+ * through a Point constructor, so subgroup membership is checked here; a key outside G2 gives BGLS_ERR_ENCODING), verify, free. */
 int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
                                 size_t n, int allow_duplicates, const int* devices, int n_devices);
 int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len,

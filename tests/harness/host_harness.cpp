@@ -128,11 +128,11 @@ static int group_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* k
       r = jac_add<F>(jac_dbl<F>(jac_from_aff<F>(P)), jac_dbl<F>(jac_from_aff<F>(Q)));  // 2P + 2Q
     } else if (op == 3) {
       return aff_on_curve<F>(P) ? 1 : 0;
-    } else if (op == 4) {      // the scale kernels' form: width-4 NAF over the scalar's actual bit length
+    } else if (op == 4) {      // the scale kernels' form: signed radix-16 windows over the scalar's actual bit length
       int top = -1;
       for (int j = 7; j >= 0 && top < 0; --j)
         if (k[j]) top = j * 32 + 31 - __builtin_clz(k[j]);
-      r = jac_mul_wnaf<F>(P, k, top + 1);
+      r = jac_mul_w4<F>(P, k, top + 1);
     } else
       return -1;
     g1_to_bytes<C>(out, jac_to_aff<F>(r));
@@ -155,7 +155,7 @@ static int group_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* k
       int top = -1;
       for (int j = 7; j >= 0 && top < 0; --j)
         if (k[j]) top = j * 32 + 31 - __builtin_clz(k[j]);
-      r = jac_mul_wnaf<F>(P, k, top + 1);
+      r = jac_mul_w4<F>(P, k, top + 1);
     } else
       return -1;
     g2_to_bytes<C>(out, jac_to_aff<F>(r));

@@ -90,7 +90,7 @@ def test_miller_final_exp_and_groups_against_golden(host_harness, curve):
                 o = out(size)
                 lib.ht_group_op(cid, base + 1, B(bytes.fromhex(row["pt"])), None, B(k.to_bytes(32, "big")), o)
                 assert bytes(o).hex() == row["out"], k
-                w = out(size)                  # the scale kernels' chain (width-4 NAF): same golden point
+                w = out(size)                  # the scale kernels' chain (signed radix-16 windows): same golden point
                 lib.ht_group_op(cid, base + 4, B(bytes.fromhex(row["pt"])), None, B(k.to_bytes(32, "big")), w)
                 assert bytes(w).hex() == row["out"], k
         # scalars that stress the recoding: runs of ones (carries across limbs), isolated top bits, all digits negative
