@@ -291,7 +291,7 @@ BGLS_FN bool g1_in_subgroup(const Aff<F1<C>>& p) {
     return true;
   } else {
     if (p.inf) return true;
-    return jac_is_inf<F1<C>>(jac_mul<F1<C>>(p, C::ORDER, 255));
+    return jac_is_inf<F1<C>>(jac_mul_w4<F1<C>>(p, C::ORDER, 255));
   }
 }
 

@@ -403,7 +403,10 @@ struct Engine {
       if ((rc = c.get(WS_F_B, (blocks / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       {
         Scope sc(c, st, ST_MILLER);
-        kl::miller_lat<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
+        // k_miller_latx: the same two-wave block on the carry-free limbs (BGLS_LATX=0 keeps k_miller_lat: A/B runs)
+        static const bool latx = [] { const char* e = getenv("BGLS_LATX"); return !(e && e[0] == '0'); }();
+        if (latx) kl::miller_latx<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
+        else kl::miller_lat<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
         HIPCHK(hipGetLastError());
       }
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;

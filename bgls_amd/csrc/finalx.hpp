@@ -133,6 +133,40 @@ __device__ __noinline__ void fx_mul(int dst, int a, int b) {
   __syncthreads();
 }
 
+// The same product on ONE wave (k_miller_latx: the accumulator wave of a latency-form Miller loop cannot share block barriers
+// with its producer wave).  Lane 6j + t computes BOTH halves of its term (x2_mul: four limb products, two reductions); the stages
+// are separated by wave barriers.
+template <class C>
+__device__ __noinline__ void fx_mul1(int dst, int a, int b) {
+  typedef FX<C> E;
+  const int lane = threadIdx.x & 63;
+  if (lane < 36) {
+    const int j = lane / 6, t = lane % 6;
+    int k = j - t;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(a, t, 0));
+    const X2<C, SX_T> y = fx_ld2<C>(E::coef(b, k, wrap));
+    const X2<C, SX_T> p = x2_mul<C>(x, y);
+    fx_st<C>(E::SCR + lane * E::ES, p.c0);
+    fx_st<C>(E::SCR + lane * E::ES + E::HS, p.c1);
+  }
+  wave_sync();
+  if (lane < 12) {
+    const int j = lane >> 1, hh = lane & 1;
+    const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
+    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
+    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
+    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
+    Sx<C, SX_T> other;
+#pragma unroll
+    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
+    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
+  }
+  wave_sync();
+}
+
 template <class C>
 __device__ __forceinline__ void fx_conj(int dst, int a) {           // a^(p^6): w -> -w
   typedef FX<C> E;

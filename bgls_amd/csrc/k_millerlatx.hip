@@ -1,0 +1,272 @@
+// Latency form of the Miller loop on the carry-free limbs: ONE pairing per block (the two-pairing tail of verifyMultiSignature,
+// bgls/bgls.go:59-70,89-92; the reference's own n = 64 benchmark shape).  Same roles, hand-over and results as k_miller_lat
+// (k_tail.inc), which it replaces: wave 1 computes the G2 point step as 3 (doubling) / 4 (addition) rounds of independent Fp2
+// products, one product per LANE PAIR (rx_pair.hpp: the even lane holds the real parts, the odd lane the imaginary parts; two
+// limb products and one reduction per lane) with the operands exchanged through LDS; wave 0 keeps the Fp12 accumulator on the
+// 36-lane arithmetic of finalx.hpp (fx_mul1) and folds the line of step s while wave 1 computes step s + 1.  On a lone wave
+// the rows of a carry-free product are independent multiplier instructions, where the 32-bit form walks a carry chain: a
+// round costs ~1 500 clocks instead of ~6 000.  Block `n` (when sig_at >= 0) is the (-sigma, g2) pair on the pre-computed
+// generator lines.  out: one w-basis Fp12 (6 Fp2, the library's 32-bit Montgomery form) per block.
+#include "dev_common.hpp"
+#include "pairing.hpp"
+#include "finalx.hpp"
+#include "rx_jacpair.hpp"
+#include "launch.hpp"
+
+namespace bgls {
+
+template <class C>
+__global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                                                     const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+  typedef FX<C> E;
+  constexpr int ES = E::ES, HS = E::HS, N = C::RX_NL;
+  enum { S_F = 0, S_L0 = 2, S_L1 = 3, S_PA = 4 };                      // accumulator, two line buffers, producer scratch (slots 4, 5: 24 Fp2)
+  enum { PX = 0, PY, PZ, PQX, PQY, PB, PC, PS, PJ, PM, PE, PZN, PXN, PG, PE2, PT0, PT1, PU0, PU1, PD, PGG, PV0, PV1, PN };
+  static_assert(PN <= 24, "producer scratch fits two slots");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t blk = blockIdx.x;
+  const bool is_sig = sig_at >= 0 && blk == n;
+  const int pbase = E::coef(S_PA, 0, 0);
+  __shared__ int s_valid;
+  const bool odd = lane & 1;
+  const int q = lane >> 1;                                              // the lane pair's product index within a round
+  // own half of scratch entry e / store it (values are tight: reductions' outputs or carried sums)
+  auto LD = [&](int e) { return fx_ld<C>(pbase + e * ES + (odd ? HS : 0)); };
+  auto ST = [&](int e, const Sx<C, SX_T>& v, bool active) {
+    if (active) fx_st<C>(pbase + e * ES + (odd ? HS : 0), v);
+  };
+  // own half of line coefficient `which` into line buffer `buf`, plain and xi multiple:
+  // D-type  k = 0: c0 yP, 1: c1 xP, 3: c2;   M-type  0: c2, 2: c1 xP, 3: c0 yP
+  auto put_line = [&](int buf, int which, const Sx<C, SX_T>& v, bool active) {
+    const int k = which == 0 ? (C::TWIST_D ? 0 : 3) : which == 1 ? (C::TWIST_D ? 1 : 2) : (C::TWIST_D ? 3 : 0);
+    Sx<C, SX_T> other;
+#pragma unroll
+    for (int i = 0; i < N; ++i) other.v[i] = pair_swap1(v.v[i]);
+    const Sx<C, SX_T> z = fx_mulxi_half<C>(v, other, odd);
+    if (active) {
+      fx_st<C>(E::coef(buf ? S_L1 : S_L0, k, 0) + (odd ? HS : 0), v);
+      fx_st<C>(E::coef(buf ? S_L1 : S_L0, k, 1) + (odd ? HS : 0), z);
+    }
+  };
+  if (wave == 0) {
+    if (lane < 6) {
+      const Sx<C, SX_T> zero = ux_to_sx<C>(ux_zero<C>());
+      const X2<C, SX_T> z2 = {zero, zero}, one = {sx_const<C>(C::RX_ONE), zero};
+      fx_put<C>(S_F, lane, lane == 0 ? one : z2);
+      fx_put<C>(S_L0, lane, z2);
+      fx_put<C>(S_L1, lane, z2);
+    }
+  } else if (lane < 2) {
+    // lane pair 0 parses this block's pair (block n: -sigma against the generator)
+    Aff<F1<C>> P = g1s[is_sig ? (size_t)sig_at : blk];
+    AffP<C> Q;
+    bool valid;
+    if (is_sig) {
+      Q.x = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + (odd ? C::L : 0))));
+      Q.y = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + 2 * C::L + (odd ? C::L : 0))));
+      Q.inf = false;
+    } else {
+      bool ok = affp_from_bytes<C>(Q, g2s + blk * 4 * C::FP_BYTES, odd);
+      ok = affp_on_curve<C>(Q, odd) && ok;
+      if (!ok && !odd) atomicOr(flags, FLAG_ENC);
+    }
+    valid = !P.inf && !Q.inf;
+    if (!valid) {
+      Q.x = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + (odd ? C::L : 0))));
+      Q.y = ux_to_sx<C>(to_ux<C>(fp_load<C>(C::G2 + 2 * C::L + (odd ? C::L : 0))));
+      P.x = fp_load<C>(C::G1X);
+      P.y = fp_load<C>(C::G1Y);
+    }
+    const Sx<C, SX_T> zero = ux_to_sx<C>(ux_zero<C>());
+    ST(PX, Q.x, true); ST(PY, Q.y, true); ST(PZ, pair_one<C>(odd), true);
+    ST(PQX, Q.x, true); ST(PQY, Q.y, true);
+    ST(PT0, odd ? zero : ux_to_sx<C>(to_ux<C>(P.x)), true);             // (xP, 0), (yP, 0): Fp2 operands of the scaling products
+    ST(PT1, odd ? zero : ux_to_sx<C>(to_ux<C>(P.y)), true);
+    if (!odd) s_valid = valid ? 1 : 0;
+  }
+  __syncthreads();
+  const bool valid = s_valid != 0;
+  if (wave == 1) {
+    // ------------------------------------------------ producer: point steps on lane pairs, or generator lines
+    const Sx<C, SX_T> xP = LD(PT0), yP = LD(PT1);                        // own halves of (xP, 0), (yP, 0)
+    Sx<C, SX_T> xPs, yPs;                                                // the same scalars on both lanes (the odd lane holds zero)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      xPs.v[i] = xP.v[i] + pair_swap1(xP.v[i]);
+      yPs.v[i] = yP.v[i] + pair_swap1(yP.v[i]);
+    }
+    int buf = 0, step = 0;
+    auto publish = [&]() {                                    // line of this step is in the buffer: hand it over
+      ++step;
+      __syncthreads();
+      buf ^= 1;
+    };
+    auto F = [&](const auto& v) { return sx_normf<C>(v); };                      // any bound below 128 -> almost tight
+    auto T = [&](const Sx<C, SX_T>& v) { return sx_as<SX_F, C>(v); };
+    auto gen_step = [&]() {                                   // (-sigma, g2): scale the pre-computed coefficients
+      const LineCoeffs<C> l = gen_lines[step];
+      const Fp2<C> cq = q == 0 ? l.c0 : q == 1 ? l.c1 : l.c2;
+      const Sx<C, SX_T> own = ux_to_sx<C>(to_ux<C>(odd ? cq.c1 : cq.c0));
+      const Sx<C, SX_T> s = sx_select<C>(q == 0, yPs, xPs);
+      const Sx<C, SX_T> r = pair_muls<C>(own, s);
+      put_line(buf, q == 0 ? 0 : q == 1 ? 1 : 2, q == 2 ? own : r, q < 3);
+      wave_sync();
+      publish();
+    };
+    auto dbl_step = [&]() {
+      const Sx<C, SX_T> X = LD(PX), Y = LD(PY), Z = LD(PZ);
+      {   // round 1: B = Y^2, C = Z^2, S = (Y+Z)^2, J = X^2, M = X Y
+        const Sx<C, SX_F> yz = F(sx_add<C>(Y, Z));
+        const Sx<C, SX_F> a = q == 0 ? T(Y) : q == 1 ? T(Z) : q == 2 ? yz : T(X);
+        const Sx<C, SX_F> b = q == 3 ? T(X) : q == 4 ? T(Y) : a;
+        const int dst = q == 0 ? PB : q == 1 ? PC : q == 2 ? PS : q == 3 ? PJ : PM;
+        ST(dst, pair_mul<C>(a, b, odd), q < 5);
+        wave_sync();
+      }
+      const Sx<C, SX_T> B = LD(PB), Cc = LD(PC);
+      const Sx<C, SX_F> H = F(sx_sub<C>(LD(PS), sx_add<C>(B, Cc)));
+      {   // round 2: E = 3b' C, ZN = B H, line c1 xP = 3J xP, line c0 yP = -H yP
+        const Sx<C, SX_F> j3 = F(sx_mulc<3, C>(LD(PJ)));
+        const Sx<C, SX_F> a = q == 0 ? T(sx_const<C>(odd ? C::RX_B2X3_IM : C::RX_B2X3_RE)) : q == 1 ? T(B) : q == 2 ? j3 : sx_neg<C>(H);
+        const Sx<C, SX_F> b = q == 0 ? T(Cc) : q == 1 ? H : q == 2 ? T(xP) : T(yP);
+        const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
+        ST(PE, r, q == 0);
+        ST(PZN, r, q == 1);
+        put_line(buf, q == 2 ? 1 : 0, r, q == 2 || q == 3);
+        wave_sync();
+      }
+      const Sx<C, SX_T> Ev = LD(PE);
+      const Sx<C, SX_F> Fv = F(sx_mulc<3, C>(Ev));
+      {   // round 3: XN = (M/2)(B - Fv), G^2 with G = (B + Fv)/2, E^2
+        const Sx<C, SX_F> hm = F(sx_half<C>(q == 0 ? T(LD(PM)) : F(sx_add<C>(B, Fv))));
+        const Sx<C, SX_F> a = q == 2 ? T(Ev) : hm;
+        const Sx<C, SX_F> b = q == 0 ? F(sx_sub<C>(B, Fv)) : a;
+        const int dst = q == 0 ? PXN : q == 1 ? PG : PE2;
+        ST(dst, pair_mul<C>(a, b, odd), q < 3);
+        wave_sync();
+      }
+      {
+        const Sx<C, SX_T> xn = LD(PXN), zn = LD(PZN);
+        const Sx<C, SX_T> yn = sx_norm<C>(sx_sub<C>(LD(PG), sx_mulc<3, C>(LD(PE2))));
+        const Sx<C, SX_T> c2 = sx_norm<C>(sx_sub<C>(Ev, B));
+        wave_sync();
+        ST(PX, xn, q == 0); ST(PZ, zn, q == 0); ST(PY, yn, q == 0);
+        put_line(buf, 2, c2, q == 1);
+      }
+      wave_sync();
+      publish();
+    };
+    auto add_step = [&](const Sx<C, SX_T>& xq, const Sx<C, SX_T>& yq) {
+      const Sx<C, SX_T> X = LD(PX), Y = LD(PY), Z = LD(PZ);
+      {   // round 1: yq Z, xq Z
+        ST(q == 0 ? PU0 : PU1, pair_mul<C>(q == 0 ? yq : xq, Z, odd), q < 2);
+        wave_sync();
+      }
+      const Sx<C, SX_F> th = F(sx_sub<C>(Y, LD(PU0))), la = F(sx_sub<C>(X, LD(PU1)));
+      {   // round 2: C = th^2, D = la^2, th xq, la yq, line c0 yP = la yP
+        const Sx<C, SX_F> a = (q == 0 || q == 2) ? th : la;
+        const Sx<C, SX_F> b = q == 0 ? th : q == 1 ? la : q == 2 ? T(xq) : q == 3 ? T(yq) : T(yP);
+        const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
+        const int dst = q == 0 ? PC : q == 1 ? PD : q == 2 ? PV0 : PV1;
+        ST(dst, r, q < 4);
+        put_line(buf, 0, r, q == 4);
+        wave_sync();
+      }
+      const Sx<C, SX_T> D = LD(PD);
+      {   // round 3: E = la D, Fv = Z C, G = X D, line c1 xP = -th xP
+        const Sx<C, SX_F> a = q == 0 ? la : q == 1 ? T(Z) : q == 2 ? T(X) : sx_neg<C>(th);
+        const Sx<C, SX_T> b = q == 1 ? LD(PC) : q == 3 ? xP : D;
+        const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
+        const int dst = q == 0 ? PE : q == 1 ? PS : PGG;
+        ST(dst, r, q < 3);
+        put_line(buf, 1, r, q == 3);
+        put_line(buf, 2, sx_norm<C>(sx_sub<C>(LD(PV0), LD(PV1))), q == 4);
+        wave_sync();
+      }
+      const Sx<C, SX_T> Ev = LD(PE), G = LD(PGG);
+      const Sx<C, SX_F> Hh = F(sx_sub<C>(sx_add<C>(Ev, LD(PS)), sx_mulc<2, C>(G)));
+      {   // round 4: XN = la Hh, ZN = Z E, th (G - Hh), E Y
+        const Sx<C, SX_F> a = q == 0 ? la : q == 1 ? T(Z) : q == 2 ? th : T(Ev);
+        const Sx<C, SX_F> b = q == 0 ? Hh : q == 1 ? T(Ev) : q == 2 ? F(sx_sub<C>(G, Hh)) : T(Y);
+        const int dst = q == 0 ? PXN : q == 1 ? PZN : q == 2 ? PU0 : PU1;
+        ST(dst, pair_mul<C>(a, b, odd), q < 4);
+        wave_sync();
+      }
+      {
+        const Sx<C, SX_T> xn = LD(PXN), zn = LD(PZN);
+        const Sx<C, SX_T> yn = sx_norm<C>(sx_sub<C>(LD(PU0), LD(PU1)));
+        wave_sync();
+        ST(PX, xn, q == 0); ST(PZ, zn, q == 0); ST(PY, yn, q == 0);
+      }
+      wave_sync();
+      publish();
+    };
+    const Sx<C, SX_T> qx = LD(PQX), qy = LD(PQY);
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      if (is_sig) gen_step(); else dbl_step();
+      const int d = C::LOOP_NAF[i];
+      if (d != 0) {
+        if (is_sig) gen_step(); else add_step(qx, d > 0 ? qy : sx_neg<C>(qy));
+      }
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      if (is_sig) {
+        gen_step();
+        gen_step();
+      } else {
+        // Q1 = pi(Q) = (conj(x) g12, conj(y) g13), -Q2 = -pi^2(Q) = (x g22, -y g23) on the twist (pairing.hpp miller_loop)
+        constexpr int N2 = 2 * N;
+        const Sx<C, SX_T> cx = sx_select<C>(odd, sx_neg<C>(qx), qx), cy = sx_select<C>(odd, sx_neg<C>(qy), qy);
+        const Sx<C, SX_T> x1 = pair_mul_const<C>(cx, C::RX_GAMMA + 0 * N2, C::RX_GAMMA + 0 * N2 + N, odd);
+        const Sx<C, SX_T> y1 = pair_mul_const<C>(cy, C::RX_GAMMA + 1 * N2, C::RX_GAMMA + 1 * N2 + N, odd);
+        add_step(x1, y1);
+        const Sx<C, SX_T> x2 = pair_mul_const<C>(qx, C::RX_GAMMA + 2 * N2, C::RX_GAMMA + 2 * N2 + N, odd);
+        const Sx<C, SX_T> y2 = sx_neg<C>(pair_mul_const<C>(qy, C::RX_GAMMA + 3 * N2, C::RX_GAMMA + 3 * N2 + N, odd));
+        add_step(x2, y2);
+      }
+    }
+  } else {
+    // ------------------------------------------------ consumer: f <- f^2 * line, one Fp12 on 36 lanes
+    int buf = 0;
+    auto fold = [&]() {
+      __syncthreads();                                        // the line of this step is complete
+      if (valid) fx_mul1<C>(S_F, S_F, buf ? S_L1 : S_L0);
+      buf ^= 1;
+    };
+#pragma unroll 1
+    for (int i = 1; i < C::LOOP_LEN; ++i) {
+      if (i > 1 && valid) fx_mul1<C>(S_F, S_F, S_F);
+      fold();
+      if (C::LOOP_NAF[i] != 0) fold();
+    }
+    if constexpr (C::CURVE_ID == 0) {
+      fold();
+      fold();
+    } else {
+      if (lane < 24) {                                        // x < 0: conjugate (w -> -w)
+        const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
+        Sx<C, SX_T> v = fx_ld<C>(E::coef(S_F, k, xi) + h * HS);
+        if (k & 1) v = sx_neg<C>(v);
+        fx_st<C>(E::coef(S_F, k, xi) + h * HS, v);
+      }
+      wave_sync();
+    }
+    if (lane < 6) {
+      const X2<C, SX_T> x = fx_ld2<C>(E::coef(S_F, lane, 0));
+      out[blk * 6 + lane] = Fp2<C>{sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
+    }
+  }
+}
+
+namespace kl {
+template <class C>
+void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at, const LineCoeffs<C>* gen_lines, Fp2<C>* out,
+                 uint32_t* flags) {
+  const unsigned blocks = (unsigned)(n + (sig_at >= 0 ? 1 : 0));
+  k_miller_latx<C><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
+}
+template void miller_latx<BN254>(hipStream_t, const Aff<F1<BN254>>*, const uint8_t*, size_t, long long, const LineCoeffs<BN254>*, Fp2<BN254>*, uint32_t*);
+template void miller_latx<BLS381>(hipStream_t, const Aff<F1<BLS381>>*, const uint8_t*, size_t, long long, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint32_t*);
+}  // namespace kl
+}  // namespace bgls
