@@ -123,40 +123,6 @@ __global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<
   out[i].y = r;
 }
 
-// alt-bn128 try-and-increment with the acceptance test done by the Legendre symbol (fp_jacobi): the lane
-// walks the counters with cheap tests only and pays ONE square-root exponentiation, for the accepted x.
-// Same accepted counter, same (x, y) as curves/hash.go:53-77.
-__global__ void __launch_bounds__(64) k_h2c_bn_jacobi(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
-  typedef BN254 C;
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* msg = mv.ptr(i);
-  const size_t len = mv.size(i);
-  Fp<C> x, y2;
-  bool found = false;
-  for (u32 c = 0; c < 256 && !found; ++c) {
-    ByteSrc src;
-    src.msg = msg; src.len = len; src.pre[0] = (uint8_t)c; src.npre = 1; src.nsuf = 0;
-    u32 d[8];
-    keccak256_legacy(src, d);
-    Fp<C> h;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
-    x = fp_to_mont<C>(h);
-    y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(x), x), fp_load<C>(C::B));
-    found = fp_jacobi<C>(y2) >= 0;
-  }
-  if (!found) {
-    atomicOr(flags, FLAG_HASH);
-    out[i] = {fp_zero<C>(), fp_zero<C>(), true};
-    return;
-  }
-  __shared__ i32 tab[rxp_lds_words<C>()];
-  Fp<C> r = rx_sqrt_pow<C, false>(y2, tab);       // carry-free limbs: a lone wave issues the independent limb products back to back
-  if (bn_h2c_sign(msg, len)) r = fp_neg<C>(r);
-  out[i] = {x, r, false};
-}
-
 // Small batches (n < 256: the reference's own n = 64 benchmark shape, the single message of a multi-signature): SIXTEEN lanes
 // per message.  With one lane per message a wave walks the counters for as long as its unluckiest message needs (7 tries
 // expected for 64 messages, ~50 us each on a lone wave: Keccak-f plus a Legendre symbol) and then hashes the sign byte; here
