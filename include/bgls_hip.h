@@ -283,6 +283,9 @@ typedef uint64_t bgls_keys_t;
 #define BGLS_KEYS_CHECK 1u
 #define BGLS_KEYS_PREPARE 2u
 int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out);
+/* Lifetime: a key set must not be freed while a call that uses it is in progress or has device work outstanding (the *_dev
+ * entry points return before their kernels finish: synchronise the stream first); calls on one key set from several threads
+ * are otherwise safe, each running on the calling thread's context. */
 int bgls_keys_free(bgls_keys_t handle);
 int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices);
 /* verifyAggSig (bgls/bgls.go:94-119) against a resident key set: message i belongs to key i; n must equal the set's size.
