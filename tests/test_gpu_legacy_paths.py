@@ -1,0 +1,58 @@
+"""GPU tier: the kernels that round 3 replaced stay selectable for A/B measurements (BGLS_FINALX=0: 36-lane final exponentiation
+on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane).  The switches are read once
+per process, so each combination runs in a child process: PairingProduct of a handful of pairings (the latency path: k_miller_lat(x)
++ reduce + final exponentiation) must give the C oracle's GT bytes, and a 300-key aggregate of public keys the oracle's point."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import ctypes, json, random, sys
+sys.path.insert(0, %r)
+from bgls_amd import _lib
+from oracle import coracle
+L = _lib.load()
+assert L.bgls_init(0) == 0
+B = lambda b: (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b))
+gold = %r
+res = {}
+for cname, cid, fp in (("altbn128", 0, 32), ("bls12", 1, 48)):
+    v = json.load(open(gold + "/vectors_" + cname + ".json"))
+    g1 = bytes.fromhex(v["pairings"][3]["g1"]); g2 = bytes.fromhex(v["pairings"][3]["g2"])
+    rnd = random.Random(5 + cid)
+    n = 7
+    g1s = [coracle.scale_point(cid, 1, g1, rnd.randrange(1, 1 << 250)) for _ in range(n)]
+    g2s = [coracle.scale_point(cid, 2, g2, rnd.randrange(1, 1 << 250)) for _ in range(n)]
+    a, b = b"".join(g1s), b"".join(g2s)
+    o = (ctypes.c_uint8 * (12 * fp))()
+    assert L.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
+    res[cname + "_gt"] = bytes(o) == coracle.pairing_product(cid, a, b, n, threads=4)
+    m = 300
+    keys = [coracle.scale_point(cid, 2, g2, rnd.randrange(1, 1 << 250)) for _ in range(16)]
+    pts = b"".join(keys[i %% 16] for i in range(m))            # repeated keys: the doubling branch of the mixed addition
+    s = (ctypes.c_uint8 * (4 * fp))()
+    assert L.bgls_aggregate_points(cid, 2, B(pts), m, s) == 0
+    res[cname + "_sum"] = bytes(s) == coracle.aggregate_points(cid, 2, pts, m)
+print("RESULT " + json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0"}, {"BGLS_SUMX": "1"}, {}],
+                         ids=["32-bit tails and key sum", "one-lane key sum", "defaults"])
+def test_replaced_kernels_still_match_the_oracle(env):
+    golden = os.path.join(ROOT, "tests", "golden")
+    code = CHILD % (ROOT, golden)
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    assert res and all(res.values()), res
