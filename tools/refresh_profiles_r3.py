@@ -51,3 +51,8 @@ for key, name, kern, algo in (("k_miller_x60_altbn128", "bn_x60", "k_miller_x60<
         out[key] = t
 json.dump(out, open(dst + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else {"GB/launch x2": v["bytes_per_launch_fetch_x2"] / 1e9, "ratio": v["ratio_to_algorithmic"]}) for k, v in out.items() if k != "note"}, indent=1))
+
+# VGPR / scratch / spill / LDS table of every kernel in the shipped library (tools/kernel_resources.py)
+import subprocess
+with open(dst + "/kernel_resources.txt", "w") as fh:
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_resources.py")], stdout=fh, stderr=subprocess.STDOUT, timeout=600)
