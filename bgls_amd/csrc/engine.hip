@@ -259,7 +259,8 @@ struct Engine {
   static int miller_product(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, MsgView mv, size_t n,
                             int check_dups, uint8_t* d_partial, uint32_t* d_flags, const uint8_t* d_w16 = nullptr) {
     if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
-    const bool raw = C::CURVE_ID == 1 && n > LAT_MAX;     // BLS12-381 batches: uncleared hash points, cofactor applied once in GT
+    const bool raw = C::CURVE_ID == 1 && n > 0;           // BLS12-381: uncleared hash points, cofactor applied once in GT (any batch size:
+                                                          // clearing it per message is a 126-bit scalar multiplication on a lone lane, 4.8 ms)
     void* g1s;
     int rc;
     if ((rc = c.get(WS_G1S, (n + 2) * sizeof(Aff<G1F>), &g1s))) return rc;
@@ -396,21 +397,23 @@ struct Engine {
     void *pa, *pb;
     Fp2<C>* red = nullptr;
     bool epilogue = cofactor;
-    if (npairs <= LAT_MAX && !cofactor && miller_shape() == 0) {
-      // a handful of pairings: one block per pairing (k_miller_lat), the signature pair as one more block
-      const size_t blocks = npairs + (sig ? 1 : 0);
+    if (npairs <= LAT_MAX && miller_shape() == 0) {
+      // a handful of pairings: one block per pairing (k_miller_latx), the signature pair as one more block -- or, with uncleared
+      // BLS12-381 hash points, in the epilogue that raises the other pairs' product to the cofactor
+      const bool sig_block = sig && !cofactor;
+      const size_t blocks = npairs + (sig_block ? 1 : 0);
       if ((rc = c.get(WS_F_A, (blocks + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
       if ((rc = c.get(WS_F_B, (blocks / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       {
         Scope sc(c, st, ST_MILLER);
         // k_miller_latx: the same two-wave block on the carry-free limbs (BGLS_LATX=0 keeps k_miller_lat: A/B runs)
         static const bool latx = [] { const char* e = getenv("BGLS_LATX"); return !(e && e[0] == '0'); }();
-        if (latx) kl::miller_latx<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
-        else kl::miller_lat<C>(st, g1s, g2s, npairs, sig ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
+        if (latx) kl::miller_latx<C>(st, g1s, g2s, npairs, sig_block ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
+        else kl::miller_lat<C>(st, g1s, g2s, npairs, sig_block ? (long long)(sig - g1s) : -1LL, gl, (Fp2<C>*)pa, d_flags);
         HIPCHK(hipGetLastError());
       }
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;
-      return emit_partial(c, st, red, false, nullptr, gl, d_partial);
+      return emit_partial(c, st, red, cofactor, cofactor ? sig : nullptr, gl, d_partial);
     }
     // k_miller_x60 (60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes to
     // the epilogue kernel) is the default above the latency shape.  One exception: 1024 blocks are resident at a time, and a
@@ -753,9 +756,10 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   // with the (-sig, g2) pair on the pre-computed generator lines
   MsgView mv = {d_msg, nullptr, msg_len, msg_len};
   Aff<F1<C>>* g1s = (Aff<F1<C>>*)d_g1s;
-  if ((rc = E::hash_to_g1(c, st, mv, 1, g1s, (uint32_t*)d_flags))) return rc;               // H(m)
+  constexpr bool raw = C::CURVE_ID == 1;        // BLS12-381: H(m) before cofactor clearing, the cofactor applied in GT
+  if ((rc = E::hash_to_g1(c, st, mv, 1, g1s, (uint32_t*)d_flags, raw))) return rc;          // H(m)
   kl::g1_parse<C>(st, d_sig, 1, 1, g1s + 1, (uint32_t*)d_flags);                            // -sig
-  if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags))) return rc;
+  if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags, raw))) return rc;
   if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
   return E::finalize(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);
 }
