@@ -64,7 +64,7 @@ constexpr size_t MAX_BATCH = (size_t)1 << 30;
 constexpr size_t LAT_MAX = 128;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_SEG_OFF, WS_SEG_KEYS, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_SEG_OFF, WS_SEG_KEYS, WS_EPI, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -523,9 +523,17 @@ struct Engine {
   // exponent on alt-bn128) and fold the signature pair in on the 36-lane arithmetic
   static int emit_partial(Ctx& c, hipStream_t st, const Fp2<C>* w, bool epilogue, const Aff<G1F>* sig, const LineCoeffs<C>* gl,
                           uint8_t* d_partial) {
-    (void)c;
-    if (!epilogue) kl::w_to_bytes<C>(st, w, d_partial);
-    else kl::cofactor_epilogue<C>(st, w, sig, gl, d_partial);
+    if (!epilogue) {
+      kl::w_to_bytes<C>(st, w, d_partial);
+    } else {
+      // k_epilogue_ax / _bx: the two chains on the carry-free limbs, side by side as two blocks (BGLS_EPIX=0 keeps k_cofactor_epilogue)
+      static const bool epix = [] { const char* e = getenv("BGLS_EPIX"); return !(e && e[0] == '0'); }();
+      void* tmp = nullptr;
+      int rc;
+      if (epix && (rc = c.get(WS_EPI, 12 * sizeof(Fp2<C>), &tmp))) return rc;
+      if (epix) kl::cofactor_epiloguex<C>(st, w, sig, gl, (Fp2<C>*)tmp, d_partial, nullptr);
+      else kl::cofactor_epilogue<C>(st, w, sig, gl, d_partial);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   }

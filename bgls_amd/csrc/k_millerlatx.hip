@@ -15,16 +15,17 @@
 
 namespace bgls {
 
+// one block = one pairing: pair `blk` of the batch (blk == n with sig_at >= 0: the (-sigma, g2) pair); the six w-basis coefficients
+// of the Miller value go to out[blk * 6 ..]
 template <class C>
-__global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
-                                                     const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+__device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                                                  const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, size_t blk) {
   typedef FX<C> E;
   constexpr int ES = E::ES, HS = E::HS, N = C::RX_NL;
   enum { S_F = 0, S_L0 = 2, S_L1 = 3, S_PA = 4 };                      // accumulator, two line buffers, producer scratch (slots 4, 5: 24 Fp2)
   enum { PX = 0, PY, PZ, PQX, PQY, PB, PC, PS, PJ, PM, PE, PZN, PXN, PG, PE2, PT0, PT1, PU0, PU1, PD, PGG, PV0, PV1, PN };
   static_assert(PN <= 24, "producer scratch fits two slots");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t blk = blockIdx.x;
   const bool is_sig = sig_at >= 0 && blk == n;
   const int pbase = E::coef(S_PA, 0, 0);
   __shared__ int s_valid;
@@ -259,7 +260,80 @@ __global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, cons
   }
 }
 
+template <class C>
+__global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                                                     const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+  miller_latx_block<C>(g1s, g2s, n, sig_at, gen_lines, out, flags, blockIdx.x);
+}
+
+// ---- epilogue of a batch verification on the same arithmetic (replaces k_cofactor_epilogue of k_tail.inc): partial product =
+// miller(-sigma, g2) * rest^h, h = the G1 cofactor (BLS12-381 raw hash points; alt-bn128: h = 1).  Both
+// factors are serial chains with no batch dimension: they run side by side as the two blocks of ONE launch -- block 0 walks the
+// generator's pre-computed lines for the signature pair (the latency-form Miller block above), block 1 raises rest to h on the
+// one-wave 36-lane product (general squarings: rest is not unitary before the final exponentiation) -- and a second, one-wave
+// launch multiplies the two and serialises the result.  tmp: 12 Fp2 (w-basis, the library's Montgomery form).
+template <class C>
+__global__ void __launch_bounds__(128) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
+                                                     uint32_t* flags) {
+  typedef FX<C> E;
+  if (blockIdx.x == 0) {
+    if (sig != nullptr) {
+      miller_latx_block<C>(sig, nullptr, 0, 0, gen_lines, tmp, flags, 0);      // (-sigma, g2): pair "n" of an empty batch
+    } else if (threadIdx.x < 6) {
+      tmp[threadIdx.x] = threadIdx.x == 0 ? f2_one<C>() : f2_zero<C>();
+    }
+    return;
+  }
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  enum { S_BASE = 0, S_ACC = 1 };
+  if (lane < 6) {
+    const Fp2<C> v = rest[lane];
+    const X2<C, SX_T> x = {sx_from_mont<C>(v.c0), sx_from_mont<C>(v.c1)};
+    fx_put<C>(S_BASE, lane, x);
+    fx_put<C>(S_ACC, lane, x);
+  }
+  wave_sync();
+  if constexpr (C::CURVE_ID == 1) {
+    for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
+      fx_mul1<C>(S_ACC, S_ACC, S_ACC);
+      if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) fx_mul1<C>(S_ACC, S_ACC, S_BASE);
+    }
+  }
+  if (lane < 6) {
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(S_ACC, lane, 0));
+    tmp[6 + lane] = Fp2<C>{sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
+  }
+}
+template <class C>
+__global__ void __launch_bounds__(64) k_epilogue_bx(const Fp2<C>* tmp, uint8_t* out) {
+  typedef FX<C> E;
+  const int lane = threadIdx.x;
+  if (lane < 6) {
+    const Fp2<C> a = tmp[lane], b = tmp[6 + lane];
+    fx_put<C>(0, lane, X2<C, SX_T>{sx_from_mont<C>(a.c0), sx_from_mont<C>(a.c1)});
+    fx_put<C>(1, lane, X2<C, SX_T>{sx_from_mont<C>(b.c0), sx_from_mont<C>(b.c1)});
+  }
+  wave_sync();
+  fx_mul1<C>(0, 0, 1);
+  if (lane < 6) {
+    const int order_pos[6] = {5, 2, 4, 1, 3, 0};
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(0, lane, 0));
+    uint8_t* o = out + (size_t)(2 * order_pos[lane]) * C::FP_BYTES;
+    fp_to_be<C>(o, fp_from_mont<C>(sx_to_mont<C>(x.c1)));
+    fp_to_be<C>(o + C::FP_BYTES, fp_from_mont<C>(sx_to_mont<C>(x.c0)));
+  }
+}
+
 namespace kl {
+template <class C>
+void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
+                        uint32_t* flags) {
+  k_epilogue_ax<C><<<2, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags);
+  k_epilogue_bx<C><<<1, 64, FX<C>::LDS_BYTES, st>>>(tmp, out);
+}
+template void cofactor_epiloguex<BN254>(hipStream_t, const Fp2<BN254>*, const Aff<F1<BN254>>*, const LineCoeffs<BN254>*, Fp2<BN254>*, uint8_t*, uint32_t*);
+template void cofactor_epiloguex<BLS381>(hipStream_t, const Fp2<BLS381>*, const Aff<F1<BLS381>>*, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint8_t*, uint32_t*);
 template <class C>
 void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at, const LineCoeffs<C>* gen_lines, Fp2<C>* out,
                  uint32_t* flags) {

@@ -101,6 +101,7 @@ void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size
                 uint32_t* flags);
 template <class C> void gt_pow(hipStream_t st, const uint8_t* gt_in, const uint8_t* k_be32, int negate, uint8_t* gt_out, uint32_t* flags);
 template <class C> void cofactor_epilogue(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, uint8_t* out);
+template <class C> void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out, uint32_t* flags);
 
 }  // namespace kl
 }  // namespace bgls
