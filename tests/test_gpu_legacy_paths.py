@@ -1,5 +1,5 @@
 """GPU tier: the kernels that round 3 replaced stay selectable for A/B measurements (BGLS_FINALX=0: 36-lane final exponentiation
-on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane).  The switches are read once
+on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue).  The switches are read once
 per process, so each combination runs in a child process: PairingProduct of a handful of pairings (the latency path: k_miller_lat(x)
 + reduce + final exponentiation) must give the C oracle's GT bytes, and a 300-key aggregate of public keys the oracle's point."""
 import json
@@ -40,11 +40,25 @@ for cname, cid, fp in (("altbn128", 0, 32), ("bls12", 1, 48)):
     s = (ctypes.c_uint8 * (4 * fp))()
     assert L.bgls_aggregate_points(cid, 2, B(pts), m, s) == 0
     res[cname + "_sum"] = bytes(s) == coracle.aggregate_points(cid, 2, pts, m)
+    # a small aggregate verification through the C ABI: hashing, latency-form Miller loop, epilogue (BLS12-381: uncleared
+    # cofactor), final exponentiation; a flipped message bit must reject
+    ns = 5
+    sks = [rnd.randrange(1, 1 << 250) for _ in range(ns)]
+    kb = b"".join(x.to_bytes(32, "big") for x in sks)
+    msgs = [rnd.randbytes(40) for _ in range(ns)]
+    off = (ctypes.c_uint64 * (ns + 1))(*[40 * i for i in range(ns + 1)])
+    keys2 = (ctypes.c_uint8 * (ns * 4 * fp))(); assert L.bgls_scale_generator(cid, 2, B(kb), ns, keys2) == 0
+    sigs = (ctypes.c_uint8 * (ns * 2 * fp))(); assert L.bgls_sign_batch(cid, B(kb), B(b"".join(msgs)), off, ns, sigs) == 0
+    agg = (ctypes.c_uint8 * (2 * fp))(); assert L.bgls_aggregate_points(cid, 1, sigs, ns, agg) == 0
+    ok = L.bgls_verify_aggregate(cid, agg, keys2, B(b"".join(msgs)), off, ns, 0)
+    bad = bytearray(b"".join(msgs)); bad[7] ^= 4
+    no = L.bgls_verify_aggregate(cid, agg, keys2, B(bytes(bad)), off, ns, 0)
+    res[cname + "_verify"] = ok == 1 and no == 0 and coracle.verify_aggregate(cid, bytes(agg), bytes(keys2), msgs, False, 2, 0) == 1
 print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0"}, {"BGLS_SUMX": "1"}, {}],
+@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {}],
                          ids=["32-bit tails and key sum", "one-lane key sum", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
     golden = os.path.join(ROOT, "tests", "golden")
