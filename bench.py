@@ -787,7 +787,7 @@ def main():
                                                                                         tp, CNAME[c_] + " prepared", with_h2d=False, prepared=True)
             bn = inst if cid == 0 else oinst
             records["altbn128_multisig_%d" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16)
-            records["altbn128_multisig_batch_16x%d" % bn["n"]] = bench_multisig_batch(lib, dev, bn, bn["n"], 16, 8, 2, args.reps, 4)
+            records["altbn128_multisig_batch_16x%d" % bn["n"]] = bench_multisig_batch(lib, dev, bn, bn["n"], 16, 16, 2, args.reps, 8)
             records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)
             if not args.no_cpu_baseline:
                 for c_, i_ in ((cid, inst), (other, oinst)):
