@@ -625,6 +625,10 @@ struct Engine {
     else kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     void *a = ja, *b = jb;
     size_t p = P, cnt = nsets * P;
+    if (group == BGLS_G2 && sum_mode<C>() == 2) {             // the lane-pair kernel leaves one partial per block of 32 pairs
+      p = P / 32;
+      cnt = nsets * p;
+    }
     while (p > 1) {
       if (group == BGLS_G2 && cnt <= 8192) {
         kl::sum_coop<C>(st, a, cnt, b);
@@ -657,18 +661,18 @@ struct Engine {
     size_t waves = (n + 255) / 256;
     if (waves > 2048) waves = 2048;
     const bool pairs = group == BGLS_G2 && sum_mode<C>() == 2;
-    if (pairs) {                      // one partial per lane pair: three waves per SIMD resident (3072), >= ~4 keys per pair
-      waves = (n + 127) / 128;
+    if (pairs) {                      // one running sum per lane pair, three waves per SIMD resident (3072), >= ~4 keys per pair;
+      waves = (n + 127) / 128;        // a block (one wave) adds its 32 sums itself and leaves ONE partial
       if (waves > 3072) waves = 3072;
     }
-    const size_t partials = pairs ? waves * 32 : waves * 64;
+    const size_t partials = pairs ? waves : waves * 64;
     void *ja, *jb;
     int rc;
     Scope sc(c, st, ST_SUM);
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (partials + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (partials / 2 + 2) * JB, &jb))) return rc;
-    if (pairs) kl::sumpair_main<C>(st, parsed, d_pts, n, (unsigned)partials, ja, d_flags);                                  // lane pairs, carry-free limbs (rx_jacpair.hpp)
+    if (pairs) kl::sumpair_main<C>(st, parsed, d_pts, n, (unsigned)(waves * 32), ja, d_flags);                                  // lane pairs, carry-free limbs (rx_jacpair.hpp)
     else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags); // one lane, carry-free limbs (rx_jac.hpp)
     else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
     void *a = ja, *b = jb;

@@ -1,10 +1,13 @@
 // G2 key sums (the main pass of AggregatePoints, curves/curve.go:73-121) on LANE PAIRS in the carry-free form: rx_jacpair.hpp.
-//   k_sumpair_main      pair t adds keys t, t + T, t + 2T, ... (T = lane pairs in the launch) into its own Jacobian partial
+//   k_sumpair_main      pair t adds keys t, t + T, t + 2T, ... (T = lane pairs in the launch) into its own Jacobian sum
 //   k_sumpairseg_main   the same for nsets key sets in one launch (KoskVerifyBatchMultiSignature, bgls/blsKosk.go:126-133)
-// Partials leave in the library's 32-bit Montgomery Jacobian form (the even lane writes the real parts, the odd lane the
-// imaginary parts): the tree above them (k_sum_pair / k_sum_coop / k_sum_wave) is unchanged.  Own translation unit: everything is
+// The 32 sums of a block (one wave) are then added in the block, five levels through LDS (general Jacobian additions on the same
+// lane pairs), so that a block leaves ONE partial: 3072 for 2^20 keys instead of 98 304, and the tree above them (k_sum_coop:
+// one wave per addition) starts where it has few enough additions to be worth a wave each.  Partials leave in the library's
+// 32-bit Montgomery Jacobian form (the even lane writes the real parts, the odd lane the imaginary parts).  Own translation unit: everything is
 // expanded in place for this kernel's register budget (three waves per SIMD).
 #include "dev_common.hpp"
+#include "coop.hpp"
 #include "rx_jacpair.hpp"
 #include "launch.hpp"
 
@@ -36,6 +39,43 @@ __device__ __forceinline__ void sumpair_store(Jac<F2<C>>* out, const JacP<C>& ac
   o[4] = sxp_to_mont<C>(acc.Z);
 }
 
+// the block's 32 per-pair sums -> one (in pair 0).  LDS: limb-major columns of the 64 lanes (conflict-free), 3 NL dwords per lane.
+template <class C>
+__device__ __noinline__ JacP<C> sumpair_block_tree(JacP<C> acc, bool odd) {
+  constexpr int N = C::RX_NL;
+  __shared__ i32 cols[3 * N * 64];
+  __shared__ int infs[64];
+  const int lane = threadIdx.x & 63, pi = lane >> 1;
+  auto put = [&]() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      cols[(0 * N + i) * 64 + lane] = acc.X.v[i];
+      cols[(1 * N + i) * 64 + lane] = acc.Y.v[i];
+      cols[(2 * N + i) * 64 + lane] = acc.Z.v[i];
+    }
+    infs[lane] = acc.inf ? 1 : 0;
+  };
+  put();
+#pragma unroll 1
+  for (int s = 16; s >= 1; s >>= 1) {
+    wave_sync();
+    if (pi < s) {
+      const int src = lane + 2 * s;
+      JacP<C> o;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        o.X.v[i] = cols[(0 * N + i) * 64 + src];
+        o.Y.v[i] = cols[(1 * N + i) * 64 + src];
+        o.Z.v[i] = cols[(2 * N + i) * 64 + src];
+      }
+      o.inf = infs[src] != 0;
+      acc = jacp_add<C>(acc, o, odd);
+      put();                       // slots below s are read again only after the next barrier
+    }
+  }
+  return acc;
+}
+
 template <class C, bool PARSED>
 __global__ void __launch_bounds__(64, 3) k_sumpair_main(const uint8_t* pts, size_t n, Jac<F2<C>>* out, uint32_t* flags) {
   const size_t T = (size_t)gridDim.x * 32;
@@ -50,7 +90,8 @@ __global__ void __launch_bounds__(64, 3) k_sumpair_main(const uint8_t* pts, size
     acc = jacp_madd<C>(acc, q, odd);
   }
   if (bad && !odd) atomicOr(flags, FLAG_ENC);
-  sumpair_store<C>(out + t, acc, odd);
+  acc = sumpair_block_tree<C>(acc, odd);
+  if (threadIdx.x < 2) sumpair_store<C>(out + blockIdx.x, acc, odd);
 }
 
 template <class C>
@@ -69,16 +110,17 @@ __global__ void __launch_bounds__(64, 3) k_sumpairseg_main(const uint8_t* pts, c
     acc = jacp_madd<C>(acc, q, odd);
   }
   if (bad && !odd) atomicOr(flags, FLAG_ENC);
-  sumpair_store<C>(out + b * P + t, acc, odd);
+  acc = sumpair_block_tree<C>(acc, odd);
+  if (threadIdx.x < 2) sumpair_store<C>(out + blockIdx.x, acc, odd);      // partials of set b: blocks b * per .. (b + 1) * per - 1
 }
 
 namespace kl {
 
-// `partials` = number of Jacobian partial sums written (a multiple of 32): one lane pair each
+// `pairs` = lane pairs in the launch (a multiple of 32); pairs / 32 Jacobian partial sums are written, one per block
 template <class C>
-void sumpair_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned partials, void* out, uint32_t* flags) {
-  if (parsed) k_sumpair_main<C, true><<<partials / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
-  else k_sumpair_main<C, false><<<partials / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
+void sumpair_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned pairs, void* out, uint32_t* flags) {
+  if (parsed) k_sumpair_main<C, true><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
+  else k_sumpair_main<C, false><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
 }
 template <class C>
 void sumpairseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags) {

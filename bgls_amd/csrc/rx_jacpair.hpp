@@ -101,6 +101,35 @@ RX_DEV JacP<C> jacp_madd(const JacP<C>& p, const AffP<C>& q, bool odd) {
   return r;
 }
 
+// p + q, both Jacobian (add-2007-bl, 11 products + 5 squarings): the in-block tree above the per-pair partial sums
+template <class C>
+RX_DEV JacP<C> jacp_add(const JacP<C>& p, const JacP<C>& q, bool odd) {
+  if (q.inf) return p;
+  if (p.inf) return q;
+  const Sx<C, SX_T> Z1Z1 = pair_sqr<C>(p.Z, odd), Z2Z2 = pair_sqr<C>(q.Z, odd);
+  const Sx<C, SX_T> U1 = pair_mul<C>(p.X, Z2Z2, odd), U2 = pair_mul<C>(q.X, Z1Z1, odd);
+  const Sx<C, SX_T> S1 = pair_mul<C>(pair_mul<C>(p.Y, q.Z, odd), Z2Z2, odd);
+  const Sx<C, SX_T> S2 = pair_mul<C>(pair_mul<C>(q.Y, p.Z, odd), Z1Z1, odd);
+  const auto Hd = sx_sub<C>(U2, U1);
+  const auto Rd = sx_sub<C>(S2, S1);
+  if (pair_both(sx_is_zero_mod_p<C>(Hd))) {                     // same x: P = Q (double) or P = -Q (infinity)
+    if (pair_both(sx_is_zero_mod_p<C>(Rd))) return jacp_dbl<C>(p, odd);
+    return jacp_inf<C>();
+  }
+  const Sx<C, SX_F> H = sx_normf<C>(Hd);
+  const Sx<C, SX_F> rr = sx_normf<C>(sx_mulc<2, C>(Rd));
+  const Sx<C, SX_T> I = pair_sqr<C>(sx_normf<C>(sx_mulc<2, C>(H)), odd);
+  const Sx<C, SX_T> J = pair_mul<C>(H, I, odd);
+  const Sx<C, SX_T> V = pair_mul<C>(U1, I, odd);
+  JacP<C> r;
+  r.X = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(rr, odd), J), sx_mulc<2, C>(V)));
+  r.Y = sx_as<SX_F, C>(pair_mulsub<C>(rr, sx_normf<C>(sx_sub<C>(V, r.X)), sx_mulc<2, C>(S1), J, odd));
+  const Sx<C, SX_F> zz = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(p.Z, q.Z)), odd), Z1Z1), Z2Z2));
+  r.Z = sx_as<SX_F, C>(pair_mul<C>(zz, H, odd));
+  r.inf = false;
+  return r;
+}
+
 // own halves of a key from its wire bytes (x_im || x_re || y_im || y_re, big-endian; all zero = infinity); ok = canonical
 template <class C>
 RX_DEV bool affp_from_bytes(AffP<C>& out, const uint8_t* b, bool odd) {

@@ -524,18 +524,18 @@ template <class C>
 struct RxSumPair {
   const uint8_t* pts;
   int n;
-  Fp<C> part[2][6];            // [form][X.c0 X.c1 Y.c0 Y.c1 Z.c0 Z.c1]
-  bool inf[2];
+  Fp<C> part[3][6];            // [form][X.c0 X.c1 Y.c0 Y.c1 Z.c0 Z.c1]; form 2: two interleaved partial sums joined by jacp_add
+  bool inf[3];
   int bad = 0;
   void lane(int l) {
     tl_pair_lane = l;
     const bool odd = l == 1;
-    for (int form = 0; form < 2; ++form) {
-      JacP<C> acc = jacp_inf<C>();
+    for (int form = 0; form < 3; ++form) {
+      JacP<C> acc = jacp_inf<C>(), acc2 = jacp_inf<C>();
       for (int i = 0; i < n; ++i) {
         AffP<C> q;
         const uint8_t* b = pts + (size_t)i * 4 * C::FP_BYTES;
-        if (form == 0) {
+        if (form != 1) {
           const bool ok = affp_from_bytes<C>(q, b, odd);
           if (!(affp_on_curve<C>(q, odd) && ok)) bad = 1;
         } else {
@@ -543,8 +543,10 @@ struct RxSumPair {
           g2_from_bytes<C>(a, b);
           q = affp_from_mont<C>(a, odd);
         }
-        acc = jacp_madd<C>(acc, q, odd);
+        if (form == 2 && (i & 1)) acc2 = jacp_madd<C>(acc2, q, odd);
+        else acc = jacp_madd<C>(acc, q, odd);
       }
+      if (form == 2) acc = jacp_add<C>(acc, acc2, odd);
       inf[form] = acc.inf;
       if (!acc.inf) {
         part[form][0 + l] = sxp_to_mont<C>(acc.X);
@@ -567,15 +569,17 @@ static int rx_sumpair(const uint8_t* pts, int n, uint8_t* out) {
   t1.join();
   if (run.bad) return -2;
   if (g_rx_overflow) return -3;
-  Aff<F> got[2];
-  for (int form = 0; form < 2; ++form) {
+  Aff<F> got[3];
+  for (int form = 0; form < 3; ++form) {
     Jac<F> j = jac_inf<F>();
     if (!run.inf[form]) j = {{run.part[form][0], run.part[form][1]}, {run.part[form][2], run.part[form][3]}, {run.part[form][4], run.part[form][5]}};
     got[form] = jac_to_aff<F>(j);
   }
-  uint8_t other[4 * 48];
+  uint8_t other[4 * 48], third[4 * 48];
   g2_to_bytes<C>(out, got[0]);
   g2_to_bytes<C>(other, got[1]);
+  g2_to_bytes<C>(third, got[2]);
+  if (memcmp(out, third, 4 * C::FP_BYTES)) return -6;
   return memcmp(out, other, 4 * C::FP_BYTES) ? -5 : 0;
 }
 extern "C" int ht_rx_sumpair(int curve, const uint8_t* pts, int n, uint8_t* out) {
