@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include <memory>
+#include <optional>
 #include <unordered_map>
 #include <dlfcn.h>
 // RCCL is reached through dlopen only (see struct Rccl): the few types and constants it needs are declared here, so the
@@ -219,8 +220,9 @@ int miller_dbg() {
 constexpr int miller_dbg() { return 0; }
 #endif
 
-enum { ST_DUP = 0, ST_H2C, ST_MILLER, ST_REDUCE, ST_FINAL, ST_SUM, ST_NUM };
-const char* const STAGE_NAMES[ST_NUM] = {"dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points"};
+// ST_SUM is opened ONCE per key sum (main pass + tree + conversion); ST_SUM_MAIN brackets the main-pass kernel alone, inside it
+enum { ST_DUP = 0, ST_H2C, ST_MILLER, ST_REDUCE, ST_FINAL, ST_SUM, ST_SUM_MAIN, ST_NUM };
+const char* const STAGE_NAMES[ST_NUM] = {"dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points", "sum_main"};
 
 struct Scope {  // brackets the launches of one stage with events when profiling is on
   Ctx& c; hipStream_t st; int stage; hipEvent_t a = nullptr;
@@ -576,6 +578,7 @@ struct Engine {
     uint32_t f = c.h_res[1] | c.h_res[2];
     if (f & FLAG_ENC) return fail(BGLS_ERR_ENCODING, "non-canonical coordinate or point not on curve");
     if (f & FLAG_SUBGROUP) return fail(BGLS_ERR_ENCODING, "G2 point outside the order-r subgroup");
+    if (f & FLAG_DEGENERATE) return fail(BGLS_ERR_ENCODING, "degenerate point step (small-order key)");
     if (f & FLAG_HASH) return fail(BGLS_ERR_HASH, "try-and-increment exhausted");
     if (f & FLAG_DUP) return 0;
     return c.h_res[0] ? 1 : 0;
@@ -600,8 +603,8 @@ struct Engine {
     void* jac;
     int rc;
     if ((rc = c.get(WS_SUMJ, 4 * kl::jac_bytes<C>(group), &jac))) return rc;
-    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, parsed))) return rc;
-    Scope sc(c, st, ST_SUM);
+    Scope sc(c, st, ST_SUM);                                   // one scope per key sum: the stage count equals the number of sums
+    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, parsed, false))) return rc;
     kl::jac_to_bytes<C>(st, group, jac, 1, d_out);
     HIPCHK(hipGetLastError());
     return 0;
@@ -651,7 +654,7 @@ struct Engine {
   // the same sum left in Jacobian form at d_jac (multi-device key sums exchange projective partials);
   // n == 0 gives the point at infinity (all-zero record: Z = 0)
   static int sum_points_jac(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, void* d_jac, uint32_t* d_flags,
-                            bool parsed = false) {
+                            bool parsed = false, bool own_scope = true) {
     if (n == 0) {
       HIPCHK(hipMemsetAsync(d_jac, 0, kl::jac_bytes<C>(group), st));
       return 0;
@@ -668,13 +671,17 @@ struct Engine {
     const size_t partials = pairs ? waves : waves * 64;
     void *ja, *jb;
     int rc;
-    Scope sc(c, st, ST_SUM);
+    std::optional<Scope> sc;
+    if (own_scope) sc.emplace(c, st, ST_SUM);
     const size_t JB = kl::jac_bytes<C>(group);
     if ((rc = c.get(WS_JAC_A, (partials + 1) * JB, &ja))) return rc;
     if ((rc = c.get(WS_JAC_B, (partials / 2 + 2) * JB, &jb))) return rc;
+    std::optional<Scope> scm;
+    scm.emplace(c, st, ST_SUM_MAIN);
     if (pairs) kl::sumpair_main<C>(st, parsed, d_pts, n, (unsigned)(waves * 32), ja, d_flags);                                  // lane pairs, carry-free limbs (rx_jacpair.hpp)
     else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags); // one lane, carry-free limbs (rx_jac.hpp)
     else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
+    scm.reset();
     void *a = ja, *b = jb;
     size_t cnt = partials;
     while (cnt > 1) {

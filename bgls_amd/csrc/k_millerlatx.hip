@@ -227,6 +227,11 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
         add_step(x2, y2);
       }
     }
+    if (!is_sig && valid && lane < 2) {                       // a degenerate point step leaves Z = 0 (miller_x.hpp)
+      const bool z_own = sx_is_zero_mod_p<C>(LD(PZ));
+      const bool z_zero = z_own && pair_swap1(z_own ? 1 : 0) != 0;
+      if (z_zero && !odd) atomicOr(flags, FLAG_DEGENERATE);
+    }
   } else {
     // ------------------------------------------------ consumer: f <- f^2 * line, one Fp12 on 36 lanes
     int buf = 0;

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
         publish(cap);
       }
     }
+    if (DBG == 0 && valid && f2_is_zero<C>(T.Z)) atomicOr(flags, FLAG_DEGENERATE);     // a degenerate point step leaves Z = 0 (miller_x.hpp)
   } else {
     // ---------------- consumer: 10 groups x 6 lanes; per step 3 line pairs + 1 single line
     const bool live = lane < 60;
@@ -373,6 +374,7 @@ __global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, co
       if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
       done();
     }
+    if (DBG == 0 && valid && f2_is_zero<C>(T.Z)) atomicOr(flags, FLAG_DEGENERATE);     // a degenerate point step leaves Z = 0 (miller_x.hpp)
   } else {
     // ---------------- consumer: 10 groups x 6 lanes, six three-term lines per step
     const bool live = lane < 60;
@@ -542,6 +544,7 @@ __global__ void __launch_bounds__(64, 2) k_lines(const Aff<F1<C>>* g1s, const ui
       add_step_emit<C>(R, x2, y2, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
     }
   }
+  if (valid && f2_is_zero<C>(R.Z)) atomicOr(flags, FLAG_DEGENERATE);                 // a degenerate point step leaves Z = 0 (miller_x.hpp)
 }
 
 // LDS of one fold wave: 10 groups x (accumulator region + two line slots)

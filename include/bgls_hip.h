@@ -320,7 +320,8 @@ int bgls_last_exchange(void);
 int bgls_rccl_available(void);
 
 /* Per-stage device time, measured with HIP events on the stream the kernels are launched on.
- * Stages: "dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points". */
+ * Stages: "dup_check", "h2c", "miller", "reduce", "final_exp", "sum_points" (one scope per key sum: main pass, tree and
+ * conversion), "sum_main" (the main-pass kernel of a key sum alone, nested in "sum_points"). */
 int bgls_profile_enable(int on); /* also resets the counters */
 int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches);
 /* Measured peak of dependent-free v_mad_u64_u32 chains on this GPU, in 32x32->64 MAC/s:

@@ -62,3 +62,21 @@ def test_line_shrinks_rather_than_overflowing():
     assert len(line) < 4096 and json.loads(line)["value"] > 0
     full["records"] = {"r%d" % i: _canned_record(bench, "bls12", 10) for i in range(40)}
     assert len(bench.compact_line(full)) < 4096
+
+
+def test_stage_time_is_per_call_not_per_scope():
+    """the key-sum stage of a multi-signature check was divided by the stage's scope COUNT (two scopes per check), which
+    halved it.  The per-call figure must equal the rocprof-style sum of the stage's kernels whatever the number of scopes."""
+    import pytest
+    bench = _bench()
+    # rocprof summary of one check (profiles/r3/stats_multisig_1048576): main pass, 12 tree levels, conversion
+    kernels_ms = [0.680] + [0.243 / 12] * 12 + [0.117]
+    calls = 5
+    total_ms = sum(kernels_ms) * calls
+    for scopes_per_call in (1, 2, 3):
+        count = scopes_per_call * calls                                   # what bgls_profile_get reports as `launches`
+        assert abs(bench.stage_ms_per_call(total_ms, calls) - sum(kernels_ms)) < 1e-9, count
+        if scopes_per_call > 1:
+            assert total_ms / count < 0.6 * sum(kernels_ms)               # the old arithmetic, for the record
+    with pytest.raises(ValueError):
+        bench.stage_ms_per_call(1.0, 0)

@@ -105,3 +105,70 @@ def test_off_curve_key_is_reported(gpu_lib, curve, shape):
     shape(4)
     o = out(12 * n_fp)
     assert gpu_lib.bgls_pairing_product(cid, B(b"".join(g1s)), B(b"".join(g2s)), n, o) < 0
+
+
+def _degenerates(curve_name, q_bytes):
+    """Walk the Miller loop's point steps with the Python oracle (oracle/pyref/pairing.py, no field shortcuts) and say whether
+    the running point's Z becomes 0: a degenerate step (T = +-Q in an addition, 2-torsion / infinity in a doubling)."""
+    from oracle.pyref import pairing
+    from oracle.pyref.params import CURVES
+    pr = pairing.Pairing(CURVES[curve_name])
+    q = pr.G.g2_from_bytes(q_bytes)
+    r, nq = (q[0], q[1], (1, 0)), pr.G.g2_neg(q)
+    for d in pr.digits[1:]:
+        r, _ = pr.dbl_step(r)
+        if d:
+            r, _ = pr.add_step(r, q if d > 0 else nq)
+    if curve_name == "altbn128":
+        t = pr.T
+        g1, g2 = t.gamma[1], t.gamma[2]
+        r, _ = pr.add_step(r, (t.f2_mul(t.f2_conj(q[0]), g1[2]), t.f2_mul(t.f2_conj(q[1]), g1[3])))
+        r, _ = pr.add_step(r, (t.f2_mul(q[0], g2[2]), t.f2_neg(t.f2_mul(q[1], g2[3]))))
+    return r[2] == (0, 0)
+
+
+def test_degenerate_point_step_is_an_encoding_error(gpu_lib, curve, shape):
+    """A twist point outside G2 handed to the Miller producers WITHOUT the subgroup check (the reference cannot construct one:
+    curves/bls12_381.go:196-264, curves/altbn128.go:157-179).  Where its point steps degenerate (the fixture's point of order
+    13 on BLS12-381: T = +-Q after six steps) every producer -- latency form, k_miller_x60, the 32-bit fused kernels --
+    reports BGLS_ERR_ENCODING instead of an unspecified verdict; where they do not (no on-curve point of alt-bn128's twist
+    degenerates: its smallest cofactor order is 10069) the value is the oracle's Miller formula, byte for byte."""
+    from tests.conftest import load_golden
+    cid, n_fp = curve["id"], curve["fp"]
+    rows = [r for r in load_golden("subgroup_%s.json" % curve["name"])["points"] if r["on_twist"] and not r["in_subgroup"]]
+    rnd = random.Random(13 + cid)
+    seen_degenerate = 0
+    for r in rows:
+        bad = bytes.fromhex(r["pt"])
+        deg = _degenerates(curve["name"], bad)
+        seen_degenerate += deg
+        for n, shapes in ((3, (0,)), (200, (4, 5))):        # <= 128 pairings: k_miller_latx; above: k_miller_x60 / k_miller_ab64
+            g1s, g2s = random_points(curve, rnd, n)
+            g2s[n // 2] = bad
+            a, b = b"".join(g1s), b"".join(g2s)
+            for s in shapes:
+                shape(s)
+                o = out(12 * n_fp)
+                rc = gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o)
+                if deg:
+                    assert rc == -2, (r["note"], n, s, rc)              # BGLS_ERR_ENCODING
+                else:
+                    assert rc == 0, (r["note"], n, s, rc)
+                    if n == 3 or s == 4:
+                        assert bytes(o) == coracle.pairing_product(cid, a, b, n, threads=8), (r["note"], n, s)
+    assert seen_degenerate == (1 if cid == 1 else 0)
+    # the verification door: one such key among valid ones
+    if cid == 1:
+        bad = bytes.fromhex(next(r["pt"] for r in rows if r["note"] == "point of order 13"))
+        v = next(c for c in curve["vec"]["aggregate_cases"] if c["expect"] and len(c["keys"]) >= 2)
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        msgs = [bytes.fromhex(m) for m in v["msgs"]]
+        keys[len(keys) // 2] = bad
+        off = (ctypes.c_uint64 * (len(msgs) + 1))()
+        acc = 0
+        for i, m in enumerate(msgs):
+            off[i] = acc
+            acc += len(m)
+        off[len(msgs)] = acc
+        shape(0)
+        assert gpu_lib.bgls_verify_aggregate(cid, B(bytes.fromhex(v["sig"])), B(b"".join(keys)), B(b"".join(msgs)), off, len(msgs), 0) == -2
