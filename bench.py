@@ -131,7 +131,7 @@ def pinned_peak(lib):
 def traffic_for(kernel_key):
     """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r3, r2): a
     builder-held constant of the evidence run, not measured in this process (labelled as such)."""
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(path):
             det = json.load(open(path))
@@ -421,8 +421,6 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     value = n_total / med
     launches_per_step = 1 if prepared else (n + LAUNCH_PAIRS - 1) // LAUNCH_PAIRS
     pairs_per_launch = n if prepared else min(n, LAUNCH_PAIRS)
-    if not prepared and 61440 < n <= 65536:
-        launches_per_step, pairs_per_launch = 1, n
     macs_per_launch = (pairs_per_launch + 1) * (PREPARED_FPMUL if prepared else MILLER_FPMUL)[cid] * MAC_PER_FPMUL[cid]
     ex_ms, ex_cnt = stages_excl["miller"]
     excl_launch_s = ex_ms / max(ex_cnt, 1) / launches_per_step * 1e-3         # HIP events around the Miller stage, one verification in flight
@@ -431,11 +429,14 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     # (every other stage's time included -- the conservative reading); the exclusive figure is the kernel by itself.
     shared_launch_s = med / launches_per_step
     cname = "BN254" if cid == 0 else "BLS381"
-    # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 unless the launch is
-    # 61 441 .. 65 536 pairings with one verification in flight (the exclusive measurement): k_miller_ab64
-    legacy_alone = 61440 < n <= 65536
-    kernel_excl = "k_miller_ab64<%s>" % cname if legacy_alone else "k_miller_x60<%s>" % cname
-    kernel_timed = "k_miller_x60<%s>" % cname if use_tp else kernel_excl
+    # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 with 60 pairings per block, or its
+    # 64-pairing block form where that saves a nearly empty last round of the 1024 resident blocks and one verification is in
+    # flight (61 441 .. 65 536 pairings: exactly 2^16 is one round) -- the exclusive measurement
+    nb60, nb64 = (n + 59) // 60, (n + 63) // 64
+    r60, r64 = (nb60 + 1023) // 1024, (nb64 + 1023) // 1024
+    form64_alone = r64 < r60 and r64 <= 2
+    kernel_excl = "k_miller_x60<%s, 0, %d>" % (cname, 64 if form64_alone else 60)
+    kernel_timed = "k_miller_x60<%s, 0, 60>" % cname if use_tp else kernel_excl
     if prepared:
         kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])

@@ -187,16 +187,21 @@ bool throughput_mode() {
 // BGLS_MILLER_SHAPE / BGLS_X60_ROT preset them from the environment.
 std::atomic<int> g_shape{-1}, g_ng{6}, g_x60_rot{-1};      // x60 mode -1: automatic (see Engine::miller)
 int miller_shape() {
-  int v = g_shape.load();
-  if (v < 0) {
+  // environment presets are read exactly once (thread-safe static initialiser), before any setter's value can be overwritten
+  static const bool env_once = [] {
     const char* e = getenv("BGLS_MILLER_SHAPE");
-    v = e ? atoi(e) : 0;
+    int v = e ? atoi(e) : 0;
     if (v < 0 || v > 5) v = 0;
     const char* r = getenv("BGLS_X60_ROT");
-    if (r) g_x60_rot.store(atoi(r) & 31);
-    g_shape.store(v);
-  }
-  return v;
+    int expect = -1;
+    if (r && atoi(r) >= 0 && atoi(r) <= 31 && (atoi(r) & 3) != 3) g_x60_rot.compare_exchange_strong(expect, atoi(r));
+    expect = -1;
+    g_shape.compare_exchange_strong(expect, v);
+    return true;
+  }();
+  (void)env_once;
+  const int v = g_shape.load();
+  return v < 0 ? 0 : v;
 }
 
 // G2 key sums on the carry-free 28-bit-limb form.  Mode 2 (default): one key sum partial per LANE PAIR (k_sumpair.hip,
@@ -417,30 +422,39 @@ struct Engine {
       if ((rc = reduce(c, st, (Fp2<C>*)pa, (Fp2<C>*)pb, blocks, &red))) return rc;
       return emit_partial(c, st, red, cofactor, cofactor ? sig : nullptr, gl, d_partial);
     }
-    // k_miller_x60 (60 pairings per block of three waves, both roles on carry-free 28-bit limbs; the signature pair goes to
-    // the epilogue kernel) is the default above the latency shape.  One exception: 1024 blocks are resident at a time, and a
-    // launch of slightly more (61 441 .. 65 536 pairings, e.g. exactly 2^16) pays a second, nearly empty round of blocks
-    // where the 32-bit kernels' 1024 blocks of 64 pairings need one: a verification with the machine to itself keeps
-    // k_miller_ab64 there.  In throughput mode the neighbours' blocks fill the second round and k_miller_x60 stays (measured
-    // at 2^16 with 8 / 16 verifications in flight: alt-bn128 4.91 / 4.76 ms a step against 4.99 / 5.02).
-    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX && (npairs <= 61440 || npairs > 65536 || throughput_mode());
+    // k_miller_x60 (both roles on carry-free 28-bit limbs; the signature pair goes to the epilogue kernel) is the default above
+    // the latency shape.  1024 blocks are resident at a time.  Its 60-pairing block is the faster one per pairing; the
+    // 64-pairing block (a seventh line in four of a block's ten groups: the consumer's step is a fold longer) needs fewer
+    // blocks, and a verification with the machine to itself takes it where that saves a nearly empty last round of blocks --
+    // 61 441 .. 65 536 pairings (exactly 2^16: BASELINE configs 2 / 3) are ONE round instead of two.  (Round 3 fell back to
+    // the 32-bit k_miller_ab64 there.)  In throughput mode the neighbours' blocks fill the last round and the 60-form stays.
+    const bool x60_auto = miller_shape() == 0 && npairs > LAT_MAX;
     if ((miller_shape() == 4 || x60_auto) && npairs >= 1) {
+      constexpr size_t RES = 1024;                      // resident blocks: 256 CUs x 4
+      const size_t nb60 = (npairs + 59) / 60, nb64 = (npairs + 63) / 64;
+      const size_t r60 = (nb60 + RES - 1) / RES, r64 = (nb64 + RES - 1) / RES;
+      // A/B runs and tests: BGLS_X_NP=60 / 64, or bgls_set_miller_shape(4, mode) with mode bit 16 = the 64-form (clear = the 60-form)
+      static const int env_np = [] { const char* e = getenv("BGLS_X_NP"); return e ? atoi(e) : 0; }();
+      const int force_np = miller_shape() == 4 && g_x60_rot.load() >= 0 ? ((g_x60_rot.load() & 16) ? 64 : 60) : env_np;
+      const bool np64 = force_np == 64 || (force_np != 60 && !throughput_mode() && r64 < r60 && r64 <= 2);
       // role / priority mode: consumers placed by SIMD; the producers get issue priority only when the whole batch is one round of
-      // resident blocks with the machine to itself (there the slowest block is the launch: 5.8 instead of 7.4 ms for 61 440
+      // resident blocks with the machine to itself (there the slowest block is the launch: 5.5 instead of 7.2 ms for 61 440
       // BLS12-381 pairings), in steady state it costs 3-6 % (measured at 2^20, four verifications in flight)
-      const int xmode = g_x60_rot.load() >= 0 ? g_x60_rot.load() : ((npairs <= 61440 && !throughput_mode()) ? 8 : 0);
-      const size_t nb60 = (npairs + 59) / 60, groups = nb60 * ((xmode & 16) ? 20 : 10);
-      constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take 57 / 68 KB per block)
+      const size_t nb = np64 ? nb64 : nb60, NPB = np64 ? 64 : 60, groups = nb * 10;
+      const int xmode = g_x60_rot.load() >= 0 ? (g_x60_rot.load() & 15) : ((nb <= RES && !throughput_mode()) ? 8 : 0);
+      constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take up to 57 / 49 KB per block)
       void* park;
-      if ((rc = c.get(WS_QP, kl::miller_x60_park_bytes<C>(nb60 < XB ? nb60 : XB), &park))) return rc;
+      const size_t pblocks = nb < XB ? nb : XB;
+      if ((rc = c.get(WS_QP, np64 ? kl::miller_x_park_bytes<C, 64>(pblocks) : kl::miller_x_park_bytes<C, 60>(pblocks), &park))) return rc;
       if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
       if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       {
         Scope sc(c, st, ST_MILLER);
-        for (size_t blk0 = 0; blk0 < nb60; blk0 += XB) {
-          const size_t nblocks = nb60 - blk0 < XB ? nb60 - blk0 : XB;
-          const size_t p0 = blk0 * 60;
-          kl::miller_x60<C>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * ((xmode & 16) ? 120 : 60), d_flags, (uint32_t*)park, xmode);
+        for (size_t blk0 = 0; blk0 < nb; blk0 += XB) {
+          const size_t nblocks = nb - blk0 < XB ? nb - blk0 : XB;
+          const size_t p0 = blk0 * NPB;
+          if (np64) kl::miller_x<C, 64>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, (uint32_t*)park, xmode);
+          else kl::miller_x<C, 60>(st, (unsigned)nblocks, g1s + p0, g2s + p0 * G2B, npairs - p0, (Fp2<C>*)pa + blk0 * 60, d_flags, (uint32_t*)park, xmode);
         }
         HIPCHK(hipGetLastError());
       }
@@ -2335,8 +2349,9 @@ int bgls_set_throughput_mode(int on) {
 
 int bgls_set_miller_shape(int shape, int pairings_per_group) {
   if (shape < 0 || shape > 5 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
-  if (shape >= 4) {                       // 4: k_miller_x60 always (second argument: role / priority mode); 5: the 32-bit fused kernels always
-    if (shape == 4) g_x60_rot.store(pairings_per_group & 31);
+  if (shape >= 4) {                       // 4: k_miller_x60 always (second argument: mode word, see bgls_hip.h); 5: the 32-bit fused kernels always
+    if (shape == 4 && (pairings_per_group > 31 || (pairings_per_group & 3) == 3)) return fail(BGLS_ERR_ARG, "bad k_miller_x60 mode word");
+    if (shape == 4) g_x60_rot.store(pairings_per_group);
     g_shape.store(shape);
     return 0;
   }

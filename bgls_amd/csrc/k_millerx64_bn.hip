@@ -1,0 +1,4 @@
+// k_miller_x60 for alt-bn128, 64 pairings per block: one round of 1024 resident blocks = 2^16 pairings (k_millerx.inc)
+#define BGLS_MILLER_CURVE BN254
+#define BGLS_MILLER_NP 64
+#include "k_millerx.inc"

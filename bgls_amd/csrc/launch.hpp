@@ -69,9 +69,10 @@ template <class C>
 void miller_s60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags,
                 int dbg, uint32_t* qp);
 
-template <class C>
-void miller_x60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, uint32_t* park, int rot_mode);
-template <class C> size_t miller_x60_park_bytes(size_t nblocks);
+// ---- k_millerx_{bn,bls}.hip (NP = 60), k_millerx64_{bn,bls}.hip (NP = 64)
+template <class C, int NP>
+void miller_x(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, uint32_t* park, int rot_mode);
+template <class C, int NP> size_t miller_x_park_bytes(size_t nblocks);
 
 template <class C> size_t lines_bytes(int variant, size_t n_pad);
 template <class C>

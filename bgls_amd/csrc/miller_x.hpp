@@ -27,85 +27,145 @@
 
 namespace bgls {
 
-template <class C, int NC = 1>
+// LDS layout of a block (round 4).  The consumer's operand fetches are ds_read_b128, which the LDS serves in four fixed groups
+// of sixteen lanes, conflict-free when the sixteen 16-byte slots differ mod 256 bytes (MI355X_MICROARCH.md, LDS).  Round 3's
+// layout (lane = 6 g + j, entries 24 / 32 dwords apart) spent half (alt-bn128) to two thirds (BLS12-381) of its LDS cycles
+// on conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50 / 0.70).  tools/lds_conflicts.py models the accesses; with
+//   * consumer lane = 10 j + g (coefficient-major: the lanes of a 16-lane group are runs of consecutive groups g of two or
+//     three coefficients j),
+//   * slot strides (in 16-byte slots mod 16): group GS, accumulator entry KS, xi copy WS with WS = -6 KS -- the entry a lane
+//     reads for shift s is then slot KS (j - s) whether it wraps or not, the same pattern for every shift,
+//   * (GS, KS, WS) one of the eight solutions of the exhaustive search, e.g. (15, 6, 12) and (3, 14, 12),
+// every fetch of a line fold is conflict-free and the squaring's table-driven fetches cost about a third extra.
+//   alt-bn128  (halves padded to 12 dwords): plain e_k at 24 k, xi e_k at 176 + 24 k, lines at 320 + 24 e, GROUP_DW 764 / 828
+//   BLS12-381  (halves packed, 14 dwords; a half that starts 8 bytes off a 16-byte boundary is fetched from 8 bytes before):
+//              plain e_k at 56 k, xi e_k at 368 + 56 k, the lines in the 28-dword gaps between them, GROUP_DW 844 / 940
+// which also frees the 6.7 KB that hold the BLS12-381 hash points' coordinates (round 3 re-read them from HBM every step).
+//
+// NP = pairings per block: 60 (six lines per group and step) or 64 (all 32 lane pairs of both producer waves: groups 0..3 take
+// a seventh line, the other groups' seventh line is the constant 1) -- 1024 resident blocks of the 64-form are exactly 2^16
+// pairings, the batch a lone VerifyAggregateSignature of BASELINE configs 2 / 3 submits.
+template <class C, int NP = 60>
 struct MX {
+  static_assert(NP == 60 || NP == 64, "pairings per block");
   static constexpr int NL = C::RX_NL;
-  static constexpr int HS = (NL + 3) & ~3;            // dwords per half (16-byte aligned): 12 / 16
-  static constexpr int ES = 2 * HS;                   // per Fp2 entry
-  static constexpr int RB = 0;                        // [NC][6][2] entries: coefficient k -> {e_k, xi e_k}, one set per consumer wave
-  static constexpr int RL = NC * 12 * ES;             // [6 lines][3] entries
-  static constexpr int GROUP_DW = (NC * 12 + 18) * ES + 4;   // +4: the ten groups start on different banks
-  static constexpr int THREADS = 64 * (2 + NC);
+  static constexpr bool PACKED = (C::RX_NL % 4) != 0 && C::CURVE_ID == 1;   // BLS12-381: 14-dword halves back to back
+  static constexpr int HS = PACKED ? NL : ((NL + 3) & ~3);                  // dwords per half: 12 / 14
+  static constexpr int ES = 2 * HS;                                         // per Fp2 entry: 24 / 28
+  static constexpr int NLINES = NP == 64 ? 7 : 6;
+  static constexpr int KS = PACKED ? 2 * ES : ES;                           // accumulator entry stride: 24 / 56
+  static constexpr int WS = PACKED ? 368 : 176;                             // xi copies
+  static constexpr int GROUP_DW = PACKED ? (NP == 64 ? 940 : 844) : (NP == 64 ? 828 : 764);
+  static constexpr int THREADS = 192;
+  // accumulator entry (k, wrap) and line entry e = 3 m + t of a group, in dwords from the group's base
+  static __device__ __forceinline__ int acc_off(int k, int wrap) { return k * KS + wrap * WS; }
+  static __device__ __forceinline__ int line_off(int e) {
+    if constexpr (PACKED) return e < 12 ? 28 + 56 * e + (e >= 6 ? 32 : 0) : (e == 12 ? 336 : 704 + 28 * (e - 13));
+    else return 320 + ES * e;
+  }
+  static_assert(!PACKED || (ES == 28 && 704 + 28 * (3 * NLINES - 13) <= GROUP_DW), "BLS12-381 line slots");
+  static_assert(PACKED || 320 + ES * 3 * NLINES <= GROUP_DW, "alt-bn128 line slots");
   // the hash points' coordinates (-yP, xP per pairing, read by both lanes of its pair at every step) live in LDS where a
-  // quarter of a CU's 160 KB has room for them next to the groups (alt-bn128: 34.7 KB per block), else in the lanes' global
-  // workspace (BLS12-381: the groups alone take 38.6 of the 40 KB)
-  static constexpr int PQ = 10 * GROUP_DW;            // [60 pairings][2] halves
-  static constexpr bool P_IN_LDS = (10 * GROUP_DW + 60 * 2 * HS) * 4 <= 40960;
-  static constexpr int BLOCK_BYTES = (10 * GROUP_DW + ((10 * GROUP_DW + 60 * 2 * HS) * 4 <= 40960 ? 60 * 2 * HS : 0)) * 4;
-  static constexpr int NPARK = C::CURVE_ID == 0 ? 8 : 4;   // parked per producer lane: xq yq [x1 y1 x2 y2] nyP xP  (HS dwords each)
-  static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * HS * 4; }
+  // quarter of a CU's 160 KB has room for them next to the groups, else in the lanes' global workspace (BLS12-381, NP = 64)
+  static constexpr int PQ = 10 * GROUP_DW;            // [NP pairings][2] halves
+  static constexpr bool P_IN_LDS = (10 * GROUP_DW + NP * 2 * HS) * 4 <= 40960;
+  static constexpr int BLOCK_BYTES = (10 * GROUP_DW + (P_IN_LDS ? NP * 2 * HS : 0)) * 4;
+  static constexpr int NPARK_Q = C::CURVE_ID == 0 ? 6 : 2;                  // xq yq [x1 y1 x2 y2]
+  static constexpr int NPARK = NPARK_Q + (P_IN_LDS ? 0 : 2);                // ... nyP xP   (PS dwords each)
+  static constexpr int PS = (NL + 3) & ~3;                                  // parked values stay 16-byte aligned
+  static constexpr size_t park_bytes(size_t nblocks) { return nblocks * 128 * NPARK * PS * 4; }
 };
 
-template <class C>
-__device__ __forceinline__ Ux<C> mx_ld_half(int off) {
+// one half (NL limbs) from / to LDS.  `second`: the half is the c1 of a packed entry (starts 8 bytes off a 16-byte boundary).
+// Fetches are ds_read_b128 only (a ds_read_b64 is served in two 32-lane groups whose 8-byte slots all have the same parity
+// in these layouts: two-way conflicts): a padded half over-reads its padding, a packed one two dwords of its neighbour.
+template <class C, bool PACKED>
+__device__ __forceinline__ Ux<C> mx_ld_half(int off, bool second) {
   extern __shared__ u32 lds[];
   constexpr int N = C::RX_NL;
   Ux<C> r;
-  const uint4* p = reinterpret_cast<const uint4*>(lds + off);
+  if constexpr (!PACKED) {
+    (void)second;
+    const uint4* p = reinterpret_cast<const uint4*>(lds + off);
 #pragma unroll
-  for (int k = 0; k < N / 4; ++k) {
-    const uint4 v = p[k];
-    r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y; r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w;
-  }
-  if constexpr (N % 4 == 2) {
-    const uint2 v = *reinterpret_cast<const uint2*>(lds + off + (N & ~3));
-    r.v[N - 2] = v.x; r.v[N - 1] = v.y;
+    for (int k = 0; k < (N + 3) / 4; ++k) {
+      const uint4 v = p[k];
+      r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y;
+      if (4 * k + 2 < N) { r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w; }
+    }
+  } else {
+    static_assert(!PACKED || N % 4 == 2, "packed halves: NL = 2 mod 4");
+    if (!second) {
+      const uint4* p = reinterpret_cast<const uint4*>(lds + off);
+#pragma unroll
+      for (int k = 0; k < (N + 2) / 4; ++k) {
+        const uint4 v = p[k];
+        r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y;
+        if (4 * k + 2 < N) { r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w; }
+      }
+    } else {
+      const uint4* p = reinterpret_cast<const uint4*>(lds + off - 2);
+      const uint4 v0 = p[0];
+      r.v[0] = v0.z; r.v[1] = v0.w;
+#pragma unroll
+      for (int k = 1; k < (N + 2) / 4; ++k) {
+        const uint4 v = p[k];
+        r.v[4 * k - 2] = v.x; r.v[4 * k - 1] = v.y; r.v[4 * k] = v.z; r.v[4 * k + 1] = v.w;
+      }
+    }
   }
   return r;
 }
-template <class C>
-__device__ __forceinline__ void mx_st_half(int off, const Ux<C>& a) {
+template <class C, bool PACKED>
+__device__ __forceinline__ void mx_st_half(int off, bool second, const Ux<C>& a) {
   extern __shared__ u32 lds[];
   constexpr int N = C::RX_NL;
-  uint4* p = reinterpret_cast<uint4*>(lds + off);
+  if (!PACKED || !second) {
+    uint4* p = reinterpret_cast<uint4*>(lds + off);
 #pragma unroll
-  for (int k = 0; k < N / 4; ++k) p[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
-  if constexpr (N % 4 == 2) *reinterpret_cast<uint2*>(lds + off + (N & ~3)) = make_uint2(a.v[N - 2], a.v[N - 1]);
+    for (int k = 0; k < N / 4; ++k) p[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
+    if constexpr (N % 4 == 2) *reinterpret_cast<uint2*>(lds + off + (N & ~3)) = make_uint2(a.v[N - 2], a.v[N - 1]);
+  } else {
+    *reinterpret_cast<uint2*>(lds + off) = make_uint2(a.v[0], a.v[1]);
+    uint4* p = reinterpret_cast<uint4*>(lds + off + 2);
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) p[k] = make_uint4(a.v[4 * k + 2], a.v[4 * k + 3], a.v[4 * k + 4], a.v[4 * k + 5]);
+  }
 }
 
-// ---- consumer pieces (one output coefficient per lane)
-template <class C>
-__device__ __forceinline__ void mx_publish(int rbo, int j, const Ux2<C>& v, bool live) {
-  typedef MX<C> K;
+// ---- consumer pieces (one output coefficient per lane); gb = the group's base
+template <class C, int NP>
+__device__ __forceinline__ void mx_publish(int gb, int j, const Ux2<C>& v, bool live) {
+  typedef MX<C, NP> K;
   if (live) {
-    mx_st_half<C>(rbo + (2 * j) * K::ES, v.c0);
-    mx_st_half<C>(rbo + (2 * j) * K::ES + K::HS, v.c1);
+    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 0), false, v.c0);
+    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 0) + K::HS, true, v.c1);
     const Ux2<C> x = ux_mulxi<C>(v);
-    mx_st_half<C>(rbo + (2 * j + 1) * K::ES, x.c0);
-    mx_st_half<C>(rbo + (2 * j + 1) * K::ES + K::HS, x.c1);
+    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1), false, x.c0);
+    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1) + K::HS, true, x.c1);
   }
   wave_sync();
 }
 // f <- f * line_m:  c_j = sum_t L[3m + t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
-template <class C>
-__device__ __forceinline__ Ux2<C> mx_fold(int rlo, int rbo, int m, int j) {
-  typedef MX<C> K;
+template <class C, int NP>
+__device__ __forceinline__ Ux2<C> mx_fold(int gb, int m, int j) {
+  typedef MX<C, NP> K;
   // powers of w the line's three entries sit at: {0, 1, 3} (D-type twist) / {0, 2, 3} (M-type), as arithmetic on t: a table in
   // constant memory costs a scalar load and a wait for it in front of every operand fetch
   auto sh = [](int t) { return C::TWIST_D ? t + (t == 2 ? 1 : 0) : t + (t >= 1 ? 1 : 0); };
   return ux_dot_k2p<C, 3, (C::RX_NL <= 10)>(
-      [&](int t, int h) { return mx_ld_half<C>(rlo + (3 * m + t) * K::ES + h * K::HS); },
+      [&](int t, int h) { return mx_ld_half<C, K::PACKED>(gb + K::line_off(3 * m + t) + h * K::HS, h != 0); },
       [&](int t, int h) {
         int k = j - sh(t);
         const int wrap = k < 0 ? 1 : 0;
         k += 6 * wrap;
-        return mx_ld_half<C>(rbo + (2 * k + wrap) * K::ES + h * K::HS);
+        return mx_ld_half<C, K::PACKED>(gb + K::acc_off(k, wrap) + h * K::HS, h != 0);
       });
 }
 // f <- f^2 with the symmetric terms merged (COOP_SQ_TAB)
-template <class C>
-__device__ __forceinline__ Ux2<C> mx_sqr(int rbo, int j) {
-  typedef MX<C> K;
+template <class C, int NP>
+__device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) {
+  typedef MX<C, NP> K;
   const unsigned row = COOP_SQ_TAB[j];
   // table entry per slot: bits 0-2 = i (7 = unused), bits 3-5 = k, bit 6 = wrap (xi copy), bit 7 = doubled
   return ux_sqr_dot<C>(
@@ -116,12 +176,12 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int rbo, int j) {
       [&](int t, int h) {
         const unsigned e = (row >> (8 * t)) & 0xFFu;
         const int i = (e & 7u) == 7u ? 0 : (int)(e & 7u);
-        return mx_ld_half<C>(rbo + (2 * i) * K::ES + h * K::HS);
+        return mx_ld_half<C, K::PACKED>(gb + K::acc_off(i, 0) + h * K::HS, h != 0);
       },
       [&](int t, int h) {
         const unsigned e = (row >> (8 * t)) & 0xFFu;
-        const int k2 = (e & 7u) == 7u ? 0 : 2 * (int)((e >> 3) & 7u) + (int)((e >> 6) & 1u);
-        return mx_ld_half<C>(rbo + k2 * K::ES + h * K::HS);
+        const bool unused = (e & 7u) == 7u;
+        return mx_ld_half<C, K::PACKED>(gb + K::acc_off(unused ? 0 : (int)((e >> 3) & 7u), unused ? 0 : (int)((e >> 6) & 1u)) + h * K::HS, h != 0);
       });
 }
 
@@ -132,7 +192,7 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int rbo, int j) {
 template <class C>
 struct MxPark {
   static constexpr int NL = C::RX_NL;
-  static constexpr int HS = MX<C>::HS;
+  static constexpr int HS = MX<C>::PS;                 // slot stride: 16-byte aligned
   static __device__ __forceinline__ void st_raw(u32* lane_base, int slot, const u32 (&v)[NL]) {
     uint4* p = reinterpret_cast<uint4*>(lane_base + slot * HS);
 #pragma unroll
@@ -181,16 +241,14 @@ struct MxPark {
 // SIMD; rotating the roles from block to block keeps each SIMD's mix of producers and consumers even)
 // DBG (development tools only, never instantiated in the library): 1 = producer work only, 2 = consumer work only -- wrong
 // results, used to time the two roles separately.
-// NC = consumer waves per block (1 or 2).  With two, each folds three of a group's six lines into its OWN accumulator (the
-// block hands out 20 partial products instead of 10; the squaring is done twice): 158 instead of 140 units of work per step and
-// 60 pairings, but the block's critical path -- one consumer's squaring and folds -- drops from 84 to 51 units, and a SIMD sees
-// two busy waves instead of one and a half.
-template <class C, int DBG = 0, int NC = 1>
-__global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
-                                                                int rot_mode) {
-  typedef MX<C, NC> K;
-  static_assert(NC == 1 || NC == 2, "consumer waves");
+// (Round 3's variant with two consumer waves per block -- 20 partial products, the squaring done twice -- measured slower in
+// steady state and is gone.)
+template <class C, int DBG = 0, int NP = 60>
+__global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
+                                                       int rot_mode) {
+  typedef MX<C, NP> K;
   constexpr int NL = C::RX_NL;
+  constexpr int PPW = NP / 2;                                    // pairings (lane pairs at work) per producer wave: 30 / 32
   const int w = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   // Which wave consumes?  The hardware puts the three waves of a block on three of the CU's four SIMDs, and a full CU holds
@@ -202,7 +260,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
   extern __shared__ u32 lds_roles[];
   const int rmode = rot_mode & 3;
   int role;
-  if (NC == 1 && rmode == 0) {
+  if (rmode == 0) {
     const int simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);      // HW_REG_HW_ID bits 5:4
     if (lane == 0) lds_roles[w] = (u32)simd;
     __syncthreads();
@@ -215,21 +273,22 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
     }
     role = w == cw ? 2 : (w > cw ? w - 1 : w);
   } else {
-    const int rot = (NC == 1 && rmode == 2) ? (int)(blockIdx.x % 3u) : 0;
+    const int rot = rmode == 2 ? (int)(blockIdx.x % 3u) : 0;
     role = w + rot;
-    if (NC == 1 && role >= 3) role -= 3;
+    if (role >= 3) role -= 3;
   }
   if (role < 2) {
-    // ---------------------------------------------------------------- producer: 30 pairings, one per lane pair
+    // ---------------------------------------------------------------- producer: PPW pairings, one per lane pair
     if (rot_mode & 8) __builtin_amdgcn_s_setprio(3);
     const int q = lane >> 1;
     const bool odd = lane & 1;
-    const bool owner = q < 30;
-    const int pi = role * 30 + (owner ? q : 0);
-    const size_t idx = (size_t)blockIdx.x * 60 + pi;
-    const int tg = pi / 6, m = pi % 6;
-    u32* const mypark = park + ((size_t)blockIdx.x * 128 + (role * 64 + lane)) * (K::NPARK * K::HS);
-    constexpr int P_NYP = K::NPARK - 2, P_XP = K::NPARK - 1;
+    const bool owner = q < PPW;
+    const int pi = role * PPW + (owner ? q : 0);
+    const size_t idx = (size_t)blockIdx.x * NP + pi;
+    // group and line slot of this pairing: six per group; the 64-form's last four pairings are the seventh line of groups 0..3
+    const int tg = pi < 60 ? pi / 6 : pi - 60, m = pi < 60 ? pi % 6 : 6;
+    u32* const mypark = park + ((size_t)blockIdx.x * 128 + (role * 64 + lane)) * (K::NPARK * K::PS);
+    constexpr int P_NYP = K::NPARK_Q, P_XP = K::NPARK_Q + 1;
     bool valid = owner && idx < n;
     PointX<C> T;
     {
@@ -272,7 +331,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
         MxPark<C>::st(mypark, 5, sx_norm<C>(sx_neg<C>(pair_mul_const<C>(yq, C::RX_GAMMA + 3 * N2, C::RX_GAMMA + 3 * N2 + C::RX_NL, odd))));
       }
       if constexpr (K::P_IN_LDS) {          // the even lane stores -yP, the odd lane xP; both read both (same wave: no barrier)
-        if (owner) mx_st_half<C>(K::PQ + (2 * pi + (odd ? 1 : 0)) * K::HS, odd ? to_ux<C>(P.x) : to_ux<C>(fp_neg<C>(P.y)));
+        if (owner) mx_st_half<C, K::PACKED>(K::PQ + (2 * pi + (odd ? 1 : 0)) * K::HS, odd, odd ? to_ux<C>(P.x) : to_ux<C>(fp_neg<C>(P.y)));
         wave_sync();
       } else {
         MxPark<C>::st(mypark, P_NYP, ux_to_sx<C>(to_ux<C>(fp_neg<C>(P.y))));
@@ -282,7 +341,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       T.Y = yq;
       T.Z = sx_select<C>(odd, ux_to_sx<C>(ux_zero<C>()), sx_const<C>(C::RX_ONE));
     }
-    const int rl_off = tg * K::GROUP_DW + K::RL + (3 * m) * K::ES + (odd ? K::HS : 0);
+    const int rl_base = tg * K::GROUP_DW + (odd ? K::HS : 0);
     // the three line coefficients of a step: computed last in the step, held in registers over barrier A
     Ux<C> e[3];
     auto emit = [&](int which, const auto& v) __attribute__((always_inline)) {
@@ -297,9 +356,9 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       }
       __syncthreads();                    // A: the consumer has finished with the previous lines
       if (owner) {
-        mx_st_half<C>(rl_off, e[0]);
-        mx_st_half<C>(rl_off + K::ES, e[1]);
-        mx_st_half<C>(rl_off + 2 * K::ES, e[2]);
+        mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m), odd, e[0]);
+        mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m + 1), odd, e[1]);
+        mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m + 2), odd, e[2]);
       }
       __syncthreads();                    // B: lines visible
     };
@@ -309,12 +368,12 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       bool neg_y;
       int pq;                             // LDS offset of this pairing's (-yP, xP)
       __device__ __forceinline__ Sx<C, SX_T> nyP() const {
-        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C>(pq));
-        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 2);
+        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C, K::PACKED>(pq, false));
+        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK_Q);
       }
       __device__ __forceinline__ Sx<C, SX_T> xP() const {
-        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C>(pq + K::HS));
-        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK - 1);
+        if constexpr (K::P_IN_LDS) return ux_to_sx<C>(mx_ld_half<C, K::PACKED>(pq + K::HS, true));
+        else return MxPark<C>::ld(MxPark<C>::launder(pk), K::NPARK_Q + 1);
       }
       __device__ __forceinline__ Sx<C, SX_T> xq() const { return MxPark<C>::ld(MxPark<C>::launder(pk), xs); }
       __device__ __forceinline__ Sx<C, SX_T> yq() const {
@@ -339,43 +398,59 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
         hand_over();
       }
     }
+    // Degenerate point steps (T = +-Q in an addition, a 2-torsion point or infinity in a doubling) leave Z = 0, and Z = 0 stays:
+    // Z3 = 2 Y^3 Z (doubling), Z3 = Z la^3 (addition).  A key of order r never gets there; a small-order twist point handed in
+    // without the subgroup check does, and the reference refuses such points at construction (curves/bls12_381.go:196-264,
+    // curves/altbn128.go:157-179) -- so the verification reports an encoding error instead of an unspecified verdict.
+    if constexpr (DBG == 0) {
+      const bool z_own = sx_is_zero_mod_p<C>(T.Z);
+      const bool z_zero = z_own && pair_swap1(z_own ? 1 : 0) != 0;
+      if (valid && z_zero && !odd) atomicOr(flags, FLAG_DEGENERATE);
+    }
   } else {
-    // ---------------------------------------------------------------- consumer: 10 groups x 6 lanes
+    // ---------------------------------------------------------------- consumer: 10 groups x 6 lanes, lane = 10 j + g
     if (rot_mode & 4) __builtin_amdgcn_s_setprio(3);       // the consumer is the long pole of a block's step: let it issue first
     const bool live = lane < 60;
-    const int g = live ? lane / 6 : 9;
-    const int j = live ? lane % 6 : lane - 60;
+    const int cl = live ? lane : lane - 12;                // lanes 60..63 shadow lanes 48..51 (same 16-lane group of a ds_read_b128: broadcast)
+    const int g = cl % 10;
+    const int j = cl / 10;
     const int gb = g * K::GROUP_DW;
-    const int cw = role - 2;                            // which consumer: lines [cw * 6 / NC, (cw + 1) * 6 / NC)
-    const int rbo = gb + K::RB + cw * 12 * K::ES, rlo = gb + K::RL;
     Ux2<C> fj;
     {
       const Ux<C> one = ux_load<C>(C::RX_ONE);
 #pragma unroll
       for (int k = 0; k < NL; ++k) { fj.c0.v[k] = j == 0 ? one.v[k] : 0u; fj.c1.v[k] = 0u; }
     }
-    mx_publish<C>(rbo, j, fj, live);
-    auto fold6 = [&]() __attribute__((always_inline)) {
+    if constexpr (NP == 64) {
+      // groups 4..9 have six pairings: their seventh line is the constant 1 for the whole loop (no producer writes it)
+      if (live && g >= 4 && j < 3) {
+        const Ux<C> one = ux_load<C>(C::RX_ONE), zero = ux_zero<C>();
+        mx_st_half<C, K::PACKED>(gb + K::line_off(18 + j), false, j == 0 ? one : zero);
+        mx_st_half<C, K::PACKED>(gb + K::line_off(18 + j) + K::HS, true, zero);
+      }
+    }
+    mx_publish<C, NP>(gb, j, fj, live);
+    auto fold_all = [&]() __attribute__((always_inline)) {
       if constexpr (DBG == 1) return;
 #pragma unroll 1
-      for (int m = cw * (6 / NC); m < (cw + 1) * (6 / NC); ++m) {
-        fj = mx_fold<C>(rlo, rbo, m, j);
-        mx_publish<C>(rbo, j, fj, live);
+      for (int m = 0; m < K::NLINES; ++m) {
+        fj = mx_fold<C, NP>(gb, m, j);
+        mx_publish<C, NP>(gb, j, fj, live);
       }
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();                    // A
       if (DBG != 1 && i > 1) {            // f = 1 before the first step
-        fj = mx_sqr<C>(rbo, j);
-        mx_publish<C>(rbo, j, fj, live);
+        fj = mx_sqr<C, NP>(gb, j);
+        mx_publish<C, NP>(gb, j, fj, live);
       }
       __syncthreads();                    // B
-      fold6();
+      fold_all();
       if (C::LOOP_NAF[i] != 0) {
         __syncthreads();
         __syncthreads();
-        fold6();
+        fold_all();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
@@ -383,7 +458,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       for (int s = 0; s < 2; ++s) {
         __syncthreads();
         __syncthreads();
-        fold6();
+        fold_all();
       }
     }
     if (live) {
@@ -391,7 +466,7 @@ __global__ void __launch_bounds__(64 * (2 + NC), 3) k_miller_x60(const Aff<F1<C>
       if constexpr (C::CURVE_ID != 0) {
         if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w
       }
-      out[(((size_t)blockIdx.x * NC + cw) * 10 + g) * 6 + j] = r;
+      out[((size_t)blockIdx.x * 10 + g) * 6 + j] = r;
     }
   }
 }

@@ -232,17 +232,21 @@ int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const
  * flight per context. */
 int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream);
 int bgls_final_verify_collect(int curve);
-/* Throughput mode: alt-bn128 Miller launches take the shape that is fastest when several verifications are in flight
- * (60 pairings per block: a 2^16 batch is 1093 blocks, one more round than fit at once when it runs alone).  Results are
- * identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the environment. */
+/* Throughput mode: tells the engine that several verifications are in flight, so that Miller launches keep the block form
+ * that is fastest per pairing (60 pairings per block) even where a launch's last round of resident blocks is nearly empty --
+ * the neighbours fill it.  Results are identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the
+ * environment. */
 int bgls_set_throughput_mode(int on);
-/* Shape of the Miller stage.  0 (default): automatic -- k_miller_x60 (carry-free 28-bit limbs, lane-pair point steps; 60
- * pairings per block) above 128 pairings, except for a lone launch of 61 441..65 536 pairings outside throughput mode,
- * which takes the 32-bit fused kernel k_miller_ab64 (one round of 1024 blocks instead of two); up to 128 pairings the
- * latency kernel.  1..3: decoupled -- k_lines writes every pairing's scaled line coefficients to a table in HBM, k_fold
- * folds them into shared accumulators, pairings_per_group pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3:
- * 28-bit limbs + Karatsuba; 2 and 3 alt-bn128 only, others fall back to 1).  4: k_miller_x60 for every batch
- * (pairings_per_group is then its role / priority mode, development).  5: the 32-bit fused kernels for every batch.
+/* Shape of the Miller stage.  0 (default): automatic -- up to 128 pairings the latency kernel; above, k_miller_x60 (carry-free
+ * 28-bit limbs, lane-pair point steps) with 60 pairings per block, or with 64 per block where that saves a nearly empty last
+ * round of the 1024 resident blocks outside throughput mode (61 441..65 536 pairings: exactly 2^16 is one round).  1..3:
+ * decoupled -- k_lines writes every pairing's scaled line coefficients to a table in HBM, k_fold folds them into shared
+ * accumulators, pairings_per_group pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs + Karatsuba; 2
+ * and 3 alt-bn128 only, others fall back to 1).  4: k_miller_x60 for every batch; pairings_per_group is then a development
+ * mode word, validated: bits 0-1 role placement (0 by SIMD id, 1 wave 2 consumes, 2 rotate by block), bit 2 consumer
+ * priority, bit 3 producer priority, bit 4 the 64-pairing block form (clear: the 60-pairing form); values above 31 are
+ * rejected.  5: the 32-bit fused kernels (k_miller_ab64) for every batch.
+ * Environment presets, read once at the first use: BGLS_MILLER_SHAPE, BGLS_X60_ROT (the mode word), BGLS_X_NP=60|64.
  * Results (partial products, GT bytes, verdicts) are identical for every shape. */
 int bgls_set_miller_shape(int shape, int pairings_per_group);
 /* Contexts 0..15: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it

@@ -1,5 +1,6 @@
 """GPU tier for k_miller_x60 (bgls_amd/csrc/miller_x.hpp: the Miller loop on carry-free 28-bit limbs, lane-pair point steps),
-forced for every batch size with bgls_set_miller_shape(4, mode):
+forced for every batch size with bgls_set_miller_shape(4, mode) -- mode bit 16 selects the 64-pairing block form (a seventh
+line in four of a block's ten groups; 1024 resident blocks = 2^16 pairings), clear the 60-pairing form:
 
   * PairingProduct (curves/curve.go:125-170) against the C oracle's GT bytes at sizes around the kernel's tile boundaries
     (30 pairings per producer wave, 60 per block, 6 per accumulator group), with points at infinity among the inputs;
@@ -43,17 +44,20 @@ def random_points(curve, rnd, n):
 def test_pairing_product_equals_oracle_at_tile_boundaries(gpu_lib, curve, shape):
     cid, n_fp = curve["id"], curve["fp"]
     rnd = random.Random(60 + cid)
-    for n in (1, 2, 29, 30, 31, 59, 60, 61, 66, 120, 121, 187):
+    for n in (1, 2, 29, 30, 31, 59, 60, 61, 63, 64, 65, 66, 120, 121, 127, 128, 129, 187, 193):
         g1s, g2s = random_points(curve, rnd, n)
         if n >= 30:                                    # points at infinity contribute the factor 1 (curves/altbn128.go:478, curves/bls12_381.go:341)
             g1s[n // 3] = bytes(2 * n_fp)
             g2s[n // 2] = bytes(4 * n_fp)
+        if n >= 63:                                    # ... also in the 64-form's seventh-line slots (pairings 60..63 of a block)
+            g2s[61] = bytes(4 * n_fp)
         a, b = b"".join(g1s), b"".join(g2s)
         want = coracle.pairing_product(cid, a, b, n, threads=8)
-        shape(4)
-        o = out(12 * n_fp)
-        assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
-        assert bytes(o) == want, "k_miller_x60, n = %d" % n
+        for form, mode in (("60", 8), ("64", 16 + 8)):
+            shape(4, mode)
+            o = out(12 * n_fp)
+            assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
+            assert bytes(o) == want, "k_miller_x60, %s pairings per block, n = %d" % (form, n)
         shape(5)
         o5 = out(12 * n_fp)
         assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o5) == 0
@@ -76,7 +80,7 @@ def test_large_batches_same_bytes_as_the_32_bit_kernels(gpu_lib, curve, shape):
     shape(5)
     ref = out(12 * n_fp)
     assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, ref) == 0
-    for mode in (8, 0, 1, 2, 9, 4):
+    for mode in (8, 0, 1, 2, 9, 4, 16, 16 + 8, 16 + 1, 16 + 2 + 4):
         shape(4, mode)
         o = out(12 * n_fp)
         assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, o) == 0
@@ -102,9 +106,11 @@ def test_off_curve_key_is_reported(gpu_lib, curve, shape):
     bad = bytearray(g2s[137])
     bad[-1] ^= 1
     g2s[137] = bytes(bad)
-    shape(4)
-    o = out(12 * n_fp)
-    assert gpu_lib.bgls_pairing_product(cid, B(b"".join(g1s)), B(b"".join(g2s)), n, o) < 0
+    for mode in (8, 16 + 8):
+        shape(4, mode)
+        o = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, B(b"".join(g1s)), B(b"".join(g2s)), n, o) < 0
+    assert gpu_lib.bgls_set_miller_shape(4, 3) < 0 and gpu_lib.bgls_set_miller_shape(4, 32) < 0      # mode words are validated
 
 
 def _degenerates(curve_name, q_bytes):
@@ -142,19 +148,22 @@ def test_degenerate_point_step_is_an_encoding_error(gpu_lib, curve, shape):
         bad = bytes.fromhex(r["pt"])
         deg = _degenerates(curve["name"], bad)
         seen_degenerate += deg
-        for n, shapes in ((3, (0,)), (200, (4, 5))):        # <= 128 pairings: k_miller_latx; above: k_miller_x60 / k_miller_ab64
+        for n, shapes in ((3, (0,)), (200, (4, 64, 5))):    # <= 128 pairings: k_miller_latx; above: k_miller_x60 (both block forms) / k_miller_ab64
             g1s, g2s = random_points(curve, rnd, n)
             g2s[n // 2] = bad
             a, b = b"".join(g1s), b"".join(g2s)
             for s in shapes:
-                shape(s)
+                if s == 64:
+                    shape(4, 16 + 8)
+                else:
+                    shape(s)
                 o = out(12 * n_fp)
                 rc = gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o)
                 if deg:
                     assert rc == -2, (r["note"], n, s, rc)              # BGLS_ERR_ENCODING
                 else:
                     assert rc == 0, (r["note"], n, s, rc)
-                    if n == 3 or s == 4:
+                    if n == 3 or s in (4, 64):
                         assert bytes(o) == coracle.pairing_product(cid, a, b, n, threads=8), (r["note"], n, s)
     assert seen_degenerate == (1 if cid == 1 else 0)
     # the verification door: one such key among valid ones
@@ -172,3 +181,35 @@ def test_degenerate_point_step_is_an_encoding_error(gpu_lib, curve, shape):
         off[len(msgs)] = acc
         shape(0)
         assert gpu_lib.bgls_verify_aggregate(cid, B(bytes.fromhex(v["sig"])), B(b"".join(keys)), B(b"".join(msgs)), off, len(msgs), 0) == -2
+
+
+def test_one_round_of_64_pairing_blocks_is_the_default_for_a_lone_2_16_batch(gpu_lib, curve, shape):
+    """BASELINE configs 2 / 3: 2^16 pairings with the machine to itself = 1024 blocks of the 64-form (automatic shape).  Same GT
+    bytes as the 60-form and as the 32-bit kernels (round 3's choice for this size), and the value itself by bilinearity."""
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(2 ** 16 + cid)
+    n = 1 << 16
+    g1, g2 = out(2 * n_fp), out(4 * n_fp)
+    gpu_lib.bgls_generator(cid, 1, g1)
+    gpu_lib.bgls_generator(cid, 2, g2)
+    k1 = b"".join(rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(n))
+    k2 = b"".join(rnd.randrange(1, 1 << 250).to_bytes(32, "big") for _ in range(n))
+    g1s, g2s = out(n * 2 * n_fp), out(n * 4 * n_fp)
+    assert gpu_lib.bgls_scale_points(cid, 1, B(bytes(g1) * n), B(k1), None, n, g1s) == 0
+    assert gpu_lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(k2), None, n, g2s) == 0
+    got = {}
+    for name, args in (("auto", (0,)), ("x60", (4, 8)), ("x64", (4, 16 + 8)), ("ab64", (5,))):
+        shape(*args)
+        o = out(12 * n_fp)
+        assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, o) == 0, name
+        got[name] = bytes(o)
+    assert got["auto"] == got["x60"] == got["x64"] == got["ab64"]
+    from oracle.pyref.params import CURVES
+    r = CURVES[curve["name"]].r
+    s = sum(int.from_bytes(k1[32 * i:32 * i + 32], "big") * int.from_bytes(k2[32 * i:32 * i + 32], "big") for i in range(n)) % r
+    one = out(2 * n_fp)
+    assert gpu_lib.bgls_scale_points(cid, 1, g1, B(s.to_bytes(32, "big")), None, 1, one) == 0
+    e = out(12 * n_fp)
+    shape(0)
+    assert gpu_lib.bgls_pairing_product(cid, one, g2, 1, e) == 0
+    assert bytes(e) == got["auto"]
