@@ -77,39 +77,45 @@ struct MX {
 };
 
 // one half (NL limbs) from / to LDS.  `second`: the half is the c1 of a packed entry (starts 8 bytes off a 16-byte boundary).
-// Fetches are ds_read_b128 only (a ds_read_b64 is served in two 32-lane groups whose 8-byte slots all have the same parity
-// in these layouts: two-way conflicts): a padded half over-reads its padding, a packed one two dwords of its neighbour.
+// Fetches are ds_read_b128 ONLY: the compiler is told that the address is 16-byte aligned (without that it emits ds_read2_b64
+// -- two 8-byte accesses per instruction at half the LDS rate, banked mod 32 -- for every 16-byte load from the unsized
+// extern array: that is what round 3's kernel ran on).  The load that holds a half's last two limbs is narrowed by the
+// compiler to a ds_read_b64 (served in two 32-lane groups; the 8-byte slots of 16-byte aligned entries all have the same
+// parity, so it is two-way conflicted: 4 LDS cycles, what the full ds_read_b128 would cost -- keeping it wide needs an asm
+// use of the unused dwords, which puts a wait behind every load, or a volatile access, which loses the LDS address space).
+__device__ __forceinline__ uint4 mx_ld16(int dw) {
+  extern __shared__ u32 lds[];
+  typedef u32 v4u __attribute__((ext_vector_type(4)));      // a native vector: HIP's uint4 is a struct, whose load is split into scalars
+  const v4u v = *reinterpret_cast<const v4u*>(__builtin_assume_aligned(lds + dw, 16));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 template <class C, bool PACKED>
 __device__ __forceinline__ Ux<C> mx_ld_half(int off, bool second) {
-  extern __shared__ u32 lds[];
   constexpr int N = C::RX_NL;
   Ux<C> r;
   if constexpr (!PACKED) {
     (void)second;
-    const uint4* p = reinterpret_cast<const uint4*>(lds + off);
 #pragma unroll
     for (int k = 0; k < (N + 3) / 4; ++k) {
-      const uint4 v = p[k];
+      const uint4 v = mx_ld16(off + 4 * k);
       r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y;
       if (4 * k + 2 < N) { r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w; }
     }
   } else {
     static_assert(!PACKED || N % 4 == 2, "packed halves: NL = 2 mod 4");
     if (!second) {
-      const uint4* p = reinterpret_cast<const uint4*>(lds + off);
 #pragma unroll
       for (int k = 0; k < (N + 2) / 4; ++k) {
-        const uint4 v = p[k];
+        const uint4 v = mx_ld16(off + 4 * k);
         r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y;
         if (4 * k + 2 < N) { r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w; }
       }
     } else {
-      const uint4* p = reinterpret_cast<const uint4*>(lds + off - 2);
-      const uint4 v0 = p[0];
+      const uint4 v0 = mx_ld16(off - 2);
       r.v[0] = v0.z; r.v[1] = v0.w;
 #pragma unroll
       for (int k = 1; k < (N + 2) / 4; ++k) {
-        const uint4 v = p[k];
+        const uint4 v = mx_ld16(off - 2 + 4 * k);
         r.v[4 * k - 2] = v.x; r.v[4 * k - 1] = v.y; r.v[4 * k] = v.z; r.v[4 * k + 1] = v.w;
       }
     }

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <algorithm>
 #include <vector>
 #include "miller_x.hpp"
@@ -37,14 +38,27 @@ static void time_x(const char* name, size_t n, int rot, int reps) {
   for (auto& e : ev) CHK(hipEventCreate(&e));
   for (int w = 0; w < 2; ++w) k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
   CHK(hipDeviceSynchronize());
-  CHK(hipEventRecord(ev[0]));
-  for (int r = 0; r < reps; ++r) {
-    k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
-    CHK(hipEventRecord(ev[r + 1]));
-  }
-  CHK(hipDeviceSynchronize());
   std::vector<float> ms(reps);
-  for (int r = 0; r < reps; ++r) CHK(hipEventElapsedTime(&ms[r], ev[r], ev[r + 1]));
+  const char* gap = getenv("MB_GAP_US");                  // idle time before every launch (a lone verification starts on an idle GPU)
+  if (gap) {
+    for (int r = 0; r < reps; ++r) {
+      CHK(hipDeviceSynchronize());
+      usleep(atoi(gap));
+      CHK(hipEventRecord(ev[0]));
+      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+      CHK(hipEventRecord(ev[1]));
+      CHK(hipDeviceSynchronize());
+      CHK(hipEventElapsedTime(&ms[r], ev[0], ev[1]));
+    }
+  } else {
+    CHK(hipEventRecord(ev[0]));
+    for (int r = 0; r < reps; ++r) {
+      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+      CHK(hipEventRecord(ev[r + 1]));
+    }
+    CHK(hipDeviceSynchronize());
+    for (int r = 0; r < reps; ++r) CHK(hipEventElapsedTime(&ms[r], ev[r], ev[r + 1]));
+  }
   std::sort(ms.begin(), ms.end());
   printf("%-6s NP=%d n=%zu blocks=%zu mode=%d lds=%d B  per launch: min %.3f  median %.3f  max %.3f ms   (%.2f M pairings/s at the median)\n", name, NP, n, nb, rot, K::BLOCK_BYTES,
          ms[0], ms[reps / 2], ms[reps - 1], n / ms[reps / 2] / 1e3);
