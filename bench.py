@@ -42,7 +42,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from bgls_amd import _lib  # noqa: E402
-from bgls_amd.sharding import all_gather_bytes, gather_partials_and_flags, global_duplicate_scan, shard_range  # noqa: E402
+from bgls_amd.sharding import (all_gather_bytes, enqueue_digest_probe, gather_partials_and_flags, settle_digest_hit,  # noqa: E402
+                                shard_range)
 
 # Algorithmic work model (SURVEY.md 8d / DESIGN.md): 32x32->64 MACs per unit.
 MAC_PER_FPMUL = {0: 136, 1: 300}                       # CIOS 2L^2+L, L = 8 / 12
@@ -129,8 +130,10 @@ def pinned_peak(lib):
 
 
 def traffic_for(kernel_key):
-    """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r3, r2): a
-    builder-held constant of the evidence run, not measured in this process (labelled as such)."""
+    """HBM-side traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r4, r3, r2): a
+    builder-held constant of the evidence run, not measured in this process (labelled as such).  The same file carries the
+    evidence run's SQ readings of the kernel: valu_busy = rocprofiler's VALUBusy (sum SQ_ACTIVE_INST_VALU / CUs /
+    GRBM_GUI_ACTIVE per XCD) and lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
     for rnd in ("r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(path):
@@ -188,7 +191,8 @@ def _num(x, digits=4):
 
 def collective_info(cid, world):
     """what the N > 1 exchange is: one all-gather of GT partials + status words per step"""
-    info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 4), "op": "all_gather"}
+    info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 4), "op": "all_gather",
+            "digest_bytes_per_signer": 16}       # + one all-gather of 16-byte message digests (global duplicate rule), 16 B per signer of the batch
     try:
         info["backend"] = dist.get_backend()
         info["world"] = dist.get_world_size()
@@ -211,6 +215,10 @@ def compact_line(full):
         out = {"bound": r.get("bound"), "kernel": ex.get("kernel", r.get("kernel")), "unit": r.get("unit"), "peak": _num(r.get("peak")),
                "achieved": _num(ex.get("achieved", r.get("achieved"))), "frac": _num(ex.get("frac", r.get("frac"))),
                "launch_ms": _num(ex.get("launch_ms", r.get("launch_ms"))), "traffic": r.get("traffic")}
+        td = r.get("traffic_detail") or {}
+        for k in ("valu_busy", "lds_conflict_ratio"):          # counter readings of the committed evidence run (profiles/rN/pmc_traffic.json)
+            if td.get(k) is not None:
+                out[k] = _num(td[k])
         if ex:
             out["frac_timed_region"] = _num(r.get("frac"))
             out["kernel_timed_region"] = r.get("kernel")
@@ -265,14 +273,17 @@ class Lanes:
         while len(Lanes._streams) < L:
             Lanes._streams.append(torch.cuda.Stream(device=dev))
         self.lanes = [{"stream": Lanes._streams[k], "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
-                       "flags": torch.zeros(1, dtype=torch.int32, device=dev)} for k in range(L)]
+                       "flags": torch.zeros(1, dtype=torch.int32, device=dev), "probe": torch.zeros(1, dtype=torch.int32, device=dev)} for k in range(L)]
 
-    def run(self, count, submit, overlap):
+    def run(self, count, submit, overlap, settle=None):
+        """settle(k, verdict) -> verdict: called after a lane's verdict has been collected (its stream is idle then); the
+        multi-GPU path uses it to settle a digest hit of the global duplicate scan."""
         lib, L, cid = self.lib, self.L, self.cid
 
         def collect(k):
             check(lib.bgls_select_context(k), "select_context")
-            return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
+            v = check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
+            return settle(k, v) if settle else v
 
         try:
             if not overlap:
@@ -330,9 +341,15 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
             ln["flags"].zero_()
             if h2d:                       # messages arrive from the host inside the timed region (keys stay resident)
                 msgs_t.copy_(h_msgs, non_blocking=True)
-            if world > 1:                 # duplicates may straddle shards: exact scan over every rank's messages
-                global_duplicate_scan(lambda buf, count: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), 64, 64, count, ln["flags"].data_ptr(), h),
-                                                               "duplicate_scan_dev"), msgs_t, n, world)
+            if world > 1:
+                # duplicates may straddle shards (containsDuplicateMessage is a rule about the whole list): the ranks exchange
+                # 16-byte digests of their messages, not the messages (16 MiB instead of 64 MiB at 2^20), and scan those; a hit is
+                # settled exactly when the verdict is collected (settle below)
+                ln["probe"].zero_()
+                ln["msgs"] = msgs_t
+                enqueue_digest_probe(lambda m, cnt: digests_of(m, cnt, h),
+                                     lambda buf, rl, cnt: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), rl, rl, cnt, ln["probe"].data_ptr(), h), "duplicate_scan_dev"),
+                                     msgs_t, n, world)
             if handle is not None:
                 check(lib.bgls_miller_product_keys_dev(handle, t_sig.data_ptr(), msgs_t.data_ptr(), 64, 64, n, 1, ln["part"].data_ptr(), ln["flags"].data_ptr(), h),
                       "miller_product_keys_dev")
@@ -345,10 +362,31 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
                 parts, merged = gather_partials_and_flags(ln["part"], ln["flags"], world)
                 check(lib.bgls_final_verify_submit_dev(cid, parts.data_ptr(), world, merged.data_ptr(), h), "final_verify_submit_dev")
 
+    gate = {"digest_hits": 0}
+
+    def digests_of(m, cnt, h):
+        d = torch.empty(cnt * 16, dtype=torch.uint8, device=dev)
+        check(lib.bgls_message_digests_dev(m.data_ptr(), 64, 64, cnt, d.data_ptr(), h), "message_digests_dev")
+        return d
+
+    def settle(k, verdict):
+        """A digest hit of lane k's global duplicate scan (a real duplicate or a 2^-128 collision) is settled by the exact scan over
+        the gathered messages; a duplicate makes the verification false (bgls/bgls.go:98-100)."""
+        ln = lanes.lanes[k]
+        if world == 1 or int(ln["probe"].item()) == 0:
+            return verdict
+        gate["digest_hits"] += 1
+        word = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(ln["stream"]):
+            settle_digest_hit(lambda buf, rl, cnt: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), rl, rl, cnt, word.data_ptr(), ln["stream"].cuda_stream),
+                                                         "duplicate_scan_dev"), ln["msgs"], n, world)
+        ln["stream"].synchronize()
+        return 0 if int(word.item()) & 1 else verdict
+
     def one(msgs_t=t_msgs):
         submit(0, msgs_t)
         check(lib.bgls_select_context(0), "select_context")
-        return check(lib.bgls_final_verify_collect(cid), "final_verify_collect")
+        return settle(0, check(lib.bgls_final_verify_collect(cid), "final_verify_collect"))
 
     def sync():
         if world > 1:
@@ -365,6 +403,16 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     if one(bad) != 0:
         raise RuntimeError("tampered instance accepted (%s)" % label)
     del bad
+    if world > 1:                         # a duplicate that straddles two shards: found through the digests, settled by the exact scan
+        dup = t_msgs.clone()
+        if rank == 0:
+            dup[0:64] = 0xA5
+        if rank == world - 1:
+            dup[64 * (n - 1):64 * n] = 0xA5
+        torch.cuda.synchronize()
+        if one(dup) != 0 or gate["digest_hits"] != 1:
+            raise RuntimeError("cross-shard duplicate message not caught by the digest scan (%s)" % label)
+        del dup
 
     pipelined = L > 1
     # warm-up: W steps one at a time with the stage timers on -- these give each kernel's duration when it has the machine
@@ -386,13 +434,13 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         # batches whose last round of blocks is nearly empty -- the neighbours fill it; verdicts are identical in both modes
         check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
     if pipelined:
-        lanes.run(L, lambda k: submit(k), True)
+        lanes.run(L, lambda k: submit(k), True, settle)
     regions = []
     for _ in range(reps):
         lib.bgls_profile_enable(1)
         sync()
         t0 = time.perf_counter()
-        lanes.run(steps, lambda k: submit(k), pipelined)
+        lanes.run(steps, lambda k: submit(k), pipelined, settle)
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -405,7 +453,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     if with_h2d and world == 1:
         sync()
         t0 = time.perf_counter()
-        lanes.run(steps, lambda k: submit(k, h2d=True), pipelined)
+        lanes.run(steps, lambda k: submit(k, h2d=True), pipelined, settle)
         sync()
         h2d_elapsed = time.perf_counter() - t0
     check(lib.bgls_set_throughput_mode(0), "set_throughput_mode")

@@ -629,23 +629,28 @@ struct Engine {
   static int sum_sets(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, const uint64_t* d_off, size_t nsets, size_t max_set,
                       uint8_t* d_out, uint32_t* d_flags) {
     if (nsets == 0) return 0;
-    size_t P = 64;
+    // P partials (lane pairs / lanes) per set, a power of two.  The lane-pair kernel adds the 32 sums of a block itself and
+    // leaves ONE partial per block, so a set of a few keys needs one block (P = 32) and no tree; the other kernels write one
+    // partial per lane of at least one wave (P = 64).  Workspaces are sized by what the selected kernel writes.
+    const bool pairs = group == BGLS_G2 && sum_mode<C>() == 2;
+    size_t P = pairs ? 32 : 64;
     while (P < 8192 && P * 4 <= max_set && nsets * P * 2 <= (size_t)131072) P *= 2;     // >= 4 points per partial, <= 2048 waves in all
+    const size_t written = pairs ? nsets * (P / 32) : nsets * P;                         // partial sums the main pass leaves
+    const size_t blocks = pairs ? nsets * (P / 32) : nsets * (P / 64);
+    const size_t JB = kl::jac_bytes<C>(group);
+    // bounds of one call: the grid of the main pass and the partials' workspace (the caller can cut a larger job into calls)
+    if (blocks > ((size_t)1 << 30) || (written + 1) * JB > ((size_t)8 << 30))
+      return fail(BGLS_ERR_ARG, "too many key sets for one call (cut the batch: at most 2^30 blocks / 8 GiB of partial sums)");
     void *ja, *jb;
     int rc;
     Scope sc(c, st, ST_SUM);
-    const size_t JB = kl::jac_bytes<C>(group);
-    if ((rc = c.get(WS_JAC_A, (nsets * P + 1) * JB, &ja))) return rc;
-    if ((rc = c.get(WS_JAC_B, (nsets * P / 2 + 2) * JB, &jb))) return rc;
+    if ((rc = c.get(WS_JAC_A, (written + 1) * JB, &ja))) return rc;
+    if ((rc = c.get(WS_JAC_B, (written / 2 + 2) * JB, &jb))) return rc;
     if (group == BGLS_G2 && sum_mode<C>() == 2) kl::sumpairseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumxseg_main<C>(st, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     else kl::sumseg_main<C>(st, group, d_pts, d_off, nsets, (unsigned)P, ja, d_flags);
     void *a = ja, *b = jb;
-    size_t p = P, cnt = nsets * P;
-    if (group == BGLS_G2 && sum_mode<C>() == 2) {             // the lane-pair kernel leaves one partial per block of 32 pairs
-      p = P / 32;
-      cnt = nsets * p;
-    }
+    size_t p = pairs ? P / 32 : P, cnt = written;
     while (p > 1) {
       if (group == BGLS_G2 && cnt <= 8192) {
         kl::sum_coop<C>(st, a, cnt, b);
@@ -680,7 +685,8 @@ struct Engine {
     const bool pairs = group == BGLS_G2 && sum_mode<C>() == 2;
     if (pairs) {                      // one running sum per lane pair, three waves per SIMD resident (3072), >= ~4 keys per pair;
       waves = (n + 127) / 128;        // a block (one wave) adds its 32 sums itself and leaves ONE partial
-      if (waves > 3072) waves = 3072;
+      static const size_t cap = [] { const char* e = getenv("BGLS_SUM_WAVES"); const long v = e ? atol(e) : 0; return v >= 64 && v <= 8192 ? (size_t)v : (size_t)3072; }();
+      if (waves > cap) waves = cap;
     }
     const size_t partials = pairs ? waves : waves * 64;
     void *ja, *jb;
@@ -2396,6 +2402,22 @@ int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_strid
   if (!d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n >= (1ull << 30)) return fail(BGLS_ERR_ARG, "too many messages for one scan");
   return duplicate_scan_dev(d_msgs, msg_len, msg_stride, n, d_flags, stream);
+}
+
+int bgls_message_digests_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_out16, void* stream) {
+  if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
+  if (n && (!d_out16 || (!d_msgs && msg_len))) return fail(BGLS_ERR_ARG, "NULL argument");
+  if (((uintptr_t)d_out16 & 15) != 0) return fail(BGLS_ERR_ARG, "digest buffer must be 16-byte aligned");
+  if (n == 0) return 0;
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int rc;
+  if ((rc = c.enter())) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+  MsgView mv = {(const uint8_t*)d_msgs, nullptr, msg_len, msg_stride};
+  kl::msg_digest(st, mv, n, (uint8_t*)d_out16);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {

@@ -331,9 +331,24 @@ __global__ void __launch_bounds__(64) k_blake2x_expand(const u64* root, u32 xof_
   for (u32 b = 0; b < take; ++b) out[(size_t)64 * i + b] = (uint8_t)(o[b >> 3] >> (8 * (b & 7)));
 }
 
+// 16-byte digests of fixed-stride messages: the first 16 bytes of BLAKE2b-512 (the multi-GPU duplicate scan exchanges these
+// instead of the messages; equal messages have equal digests, so "no two digests equal" proves "no two messages equal" and a
+// hit falls back to the exact byte scan)
+__global__ void k_msg_digest(MsgView mv, size_t n, uint8_t* out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ByteSrc src = {mv.ptr(i), mv.size(i), {0}, 0, {0, 0, 0, 0}, 0};
+  u32 d[16];
+  blake2b512(src, d);
+  uint4 w = make_uint4(__builtin_bswap32(d[0]), __builtin_bswap32(d[1]), __builtin_bswap32(d[2]), __builtin_bswap32(d[3]));
+  *reinterpret_cast<uint4*>(out + 16 * i) = w;
+}
+
 // ======================================================================= launchers
 namespace bgls {
 namespace kl {
+
+void msg_digest(hipStream_t st, MsgView mv, size_t n, uint8_t* out) { k_msg_digest<<<nblk(n, 256), 256, 0, st>>>(mv, n, out); }
 
 void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
   k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags);

@@ -44,10 +44,36 @@ def gather_partials_and_flags(part, flags, world):
     return parts, merged
 
 
-def global_duplicate_scan(scan, msgs, n_local, world):
+def global_duplicate_scan(scan, msgs, n_local, world, digest=None, msg_len=64, probe=None):
     """containsDuplicateMessage (bgls/bgls.go:139-150) is a property of the WHOLE message list: two equal messages may sit
-    in different shards.  Every rank all-gathers the (fixed-stride, equal-count) message bytes and runs the exact scan
-    over all world * n_local of them; `scan(buffer, count)` is bgls_duplicate_scan_dev on the GPU path."""
+    in different shards.  `scan(buffer, record_len, count)` is the exact scan over `count` fixed-stride records
+    (bgls_duplicate_scan_dev on the GPU path: sets the duplicate bit of the caller's status word).
+
+    With `digest` (messages -> uint8[n_local * 16], bgls_message_digests_dev) the ranks exchange 16-byte digests instead of the
+    messages -- 16 MiB instead of 64 MiB at 2^20 signers -- and every rank scans the world * n_local digests with
+    `probe(buffer, 16, count) -> bool` (the same exact scan on a scratch status word).  Equal messages have equal digests, so
+    "no two digests equal" proves the rule; a hit (a real duplicate, or a 2^-128 collision) is settled by gathering the
+    messages and running the exact scan, as the digest-free path always does.  Every rank takes the same branch: all of
+    them scan the same gathered digests."""
     if world == 1:
-        return scan(msgs, n_local)
-    return scan(all_gather_bytes(msgs, world).reshape(-1), world * n_local)
+        return scan(msgs, msg_len, n_local)
+    if digest is not None and probe is not None:
+        digests = all_gather_bytes(digest(msgs, n_local), world).reshape(-1)
+        if not probe(digests, 16, world * n_local):
+            return None
+    return scan(all_gather_bytes(msgs, world).reshape(-1), msg_len, world * n_local)
+
+
+def enqueue_digest_probe(digest, probe_scan, msgs, n_local, world):
+    """The asynchronous half of the digest path, for pipelined callers (bench.py: several verifications in flight): enqueue the
+    digests, their all-gather and the scan over them -- `probe_scan(buffer, 16, count)` ORs the duplicate bit into a word of
+    the caller's that is NOT the verification's status word.  Nothing is read back here.  When the verdict is collected the
+    caller reads that word; if it is set, `settle_digest_hit` runs the exact scan over the gathered messages (every rank sees
+    the same digests, so every rank takes the same branch)."""
+    digests = all_gather_bytes(digest(msgs, n_local), world).reshape(-1)
+    probe_scan(digests, 16, world * n_local)
+
+
+def settle_digest_hit(scan, msgs, n_local, world, msg_len=64):
+    """Two digests were equal: a real duplicate or a collision.  The exact rule decides: gather the messages, scan them."""
+    return scan(all_gather_bytes(msgs, world).reshape(-1), msg_len, world * n_local)

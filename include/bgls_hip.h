@@ -92,7 +92,13 @@ int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t
  * key_b = AggregateKeys(set b) with set b = keys[key_off[b] .. key_off[b+1]) (counts of points, n_sets + 1 offsets), then
  * verifyAggSig(aggsig, key_0 .. key_{n_sets-1}, msgs, allow_duplicates) -- ONE launch for all key sums, one Miller launch and
  * one final exponentiation for all the sets.  The Go function prepends 0x01 to every message and passes
- * allow_duplicates = true (KoskVerifyAggregateSignature, bgls/blsKosk.go:100-106); the host mirrors do the same. */
+ * allow_duplicates = true (KoskVerifyAggregateSignature, bgls/blsKosk.go:100-106); the host mirrors do the same.
+ * Keys are checked for canonical encoding and curve membership, NOT for subgroup membership: like every Verify* entry point
+ * this call takes Points the caller has constructed (validated) already -- bgls_check_points / bgls_keys_upload(BGLS_KEYS_CHECK)
+ * are the constructors' checks; a degenerate point step of a small-order key is reported as BGLS_ERR_ENCODING.
+ * One call handles what fits one launch: at most 2^30 blocks of the key-sum pass and 8 GiB of partial sums (a set of up to
+ * 128 keys takes one block and one 192 / 288-byte partial: 2^25 such sets); larger jobs return BGLS_ERR_ARG and are cut by
+ * the caller. */
 int bgls_verify_multi_batch(int curve, const uint8_t* sigs, const uint8_t* keys, const uint64_t* key_off, size_t n_sets,
                             const uint8_t* msg_blob, const uint64_t* msg_off, int allow_duplicates);
 /* AggregatePoints (curves/curve.go:73-121) over n_sets sets in one pass: out[b] = sum of pts[set_off[b] .. set_off[b+1])
@@ -220,6 +226,12 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
  * (a duplicate may straddle two shards); the per-shard scan inside bgls_miller_product_dev covers one GPU. */
 int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags,
                             void* stream);
+/* 16-byte digests (the first 16 bytes of BLAKE2b-512) of n device-resident fixed-stride messages, to d_out16 (n x 16 bytes,
+ * 16-byte aligned).  What the ranks of a multi-GPU verification exchange for the global containsDuplicateMessage rule
+ * (bgls/bgls.go:139-150) instead of the messages themselves: no two equal digests => no two equal messages; a pair of equal
+ * digests is settled by the exact scan over the messages (bgls_amd/sharding.py global_duplicate_scan). */
+int bgls_message_digests_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_out16,
+                             void* stream);
 
 /* Multiply `count` partial products (count x bgls_gt_size bytes, e.g. the all-gathered shards),
  * apply the single shared final exponentiation and compare with 1.  Returns 1 / 0 / < 0.

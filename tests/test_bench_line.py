@@ -20,7 +20,8 @@ def _canned_record(bench, name, prose=4000):
             "ms_per_step_all": [72.1, 73.7, 74.9], "steps": 20, "warmup": 5, "repetitions": 3, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
             "config": {"workload": note, "curve": name, "signers": 1 << 20, "signers_per_gpu": 1 << 20, "in_flight": 4, "parallelism": note},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_miller_s60<BN254>", "peak": 33.251234, "unit": "TMAC/s", "achieved": 15.9, "frac": 0.4781234,
-                         "launch_ms": 4.6, "launches_per_step": 16, "macs_per_launch": 7.35e10, "traffic": 104857600, "traffic_detail": {"note": note},
+                         "launch_ms": 4.6, "launches_per_step": 16, "macs_per_launch": 7.35e10, "traffic": 104857600,
+                         "traffic_detail": {"note": note, "valu_busy": 0.8191234, "lds_conflict_ratio": 0.1021234},
                          "exclusive": {"kernel": "k_miller_ab64<BN254>", "launch_ms": 5.788, "achieved": 12.7, "frac": 0.3912345, "note": note},
                          "hbm_side": {"achieved": 2.7, "peak": 8000.0, "unit": "GB/s", "note": note}, "whole_path_frac": 0.52, "note": note},
             "sequential": {"ms_per_step_median": 91.0, "note": note}, "stage_ms_per_step": {"miller": 70.0}, "stage_ms_exclusive": {"miller": 84.0},
@@ -48,6 +49,8 @@ def test_last_line_is_compact_and_complete():
     assert roof["kernel"] == "k_miller_ab64<BN254>" and abs(roof["frac"] - 0.3912) < 1e-3
     assert abs(roof["frac_timed_region"] - 0.4781) < 1e-3 and roof["kernel_timed_region"] == "k_miller_s60<BN254>"
     assert set(roof) >= {"bound", "kernel", "peak", "achieved", "frac", "launch_ms", "traffic", "unit"}
+    # north_star: "evidenced by rocprof HBM GB/s and VALU-busy against gfx950 peak" -- the evidence run's counter readings ride along
+    assert abs(roof["valu_busy"] - 0.8191) < 1e-3 and abs(roof["lds_conflict_ratio"] - 0.1021) < 1e-3 and roof["hbm_gbps"] == 2.7
     assert rec["cpu_baseline"]["cores"] == 64 and rec["cpu_baseline"]["kind"] == "port" and len(rec["cpu_baseline"]["sample"]) <= 120
     assert len(rec["records"]) == 8
     for r in rec["records"].values():

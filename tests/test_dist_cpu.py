@@ -78,18 +78,48 @@ def _worker_flags(rank, world, port, q):
         msgs[2 * ln:3 * ln] = bytes([1]) * ln                 # equals message 1 of rank 0
     seen = {}
 
-    def scan(buf, count):
+    def scan(buf, rl, count):
         raw = bytes(buf.numpy())
-        items = [raw[i * ln:(i + 1) * ln] for i in range(count)]
+        items = [raw[i * rl:(i + 1) * rl] for i in range(count)]
         seen["count"] = count
+        seen["bytes"] = len(raw)
         seen["dup"] = len(set(items)) != len(items)           # exact, like bgls/bgls.go:139-150
         return 0
 
     t = torch.frombuffer(msgs, dtype=torch.uint8)
-    scan(t, n_local)
+    scan(t, ln, n_local)
     local_dup = seen["dup"]
-    global_duplicate_scan(scan, t, n_local, world)
-    q.put((rank, ok1, local_dup, seen["dup"], seen["count"]))
+    global_duplicate_scan(scan, t, n_local, world, msg_len=ln)
+    full = (seen["dup"], seen["count"])
+    # (3) the digest path: 16-byte digests travel instead of the messages; a hit is settled by the exact scan, no hit ends there
+    import hashlib
+    traffic = {"digest": 0, "probe_hits": 0, "exact_scans": 0}
+
+    def digest(m, cnt):
+        raw = bytes(m.numpy())
+        out = b"".join(hashlib.blake2b(raw[i * ln:(i + 1) * ln]).digest()[:16] for i in range(cnt))    # what bgls_message_digests_dev computes
+        traffic["digest"] += len(out)
+        return torch.frombuffer(bytearray(out), dtype=torch.uint8)
+
+    def probe(buf, rl, count):
+        raw = bytes(buf.numpy())
+        items = [raw[i * rl:(i + 1) * rl] for i in range(count)]
+        hit = len(set(items)) != len(items)
+        traffic["probe_hits"] += hit
+        return hit
+
+    def exact(buf, rl, count):
+        traffic["exact_scans"] += 1
+        return scan(buf, rl, count)
+
+    seen["dup"] = None
+    global_duplicate_scan(exact, t, n_local, world, digest=digest, msg_len=ln, probe=probe)
+    with_dup = (seen["dup"], traffic["probe_hits"], traffic["exact_scans"])
+    clean = bytearray(b"".join(bytes([16 * rank + i]) * ln for i in range(n_local)))
+    seen["dup"] = None
+    global_duplicate_scan(exact, torch.frombuffer(clean, dtype=torch.uint8), n_local, world, digest=digest, msg_len=ln, probe=probe)
+    without_dup = (seen["dup"], traffic["probe_hits"], traffic["exact_scans"], traffic["digest"])
+    q.put((rank, ok1, local_dup, full[0], full[1], with_dup, without_dup))
     dist.destroy_process_group()
 
 
@@ -103,5 +133,57 @@ def test_two_rank_flags_and_cross_shard_duplicates():
     res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-    for rank, ok1, local_dup, global_dup, count in res:
+    for rank, ok1, local_dup, global_dup, count, with_dup, without_dup in res:
         assert ok1 and not local_dup and global_dup and count == 8, (rank, ok1, local_dup, global_dup, count)
+        assert with_dup == (True, 1, 1), with_dup                      # digest hit -> exact scan over the gathered messages -> duplicate
+        assert without_dup == (None, 1, 1, 2 * 4 * 16), without_dup    # no digest hit: no exact scan, no message ever gathered
+
+
+def _worker_multisig(rank, world, port, cid, keys, sig, bad_sig, msg, n, q):
+    """BASELINE config 4 over N ranks (bench.py bench_multisig_sharded's data path, SURVEY 8e multisig variant): every rank adds its
+    contiguous range of the keys, ONE all-gather of the partial key sums, every rank adds the N partials and runs the
+    two-pairing check -- the oracle stands in for the HIP library on this CPU tier."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fp = 32 if cid == 0 else 48
+    lo, hi = shard_range(n, rank, world)
+    part = coracle.aggregate_points(cid, 2, keys[lo * 4 * fp:hi * 4 * fp], hi - lo)
+    parts = all_gather_bytes(torch.frombuffer(bytearray(part), dtype=torch.uint8), world)
+    flat = bytes(parts.reshape(-1).numpy())
+    ok = coracle.verify_multi(cid, sig, flat, world, msg)
+    ok_bad = coracle.verify_multi(cid, bad_sig, flat, world, msg)
+    # a rank that drops its last key changes the aggregate key: every rank must reject
+    short = coracle.aggregate_points(cid, 2, keys[lo * 4 * fp:(hi - (1 if rank == world - 1 else 0)) * 4 * fp], hi - lo - (1 if rank == world - 1 else 0))
+    parts2 = all_gather_bytes(torch.frombuffer(bytearray(short), dtype=torch.uint8), world)
+    ok_short = coracle.verify_multi(cid, sig, bytes(parts2.reshape(-1).numpy()), world, msg)
+    whole = coracle.aggregate_points(cid, 2, keys[:n * 4 * fp], n)
+    summed = coracle.aggregate_points(cid, 2, flat, world)
+    q.put((rank, ok, ok_bad, ok_short, whole == summed, parts.shape[0], parts.shape[1]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_multisig_gathers_partial_key_sums():
+    from tests.conftest import load_golden
+    for cid, name in ((0, "altbn128"), (1, "bls12")):
+        fp = 32 if cid == 0 else 48
+        case = next(c for c in load_golden("vectors_%s.json" % name)["multi_cases"] if c["expect"] and len(c["keys"]) >= 4)
+        bad = next(c for c in load_golden("vectors_%s.json" % name)["multi_cases"] if not c["expect"])
+        keys = b"".join(bytes.fromhex(k) for k in case["keys"])
+        n = len(case["keys"])
+        sig, msg = bytes.fromhex(case["sig"]), bytes.fromhex(case["msg"])
+        bad_sig = bytes.fromhex(bad["sig"]) if bytes.fromhex(bad["sig"]) != sig else bytes(2 * fp)
+        assert coracle.verify_multi(cid, sig, keys, n, msg) == 1
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_multisig, args=(r, 2, port, cid, keys, sig, bad_sig, msg, n, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+        for rank, ok, ok_bad, ok_short, same_sum, rows, width in res:
+            assert ok == 1 and ok_short == 0 and same_sum and rows == 2 and width == 4 * fp, (name, rank, ok, ok_bad, ok_short, same_sum, rows, width)
+            if bad_sig != bytes(2 * fp):
+                assert ok_bad == 0

@@ -91,3 +91,30 @@ def test_batch_multi_signature_verdicts(gpu_lib, curve):
     # an off-curve key anywhere is an encoding error, not a verdict
     bad = bytearray(keys); bad[4 * n_fp * 3 + 5] ^= 0x40
     assert gpu_lib.bgls_verify_multi_batch(cid, B(aggs), B(bytes(bad)), offs([2, 3]), 2, B(b"".join(msgs)), offs([len(m) for m in msgs]), 1) < 0
+
+
+def test_many_small_sets_take_one_block_each(gpu_lib, curve):
+    """Thousands of key sets of 1..3 keys (round-3 advisor finding: every set took 64 partial sums and two blocks whatever its
+    size, so 2^16 sets needed 1.2 GB of workspace and 2^20 sets 19 GB).  The lane-pair kernel now gives a small set ONE block and
+    ONE partial (no tree above it); the sums still equal the oracle's, set by set."""
+    cid, n_fp = curve["id"], curve["fp"]
+    rnd = random.Random(2024 + cid)
+    base = 40
+    sks = [rnd.randrange(1, 1 << 250) for _ in range(base)]
+    kb = b"".join(s.to_bytes(32, "big") for s in sks)
+    pool = out(base * 4 * n_fp)
+    assert gpu_lib.bgls_scale_generator(cid, 2, B(kb), base, pool) == 0
+    pool = [bytes(pool)[i * 4 * n_fp:(i + 1) * 4 * n_fp] for i in range(base)]
+    nsets = 6000
+    sizes = [rnd.choice((1, 1, 2, 3, 0)) for _ in range(nsets)]
+    picks = [[rnd.randrange(base) for _ in range(c)] for c in sizes]
+    keys = b"".join(pool[i] for p in picks for i in p)
+    got = out(nsets * 4 * n_fp)
+    assert gpu_lib.bgls_aggregate_sets(cid, 2, B(keys), offs(sizes), nsets, got) == 0
+    got = bytes(got)
+    memo = {}
+    for b in list(range(0, nsets, 97)) + [nsets - 1]:
+        key = tuple(sorted(picks[b]))
+        if key not in memo:
+            memo[key] = coracle.aggregate_points(cid, 2, b"".join(pool[i] for i in key), len(key)) if key else bytes(4 * n_fp)
+        assert got[b * 4 * n_fp:(b + 1) * 4 * n_fp] == memo[key], (b, picks[b])
