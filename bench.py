@@ -529,9 +529,12 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     return rec
 
 
-def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
+def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=False):
     """BASELINE config 4: n signers on ONE message -- G2 key sum (AggregatePoints, curves/curve.go:73-121) + hash + 2
-    pairings (bgls/bgls.go:59-70,89-92; KoskVerifyMultiSignature's 0x01 prefix, bgls/blsKosk.go:117-120).  Single GPU."""
+    pairings (bgls/bgls.go:59-70,89-92; KoskVerifyMultiSignature's 0x01 prefix, bgls/blsKosk.go:117-120).  Single GPU.
+    key_set = False: the keys are the reference's wire bytes in HBM, parsed and checked against the curve inside the key sum.
+    key_set = True: the keys are a resident key set (bgls_keys_upload: the reference's already-constructed Points, which is what
+    its benchmarks time, bgls/bgls_test.go:186-199) -- the key sum reads the set's sum-ready records."""
     cid, fp = inst["cid"], inst["fp"]
     rnd = random.Random(0xB6150000 + 4)
     msg = b"\x01" + rnd.randbytes(64)
@@ -545,7 +548,17 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
     t_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    handle = None
+    if key_set:
+        hh = ctypes.c_uint64()
+        check(lib.bgls_keys_upload(cid, B(inst["keys"][:n * 4 * fp]), n, None, 1, 0, ctypes.byref(hh)), "keys_upload")
+        handle = hh.value
+        t_bad = torch.frombuffer(bytearray(msg[:-1] + bytes([msg[-1] ^ 1])), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+
     def one(nn=n):
+        if handle is not None:            # nn != n: the negative control is a changed message (the set is what it is)
+            return check(lib.bgls_verify_multi_keys_dev(handle, t_sig.data_ptr(), (t_msg if nn == n else t_bad).data_ptr(), len(msg), stream), "verify_multi_keys_dev")
         return check(lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), nn, t_msg.data_ptr(), len(msg), stream), "verify_multi_dev")
 
     if one() != 1 or one(n - 1) != 0:
@@ -556,6 +569,9 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
 
     def submit(k):
         check(lib.bgls_select_context(k), "select_context")
+        if handle is not None:
+            check(lib.bgls_verify_multi_keys_submit_dev(handle, t_sig.data_ptr(), t_msg.data_ptr(), len(msg), lanes.lanes[k]["stream"].cuda_stream), "verify_multi_keys_submit_dev")
+            return
         check(lib.bgls_verify_multi_submit_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_msg.data_ptr(), len(msg), lanes.lanes[k]["stream"].cuda_stream),
               "verify_multi_submit_dev")
 
@@ -578,6 +594,8 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
         torch.cuda.synchronize()
         regions.append(time.perf_counter() - t0)
     lib.bgls_profile_enable(0)
+    if handle is not None:
+        check(lib.bgls_keys_free(handle), "keys_free")
     peak = pinned_peak(lib)
     per_step = sorted(r / steps for r in regions)
     med = statistics.median(per_step)
@@ -589,8 +607,10 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight):
     return {
         "metric": "multisig-verify signers/sec", "value": n / med, "unit": "signers/s", "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3,
         "ms_per_step_all": [p * 1e3 for p in per_step], "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM" % (CNAME[cid], n), "in_flight": L},
-        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sumpair_main", "peak": peak / 1e12, "unit": "TMAC/s",
+        "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM as %s"
+                               % (CNAME[cid], n, "a key set (parsed, validated Points: sum-ready records)" if key_set else "wire bytes (parsed and curve-checked in the key sum)"),
+                   "in_flight": L, "keys": "key_set" if key_set else "wire_bytes"},
+        "roofline": {"bound": "valu-int32-mac", "kernel": "k_sumpair_main<%s>" % ("2: sum-ready records" if key_set else "0: wire bytes"), "peak": peak / 1e12, "unit": "TMAC/s",
                      "achieved": macs / main_s / 1e12, "frac": macs / main_s / peak, "launch_ms": main_s * 1e3, "traffic": traffic, "traffic_detail": tdet,
                      "stage": {"name": "sum_points (main pass + tree + conversion to affine bytes)", "stage_ms": sum_s * 1e3, "achieved": macs / sum_s / 1e12,
                                "frac": macs / sum_s / peak},
@@ -784,6 +804,7 @@ def main():
     ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "multisig_batch", "small"], help="run ONE record (profiling runs): --curve, --n apply")
     ap.add_argument("--no-records", action="store_true", help="headline only")
     ap.add_argument("--prepared", action="store_true", help="with --only aggregate: verify against a prepared key set")
+    ap.add_argument("--key-set", action="store_true", help="with --only multisig: the keys are a resident key set (bgls_keys_upload) instead of wire bytes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -812,7 +833,7 @@ def main():
 
     if args.only == "multisig":
         inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000 + 4)
-        print(json.dumps(bench_multisig(lib, dev, inst, args.n, args.steps, args.warmup, args.reps, args.in_flight)), flush=True)
+        print(json.dumps(bench_multisig(lib, dev, inst, args.n, args.steps, args.warmup, args.reps, args.in_flight, key_set=args.key_set)), flush=True)
         return
     if args.only == "multisig_batch":
         inst = make_instance(lib, CURVE[args.curve], args.n, 0xB6150000 + 4)
@@ -850,6 +871,7 @@ def main():
                                                                                         tp, CNAME[c_] + " prepared", with_h2d=False, prepared=True)
             bn = inst if cid == 0 else oinst
             records["altbn128_multisig_%d" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16)
+            records["altbn128_multisig_%d_key_set" % bn["n"]] = bench_multisig(lib, dev, bn, bn["n"], 32, 2, args.reps, 16, key_set=True)
             records["altbn128_multisig_batch_16x%d" % bn["n"]] = bench_multisig_batch(lib, dev, bn, bn["n"], 16, 16, 2, args.reps, 8)
             records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)
             if not args.no_cpu_baseline:

@@ -54,6 +54,8 @@ SIGNATURES = {
     "bgls_verify_multi_multi": (ci, [ci, u8p, u8p, sz, u8p, sz, ctypes.POINTER(ctypes.c_int), ci]),
     "bgls_last_exchange": (ci, []),
     "bgls_miller_product_keys_dev": (ci, [ctypes.c_uint64, vp, vp, sz, sz, sz, ci, vp, vp, vp]),
+    "bgls_verify_multi_keys_dev": (ci, [ctypes.c_uint64, vp, vp, sz, vp]),
+    "bgls_verify_multi_keys_submit_dev": (ci, [ctypes.c_uint64, vp, vp, sz, vp]),
     "bgls_rccl_available": (ci, []),
     "bgls_verify_aggregate_h_gt": (ci, [ctypes.c_uint64, u8p, u8p, u64p, sz, ci, u8p]),
     "bgls_generator": (ci, [ci, ci, u8p]),

@@ -605,10 +605,10 @@ struct Engine {
     return finalize_collect(c);
   }
 
-  // AggregatePoints (curves/curve.go:73-121): affine bytes of the sum of n points to d_out.  parsed: d_pts are the
-  // resident Montgomery affine points of a key-set handle instead of wire bytes.
+  // AggregatePoints (curves/curve.go:73-121): affine bytes of the sum of n points to d_out.
+  // src: 0 = wire bytes; 1 = the Montgomery affine points of a key set; 2 = its sum-ready records (lane-pair kernel only)
   static int sum_points(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, uint8_t* d_out, uint32_t* d_flags,
-                        bool parsed = false) {
+                        int src = 0) {
     const size_t PTB = group == BGLS_G1 ? G1B : G2B;
     if (n == 0) {
       HIPCHK(hipMemsetAsync(d_out, 0, PTB, st));
@@ -618,7 +618,7 @@ struct Engine {
     int rc;
     if ((rc = c.get(WS_SUMJ, 4 * kl::jac_bytes<C>(group), &jac))) return rc;
     Scope sc(c, st, ST_SUM);                                   // one scope per key sum: the stage count equals the number of sums
-    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, parsed, false))) return rc;
+    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, src, false))) return rc;
     kl::jac_to_bytes<C>(st, group, jac, 1, d_out);
     HIPCHK(hipGetLastError());
     return 0;
@@ -673,7 +673,7 @@ struct Engine {
   // the same sum left in Jacobian form at d_jac (multi-device key sums exchange projective partials);
   // n == 0 gives the point at infinity (all-zero record: Z = 0)
   static int sum_points_jac(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, void* d_jac, uint32_t* d_flags,
-                            bool parsed = false, bool own_scope = true) {
+                            int src = 0, bool own_scope = true) {
     if (n == 0) {
       HIPCHK(hipMemsetAsync(d_jac, 0, kl::jac_bytes<C>(group), st));
       return 0;
@@ -698,9 +698,10 @@ struct Engine {
     if ((rc = c.get(WS_JAC_B, (partials / 2 + 2) * JB, &jb))) return rc;
     std::optional<Scope> scm;
     scm.emplace(c, st, ST_SUM_MAIN);
-    if (pairs) kl::sumpair_main<C>(st, parsed, d_pts, n, (unsigned)(waves * 32), ja, d_flags);                                  // lane pairs, carry-free limbs (rx_jacpair.hpp)
-    else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumx_main<C>(st, parsed, d_pts, n, (unsigned)waves, ja, d_flags); // one lane, carry-free limbs (rx_jac.hpp)
-    else kl::sum_main<C>(st, group, parsed, d_pts, n, (unsigned)waves, ja, d_flags);
+    if (src == 2 && !pairs) return fail(BGLS_ERR_ARG, "sum-ready records need the lane-pair key-sum kernel");
+    if (pairs) kl::sumpair_main<C>(st, src, d_pts, n, (unsigned)(waves * 32), ja, d_flags);                                     // lane pairs, carry-free limbs (rx_jacpair.hpp)
+    else if (group == BGLS_G2 && sum_mode<C>() == 1) kl::sumx_main<C>(st, src == 1, d_pts, n, (unsigned)waves, ja, d_flags); // one lane, carry-free limbs (rx_jac.hpp)
+    else kl::sum_main<C>(st, group, src == 1, d_pts, n, (unsigned)waves, ja, d_flags);
     scm.reset();
     void *a = ja, *b = jb;
     size_t cnt = partials;
@@ -778,7 +779,7 @@ int verify_aggregate_t(const uint8_t* sig, const uint8_t* keys, const uint8_t* b
 
 template <class C>
 int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8_t* d_keys, size_t n, const uint8_t* d_msg,
-                       size_t msg_len, bool submit_only = false) {
+                       size_t msg_len, bool submit_only = false, int key_src = 0) {
   typedef Engine<C> E;
   int rc;
   void *d_flags, *d_g2s, *d_g1s, *d_part;
@@ -789,7 +790,7 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   if ((rc = c.get(WS_PART, E::GTB, &d_part))) return rc;
   HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
   // apk = sum(keys)  (AggregatePoints)
-  if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags))) return rc;
+  if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags, key_src))) return rc;
   // pairs (H(msg), apk) and (-sig, g2) -- the reference's e(sig, g2) = e(H(msg), apk) (bgls/bgls.go:59-70) as a product that
   // must be 1: one message through the batch hashing path, then the two-pairing product on the cooperative Miller kernel
   // with the (-sig, g2) pair on the pre-computed generator lines
@@ -1674,7 +1675,8 @@ struct KeyShard {
   int device = 0;
   size_t lo = 0, hi = 0;
   void* d_wire = nullptr;    // (hi - lo) wire-format keys
-  void* d_mont = nullptr;    // the same keys as Aff<F2<C>> (Montgomery form), for the key sums
+  void* d_mont = nullptr;    // the same keys as Aff<F2<C>> (Montgomery form): prepared lines, weighted sums, the one-lane key sums
+  void* d_sumr = nullptr;    // the same keys as sum-ready records (k_g2_sumready): what the lane-pair key sum reads
   void* d_rec = nullptr;     // this shard's exchange record: GT partial + status word (send buffer)
   void* d_all = nullptr;     // every shard's record (receive buffer)
   // prepared sets (BGLS_KEYS_PREPARE, prepared.hpp): normalised line ratios of every key and step, [step][n_pad] rows
@@ -1694,7 +1696,7 @@ struct KeySet {
     for (auto cm : comms) if (cm) (void)rccl().CommDestroy(cm);
     for (auto& sh : shards) {
       if (hipSetDevice(sh.device) != hipSuccess) continue;
-      for (void* q : {sh.d_wire, sh.d_mont, sh.d_rec, sh.d_all, sh.d_prep, sh.d_kinf}) if (q) (void)hipFree(q);
+      for (void* q : {sh.d_wire, sh.d_mont, sh.d_sumr, sh.d_rec, sh.d_all, sh.d_prep, sh.d_kinf}) if (q) (void)hipFree(q);
     }
   }
 };
@@ -1745,6 +1747,7 @@ int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devic
       if ((r = c.enter())) return r;
       HIPCHK(hipMalloc(&sh.d_wire, cnt ? cnt * E::G2B : 16));
       HIPCHK(hipMalloc(&sh.d_mont, cnt ? cnt * kl::g2_parsed_bytes<C>() : 16));
+      HIPCHK(hipMalloc(&sh.d_sumr, cnt ? cnt * kl::g2_sumready_bytes<C>() : 16));
       HIPCHK(hipMalloc(&sh.d_rec, REC));
       HIPCHK(hipMalloc(&sh.d_all, REC * n_devices));
       void* d_flags;
@@ -1753,6 +1756,7 @@ int keys_upload_t(const uint8_t* keys, size_t n, const int* devices, int n_devic
       if (cnt) {
         HIPCHK(hipMemcpyAsync(sh.d_wire, keys + sh.lo * E::G2B, cnt * E::G2B, hipMemcpyHostToDevice, c.stream));
         kl::g2_parse<C>(c.stream, (const uint8_t*)sh.d_wire, cnt, (flags & BGLS_KEYS_CHECK) ? 1 : 0, sh.d_mont, (uint32_t*)d_flags);
+        kl::g2_sumready<C>(c.stream, sh.d_mont, cnt, sh.d_sumr);
         HIPCHK(hipGetLastError());
       }
       uint32_t f = 0;
@@ -1972,7 +1976,8 @@ int verify_multi_h_t(KeySet& ks, const uint8_t* sig, const uint8_t* msg, size_t 
     if ((r = c.get(WS_FLAGS, 16, &d_flags))) return r;
     HIPCHK(hipMemsetAsync(d_flags, 0, 4, c.stream));
     HIPCHK(hipMemsetAsync(sh.d_rec, 0, REC, c.stream));
-    if ((r = E::sum_points_jac(c, c.stream, BGLS_G2, (const uint8_t*)sh.d_mont, sh.hi - sh.lo, sh.d_rec, (uint32_t*)d_flags, true))) return r;
+    const bool ready = sum_mode<C>() == 2;       // the lane-pair kernel reads the sum-ready records, the others the Montgomery points
+    if ((r = E::sum_points_jac(c, c.stream, BGLS_G2, (const uint8_t*)(ready ? sh.d_sumr : sh.d_mont), sh.hi - sh.lo, sh.d_rec, (uint32_t*)d_flags, ready ? 2 : 1))) return r;
     if (s) HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
   });
@@ -2214,6 +2219,42 @@ int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const vo
   }
   g_dev = pd;
   return rc;
+}
+
+// verifyMultiSignature against a one-device key set with signature and message already on the device, on the calling thread's
+// context (several checks in flight on several contexts: the handle's resident arrays are read-only)
+static int verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream, bool submit_only) {
+  auto ks = keyset(handle);
+  if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
+  if (ks->shards.size() != 1) return fail(BGLS_ERR_ARG, "device entry point: the key set must live on one device");
+  if (!d_sig || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
+  const int pd = g_dev;
+  g_dev = ks->shards[0].device;
+  Ctx& c = ctx();
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = [&]() -> int {
+      int r;
+      if ((r = c.enter())) return r;
+      hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+      const KeyShard& sh = ks->shards[0];
+      if (ks->curve == BGLS_CURVE_ALTBN128) {
+        const bool ready = sum_mode<BN254>() == 2;
+        return verify_multi_dev_t<BN254>(c, st, (const uint8_t*)d_sig, (const uint8_t*)(ready ? sh.d_sumr : sh.d_mont), ks->n, (const uint8_t*)d_msg, msg_len, submit_only, ready ? 2 : 1);
+      }
+      const bool ready = sum_mode<BLS381>() == 2;
+      return verify_multi_dev_t<BLS381>(c, st, (const uint8_t*)d_sig, (const uint8_t*)(ready ? sh.d_sumr : sh.d_mont), ks->n, (const uint8_t*)d_msg, msg_len, submit_only, ready ? 2 : 1);
+    }();
+  }
+  g_dev = pd;
+  return rc;
+}
+int bgls_verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) {
+  return verify_multi_keys_dev(handle, d_sig, d_msg, msg_len, stream, false);
+}
+int bgls_verify_multi_keys_submit_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) {
+  return verify_multi_keys_dev(handle, d_sig, d_msg, msg_len, stream, true);
 }
 
 int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len) {

@@ -22,7 +22,7 @@ template <class C> void sumseg_main(hipStream_t st, int group, const uint8_t* pt
 // ---- k_sumx.hip   (G2 key sums on carry-free limbs, rx_jac.hpp)
 template <class C> void sumx_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
 template <class C> void sumxseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
-template <class C> void sumpair_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned partials, void* out, uint32_t* flags);
+template <class C> void sumpair_main(hipStream_t st, int src, const uint8_t* pts, size_t n, unsigned partials, void* out, uint32_t* flags);
 template <class C> void sumpairseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
 template <class C> void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out);
 template <class C> void sum_pair(hipStream_t st, int group, const void* in, size_t n, void* out);
@@ -35,6 +35,8 @@ template <class C> void scale_aff(hipStream_t st, int group, const Aff<F1<C>>* g
 template <class C> void check(hipStream_t st, int group, const uint8_t* pts, size_t n, uint32_t* flags, uint8_t* ok);
 template <class C> void g2_parse(hipStream_t st, const uint8_t* in, size_t n, int check_subgroup, void* out, uint32_t* flags);
 template <class C> size_t g2_parsed_bytes();
+template <class C> void g2_sumready(hipStream_t st, const void* mont, size_t n, void* out);      // k_sumpair.hip: a key set's sum-ready records
+template <class C> size_t g2_sumready_bytes();
 template <class C> void generator(hipStream_t st, int group, uint8_t* out);
 void compress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags);
 void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);

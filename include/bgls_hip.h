@@ -315,6 +315,13 @@ int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_
  * bgls/bgls.go:113-114; the identity iff the verdict is 1): canonical bytes, identical for any number of devices. */
 int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
                                int allow_duplicates, uint8_t* gt_out);
+/* verifyMultiSignature (bgls/bgls.go:89-92) against a ONE-device key set, signature and message already on the device, on the
+ * calling thread's context and the given stream: the key sum reads the set's resident sum-ready records -- the keys are the
+ * reference's already-constructed Points (parsed and validated at upload), so nothing but the n - 1 additions of
+ * AggregatePoints (curves/curve.go:73-121) is left per key.  _submit_ enqueues and returns; the verdict is collected with
+ * bgls_final_verify_collect(curve) on the same context, as for bgls_verify_multi_submit_dev. */
+int bgls_verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream);
+int bgls_verify_multi_keys_submit_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream);
 /* bgls_miller_product_dev against a ONE-device key set (prepared or not) with device-resident fixed-stride messages, on
  * the calling thread's context and the given stream; finish with bgls_final_verify_(submit_)dev. */
 int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,

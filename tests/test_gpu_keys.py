@@ -283,3 +283,43 @@ def test_prepared_key_set_gives_the_same_gt(gpu_lib, curve):
 def _err(lib):
     from bgls_amd import _lib
     return _lib.last_error()
+
+
+def test_key_set_multisig_device_entry_reads_sum_ready_records(gpu_lib, curve):
+    """bgls_verify_multi_keys_dev / _submit_dev: verifyMultiSignature against a resident key set with signature and message in
+    device memory.  The key sum runs over the set's sum-ready records (carry-free limbs written at upload, infinity flag in bit 31):
+    the verdicts equal the oracle's and the wire-byte path's for ragged sizes around the kernel's tiles (32 lane pairs per block,
+    ~4 keys per pair), with points at infinity and a repeated key (the doubling branch) in the set."""
+    import torch
+    lib, cid, fp = gpu_lib, curve["id"], curve["fp"]
+    rnd = random.Random(77 + cid)
+    dev = torch.device("cuda:0")
+    for n in (1, 2, 31, 33, 127, 129, 4097, 20000):
+        sks = [rnd.randrange(1, ORDER[cid]) for _ in range(n)]
+        if n > 40:
+            sks[n - 2] = sks[1]                       # the same signer twice
+        keys = out(n * 4 * fp)
+        assert lib.bgls_scale_generator(cid, 2, B(b"".join(s.to_bytes(32, "big") for s in sks)), n, keys) == 0
+        keys = bytearray(bytes(keys))
+        total = sum(sks)
+        if n > 100:                                   # a key at infinity contributes nothing (curves/altbn128.go:181-188 Add with the identity)
+            keys[4 * fp * 17:4 * fp * 18] = bytes(4 * fp)
+            total -= sks[17]
+        msg = rnd.randbytes(40)
+        sig = coracle.scale_point(cid, 1, coracle.hash_to_g1(cid, msg), total % ORDER[cid])
+        if n <= 4097:
+            assert coracle.verify_multi(cid, sig, bytes(keys), n, msg) == 1
+        assert lib.bgls_verify_multi(cid, B(sig), B(bytes(keys)), n, B(msg), len(msg)) == 1, n
+        h = ctypes.c_uint64()
+        assert lib.bgls_keys_upload(cid, B(bytes(keys)), n, None, 1, 0, ctypes.byref(h)) == 0
+        t_sig = torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(dev)
+        t_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
+        t_bad = torch.frombuffer(bytearray(msg[:-1] + bytes([msg[-1] ^ 1])), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        assert lib.bgls_verify_multi_keys_dev(h, t_sig.data_ptr(), t_msg.data_ptr(), len(msg), None) == 1, n
+        assert lib.bgls_verify_multi_keys_dev(h, t_sig.data_ptr(), t_bad.data_ptr(), len(msg), None) == 0, n
+        assert lib.bgls_verify_multi_keys_submit_dev(h, t_sig.data_ptr(), t_msg.data_ptr(), len(msg), None) == 0
+        assert lib.bgls_final_verify_collect(cid) == 1
+        assert lib.bgls_verify_multi_h(h, B(sig), B(msg), len(msg)) == 1
+        assert lib.bgls_keys_free(h) == 0
+        assert lib.bgls_verify_multi_keys_dev(h, t_sig.data_ptr(), t_msg.data_ptr(), len(msg), None) < 0
