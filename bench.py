@@ -575,7 +575,7 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
         check(lib.bgls_verify_multi_submit_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_msg.data_ptr(), len(msg), lanes.lanes[k]["stream"].cuda_stream),
               "verify_multi_submit_dev")
 
-    lib.bgls_profile_enable(1)
+    # (1) latency of one check with the machine to itself (the engine hashes on a side stream beside the key sum)
     seq = []
     for _ in range(max(1, warmup)):
         torch.cuda.synchronize()
@@ -583,7 +583,14 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
         one()
         torch.cuda.synchronize()
         seq.append((time.perf_counter() - t0) * 1e3)
+    # (2) every stage by itself: the same checks one at a time on ONE stream (throughput mode: no side-stream fork), stage timers on
+    check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
+    lib.bgls_profile_enable(1)
+    for _ in range(max(1, warmup)):
+        one()
+        torch.cuda.synchronize()
     stages_excl = {s_: stage(lib, s_) for s_ in ("sum_points", "sum_main", "h2c", "miller", "reduce", "final_exp")}
+    # (3) several checks in flight (still throughput mode: one stream per check)
     lanes.run(L, submit, L > 1)
     regions = []
     for _ in range(reps):
@@ -594,6 +601,7 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
         torch.cuda.synchronize()
         regions.append(time.perf_counter() - t0)
     lib.bgls_profile_enable(0)
+    check(lib.bgls_set_throughput_mode(0), "set_throughput_mode")
     if handle is not None:
         check(lib.bgls_keys_free(handle), "keys_free")
     peak = pinned_peak(lib)
