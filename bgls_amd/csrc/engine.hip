@@ -1535,17 +1535,19 @@ int aggregate_signatures_hae_t(const uint8_t* sigs, const uint8_t* keys, size_t 
   return flags_to_rc(f);
 }
 
-// Marshal / Unmarshal* compressed branch over a batch (alt-bn128 only: BLS12-381's compressed layout belongs to the
-// un-vendored dis2/bls12 and is unpinned, curves/bls12_381.go:55,60,116,121)
+// Marshal / Unmarshal* compressed branch over a batch.  alt-bn128: the reference's own 32 / 64-byte forms
+// (curves/altbn128.go:81-89,203-221,296-376).  BLS12-381: 48 / 96 bytes in the ebfull/pairing layout the reference names as
+// its target (curves/bls12_381.go:54-62,115-123,242-264; wire.hpp) -- unpinned against the un-vendored dis2/bls12.
 int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
-  if (curve != BGLS_CURVE_ALTBN128) return fail(BGLS_ERR_ARG, "compressed point formats are defined for alt-bn128 only");
+  if (curve != BGLS_CURVE_ALTBN128 && curve != BGLS_CURVE_BLS12_381) return fail(BGLS_ERR_ARG, "unknown curve id");
+  const bool bls = curve == BGLS_CURVE_BLS12_381;
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   int rc;
   if ((rc = c.enter())) return rc;
   hipStream_t st = c.stream;
   if (n == 0) return 0;
-  const size_t CB = group == BGLS_G1 ? 32 : 64, UB = 2 * CB;
+  const size_t CB = (bls ? 48 : 32) * (group == BGLS_G1 ? 1 : 2), UB = 2 * CB;
   const size_t in_b = compress ? UB : CB, out_b = compress ? CB : UB;
   void *d_in, *d_out, *d_ok, *d_flags;
   if ((rc = c.get(WS_IN_B, n * in_b, &d_in))) return rc;
@@ -1557,9 +1559,11 @@ int wire_points(int curve, int group, bool compress, const uint8_t* in, size_t n
   {
     Scope sc(c, st, ST_SUM);
     if (compress) {
-      kl::compress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+      if (bls) kl::compress_bls(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
+      else kl::compress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint32_t*)d_flags);
     } else {
-      kl::decompress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
+      if (bls) kl::decompress_bls(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
+      else kl::decompress_bn(st, group, (const uint8_t*)d_in, n, (uint8_t*)d_out, (uint8_t*)d_ok);
     }
   }
   HIPCHK(hipGetLastError());

@@ -40,6 +40,9 @@ template <class C> size_t g2_sumready_bytes();
 template <class C> void generator(hipStream_t st, int group, uint8_t* out);
 void compress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags);
 void decompress_bn(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);
+// ---- k_wire.hip   (BLS12-381 compressed forms, ebfull/pairing layout)
+void compress_bls(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint32_t* flags);
+void decompress_bls(hipStream_t st, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);
 void mad_probe(hipStream_t st, unsigned blocks, unsigned threads, uint32_t seed, int iters, uint64_t* sink);
 template <class C> size_t jac_bytes(int group) { return (size_t)3 * (group == 1 ? 1 : 2) * C::L * 4; }
 

@@ -1,4 +1,5 @@
-// Compressed wire formats of alt-bn128 points.  Unlike every other format at the seam these are defined by the
+// Compressed wire formats.  alt-bn128 first, BLS12-381 (ebfull/pairing layout) in the second half of this file.
+// alt-bn128: unlike every other format at the seam these are defined by the
 // reference's own code (not by an upstream library), so the decoders follow it statement by statement:
 //   Marshal      G1 curves/altbn128.go:81-89    x, top bit of byte 0 <- (2y > q)
 //                G2 curves/altbn128.go:203-221  x_im || x_re, top bits <- (2 y_im > q), (2 y_re > q)
@@ -134,6 +135,119 @@ BGLS_FN bool g2_decompress(Aff<F2<C>>& out, const uint8_t* b) {
   if (!fp_apply_sign<C>(out.y.c1, yisgn)) return false;    // the two components follow their own bits (altbn128.go:360-371)
   if (!fp_apply_sign<C>(out.y.c0, yrsgn)) return false;
   return f2_eq<C>(f2_sqr<C>(out.y), y2);                   // MakeG2Point -> upstream curve check
+}
+
+
+// ================================================================================================================
+// BLS12-381.  Marshal / UnmarshalG1 / UnmarshalG2 of the reference pass the bytes to the un-vendored dis2/bls12
+// (curves/bls12_381.go:54-62,115-123,242-264) and name the layout they are meant to have: "TODO Make this match
+// ebfull/pairing marshalling".  That layout (the ZCash serialisation; Appendix C of draft-irtf-cfrg-pairing-friendly-curves)
+// is what is implemented -- PARITY UNPINNED against dis2/bls12 itself, pinned by the format's public known-answer values
+// (the generators' encodings) and the oracle (oracle/pyref/wire.py bls_*):
+//   G1  48 bytes  x big-endian;  byte 0: bit 7 = compressed, bit 6 = infinity (every other bit zero), bit 5 = y is the
+//                 lexicographically larger of {y, -y}, i.e. y > (p - 1) / 2
+//   G2  96 bytes  x.c1 || x.c0 with the same flags in byte 0; "larger" compares (c1, c0) lexicographically
+// Decoding: flags, x < p, y = sqrt(x^3 + b) chosen by the sort flag; the kernel then applies Check() = subgroup membership.
+// ================================================================================================================
+constexpr uint8_t ZC_COMPRESSED = 0x80, ZC_INFINITY = 0x40, ZC_LARGER = 0x20;
+
+template <class C>
+BGLS_HD bool f2_plain_larger(const Fp2<C>& y_mont) {
+  const Fp<C> c1 = fp_from_mont<C>(y_mont.c1);
+  if (!fp_is_zero<C>(c1)) return fp_plain_gt_half<C>(c1);
+  return fp_plain_gt_half<C>(fp_from_mont<C>(y_mont.c0));
+}
+
+// a square root in Fp2 = Fp[i] / (i^2 + 1), p = 3 mod 4, by the complex method; false when a is not a square.  Which of the
+// two roots comes out is unspecified (the sort flag selects).
+template <class C>
+BGLS_FN bool f2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
+  if (fp_is_zero<C>(a.c1)) {                               // a in Fp: a root in Fp, or i times a root of -a
+    if (fp_jacobi<C>(a.c0) >= 0) r = Fp2<C>{fp_sqrt_candidate<C>(a.c0), fp_zero<C>()};
+    else r = Fp2<C>{fp_zero<C>(), fp_sqrt_candidate<C>(fp_neg<C>(a.c0))};
+    return true;
+  }
+  const Fp<C> norm = fp_add<C>(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1));
+  const Fp<C> lam = fp_sqrt_candidate<C>(norm);
+  if (!fp_eq<C>(fp_sqr<C>(lam), norm)) return false;       // the norm of a square is a square in Fp
+  const Fp<C> half = fp_load<C>(C::HALF);
+  Fp<C> delta = fp_mul<C>(fp_add<C>(a.c0, lam), half);
+  if (fp_jacobi<C>(delta) < 0) delta = fp_mul<C>(fp_sub<C>(a.c0, lam), half);
+  r.c0 = fp_sqrt_candidate<C>(delta);
+  if (fp_is_zero<C>(r.c0)) return false;                   // delta = 0 needs a.c1 = 0
+  r.c1 = fp_mul<C>(fp_mul<C>(fp_inv<C>(r.c0), half), a.c1);
+  return f2_eq<C>(f2_sqr<C>(r), a);
+}
+
+template <class C>
+BGLS_FN void g1_compress_zc(uint8_t* out, const Aff<F1<C>>& p) {
+  if (p.inf) {
+    for (int i = 0; i < C::FP_BYTES; ++i) out[i] = 0;
+    out[0] = ZC_COMPRESSED | ZC_INFINITY;
+    return;
+  }
+  fp_to_be<C>(out, fp_from_mont<C>(p.x));
+  out[0] |= ZC_COMPRESSED | (fp_plain_gt_half<C>(fp_from_mont<C>(p.y)) ? ZC_LARGER : 0);
+}
+template <class C>
+BGLS_FN void g2_compress_zc(uint8_t* out, const Aff<F2<C>>& p) {
+  if (p.inf) {
+    for (int i = 0; i < 2 * C::FP_BYTES; ++i) out[i] = 0;
+    out[0] = ZC_COMPRESSED | ZC_INFINITY;
+    return;
+  }
+  fp_to_be<C>(out, fp_from_mont<C>(p.x.c1));
+  fp_to_be<C>(out + C::FP_BYTES, fp_from_mont<C>(p.x.c0));
+  out[0] |= ZC_COMPRESSED | (f2_plain_larger<C>(p.y) ? ZC_LARGER : 0);
+}
+
+// the first coordinate word of a compressed point with the three flag bits taken off
+template <class C>
+BGLS_HD Fp<C> fp_from_be_zc(const uint8_t* b, uint8_t& flags) {
+  uint8_t tmp[C::FP_BYTES];
+  for (int i = 0; i < C::FP_BYTES; ++i) tmp[i] = b[i];
+  flags = tmp[0] & 0xE0;
+  tmp[0] &= 0x1F;
+  return fp_from_be<C>(tmp);
+}
+
+// UnmarshalG1 on 48 bytes, before Check().  Returns false for "nil, false".
+template <class C>
+BGLS_FN bool g1_decompress_zc(Aff<F1<C>>& out, const uint8_t* b) {
+  uint8_t fl;
+  const Fp<C> xp = fp_from_be_zc<C>(b, fl);
+  if (!(fl & ZC_COMPRESSED)) return false;
+  out.x = fp_zero<C>();
+  out.y = fp_zero<C>();
+  out.inf = true;
+  if (fl & ZC_INFINITY) return !(fl & ZC_LARGER) && fp_is_zero<C>(xp);
+  if (fp_geq_p<C>(xp)) return false;
+  out.inf = false;
+  out.x = fp_to_mont<C>(xp);
+  const Fp<C> y2 = fp_add<C>(fp_mul<C>(fp_sqr<C>(out.x), out.x), fp_load<C>(C::B));
+  out.y = fp_sqrt_candidate<C>(y2);
+  if (!fp_eq<C>(fp_sqr<C>(out.y), y2)) return false;
+  if (fp_plain_gt_half<C>(fp_from_mont<C>(out.y)) != ((fl & ZC_LARGER) != 0)) out.y = fp_neg<C>(out.y);
+  return true;
+}
+// UnmarshalG2 on 96 bytes, before Check()
+template <class C>
+BGLS_FN bool g2_decompress_zc(Aff<F2<C>>& out, const uint8_t* b) {
+  uint8_t fl;
+  const Fp<C> xi = fp_from_be_zc<C>(b, fl);
+  const Fp<C> xr = fp_from_be<C>(b + C::FP_BYTES);
+  if (!(fl & ZC_COMPRESSED)) return false;
+  out.x = f2_zero<C>();
+  out.y = f2_zero<C>();
+  out.inf = true;
+  if (fl & ZC_INFINITY) return !(fl & ZC_LARGER) && fp_is_zero<C>(xi) && fp_is_zero<C>(xr);
+  if (fp_geq_p<C>(xi) || fp_geq_p<C>(xr)) return false;
+  out.inf = false;
+  out.x = Fp2<C>{fp_to_mont<C>(xr), fp_to_mont<C>(xi)};
+  const Fp2<C> y2 = f2_add<C>(f2_mul<C>(f2_sqr<C>(out.x), out.x), F2<C>::curve_b());
+  if (!f2_sqrt<C>(out.y, y2)) return false;
+  if (f2_plain_larger<C>(out.y) != ((fl & ZC_LARGER) != 0)) out.y = f2_neg<C>(out.y);
+  return true;
 }
 
 }  // namespace bgls

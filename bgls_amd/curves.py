@@ -48,10 +48,9 @@ class Point:
         return self.raw
 
     def Marshal(self):
-        """Point.Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221); BLS12-381's compressed
-        layout is upstream-defined and unpinned, so the uncompressed bytes are returned there."""
-        if self.curve.id != 0:
-            return self.raw
+        """Point.Marshal: the compressed form -- alt-bn128's own 32 / 64-byte format (curves/altbn128.go:81-89,203-221);
+        BLS12-381: 48 / 96 bytes in the ebfull/pairing layout the reference names as its target (curves/bls12_381.go:54-62,
+        115-123; unpinned against the un-vendored dis2/bls12, see include/bgls_hip.h)."""
         o = _lib.out(len(self.raw) // 2)
         rc = _lib.load().bgls_compress_points(self.curve.id, self.group, _lib.buf(self.raw), 1, o)
         if rc != 0:
@@ -152,9 +151,9 @@ class CurveSystem:
         return self._make(G2, coords, check)
 
     def _unmarshal(self, group, data):
-        if data is not None and self.id == 0 and len(data) * 2 == self._pt_size(group):
-            # compressed branch of UnmarshalG1 / UnmarshalG2 (curves/altbn128.go:296-376); the caller's bytes are NOT
-            # mutated (the reference clears the sign bit in place, :306-309,344-349)
+        if data is not None and len(data) * 2 == self._pt_size(group):
+            # compressed branch of UnmarshalG1 / UnmarshalG2 (curves/altbn128.go:296-376; curves/bls12_381.go:242-264 on 48 / 96
+            # bytes); the caller's bytes are NOT mutated (the reference clears the sign bit in place, altbn128.go:306-309,344-349)
             o, ok = _lib.out(self._pt_size(group)), _lib.out(1)
             rc = _lib.load().bgls_decompress_points(self.id, group, _lib.buf(data), 1, o, ok)
             if rc != 0 or ok[0] != 1:

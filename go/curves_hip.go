@@ -76,14 +76,10 @@ func (pt *hipPoint) Equals(o Point) bool {
 }
 func (pt *hipPoint) MarshalUncompressed() []byte { return append([]byte(nil), pt.raw...) }
 
-// Marshal: the compressed form on alt-bn128 (curves/altbn128.go:81-89,203-221).  BLS12-381's compressed layout belongs to
-// the un-vendored dis2/bls12 and carries TODOs in the reference (curves/bls12_381.go:55,60,116,121): it is NOT restated,
-// Marshal returns the UNCOMPRESSED bytes there and Unmarshal accepts only those -- a documented deviation, byte parity of
-// bls12 Marshal() with upstream is unpinned.
+// Marshal: the compressed form.  alt-bn128: the reference's own 32 / 64-byte format (curves/altbn128.go:81-89,203-221).
+// BLS12-381: 48 / 96 bytes in the ebfull/pairing layout the reference names as its target (curves/bls12_381.go:54-62,115-123
+// "TODO Make this match ebfull/pairing marshalling"); byte parity with the un-vendored dis2/bls12 is unpinned (bgls_hip.h).
 func (pt *hipPoint) Marshal() []byte {
-	if pt.c.id != C.BGLS_CURVE_ALTBN128 {
-		return pt.MarshalUncompressed()
-	}
 	out := make([]byte, len(pt.raw)/2)
 	if C.bgls_compress_points(pt.c.id, pt.group, p(pt.raw), 1, p(out)) != 0 {
 		return nil
@@ -156,7 +152,7 @@ func (t hipPointT) Mul(k *big.Int) PointT {
 func (c *hipCurve) Name() string { return c.name }
 
 func (c *hipCurve) unmarshal(group C.int, data []byte) (Point, bool) {
-	if c.id == C.BGLS_CURVE_ALTBN128 && 2*len(data) == c.size(group) { // compressed branch, curves/altbn128.go:296-376
+	if 2*len(data) == c.size(group) { // compressed branch, curves/altbn128.go:296-376, curves/bls12_381.go:242-264
 		out := make([]byte, c.size(group))
 		ok := []byte{0}
 		if C.bgls_decompress_points(c.id, group, p(data), 1, p(out), p(ok)) != 0 || ok[0] != 1 {

@@ -28,6 +28,9 @@ struct Point {
   Point Copy() const { return *this; }
   bool Equals(const Point& o) const { return curve == o.curve && group == o.group && raw == o.raw; }
   Bytes MarshalUncompressed() const { return raw; }
+  // Point.Marshal: the compressed form (curves/altbn128.go:81-89,203-221; curves/bls12_381.go:54-62,115-123 -- BLS12-381 in the
+  // ebfull/pairing layout, see bgls_compress_points); empty on failure
+  Bytes Marshal() const;
   // scalar: 32-byte big-endian magnitude; negative => negate-then-multiply (curves/altbn128.go:107-121)
   Point Mul(const Bytes& magnitude_be32, bool negative = false) const;
   Point MulInt(long long k) const;
@@ -54,6 +57,12 @@ struct CurveSystem {
   size_t size(int group) const { return group == BGLS_G1 ? bgls_g1_size(id) : bgls_g2_size(id); }
 
   std::pair<Point, bool> Unmarshal(int group, const Bytes& d) const {
+    if (2 * d.size() == size(group)) {      // compressed branch (curves/altbn128.go:296-376, curves/bls12_381.go:242-264)
+      Bytes out(size(group));
+      uint8_t ok = 0;
+      if (bgls_decompress_points(id, group, d.data(), 1, out.data(), &ok) != 0 || ok != 1) return {Point{}, false};
+      return {Point{this, group, out}, true};
+    }
     if (d.size() != size(group) || bgls_point_check(id, group, d.data()) != 1) return {Point{}, false};
     return {Point{this, group, d}, true};
   }
@@ -119,6 +128,12 @@ inline PointT PointT::Mul(const Bytes& mag, bool negative) const {
   Bytes o(raw.size());
   if (bgls_gt_pow(curve->id, raw.data(), mag.data(), negative ? 1 : 0, o.data()) != 0) return PointT{};
   return PointT{curve, o};
+}
+inline Bytes Point::Marshal() const {
+  if (!valid()) return Bytes();
+  Bytes out(raw.size() / 2);
+  if (bgls_compress_points(curve->id, group, raw.data(), 1, out.data()) != 0) return Bytes();
+  return out;
 }
 inline Point Point::Mul(const Bytes& mag, bool negative) const {
   uint8_t sign = negative ? 1 : 0;

@@ -166,18 +166,23 @@ int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, cons
                     uint8_t* sigs_out);
 
 /* ---- compressed wire formats ------------------------------------------------------------- */
-/* Point.Marshal of alt-bn128 (curves/altbn128.go:81-89 G1, :203-221 G2): out = n compressed points -- G1: x (32-byte
- * big-endian) with the top bit of byte 0 set iff 2y > q; G2: x_im || x_re with the top bits set iff 2 y_im > q / 2 y_re > q;
- * infinity = zeros.  Inputs are validated like every other point (BGLS_ERR_ENCODING).
- * alt-bn128 ONLY, by decision: BLS12-381 compressed encodings are NOT part of this ABI (both calls return BGLS_ERR_ARG for
- * curve 1).  The reference's layout there is whatever the un-vendored, unpinned github.com/dis2/bls12 emits, and the
- * reference itself carries TODOs that it does not match the ebfull/pairing (ZCash) layout (curves/bls12_381.go:55,60,116,121):
- * there is no vector to pin an implementation against, so Marshal() on BLS12-381 returns the uncompressed bytes in the host
- * mirrors (stated in the Go shim) rather than bytes that might silently disagree with upstream. */
+/* Point.Marshal over a batch: out = n compressed points.  Inputs are validated like every other point (BGLS_ERR_ENCODING).
+ *   alt-bn128 (curves/altbn128.go:81-89 G1, :203-221 G2; the reference's OWN format): G1 = x (32-byte big-endian) with the top
+ *     bit of byte 0 set iff 2y > q; G2 = x_im || x_re with the top bits set iff 2 y_im > q / 2 y_re > q; infinity = zeros.
+ *   BLS12-381 (curves/bls12_381.go:54-62 G1, :115-123 G2): 48 / 96 bytes in the ebfull/pairing ("ZCash") layout, the layout the
+ *     reference names as its target ("TODO Make this match ebfull/pairing marshalling"): G1 = x big-endian, G2 = x.c1 || x.c0;
+ *     byte 0 bit 7 = compressed, bit 6 = infinity (every other bit zero), bit 5 = y is the lexicographically larger of
+ *     {y, -y} (G2: compare c1, then c0).  PARITY UNPINNED against the un-vendored github.com/dis2/bls12 the reference links
+ *     (no vector exists in the reference); pinned by the format's public known-answer values (the generators' encodings,
+ *     tests/test_wire.py) and by round trips. */
 int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out);
-/* UnmarshalG1 / UnmarshalG2, compressed branches (curves/altbn128.go:296-327, :329-376): square roots by calcQuadRes /
- * calcComplexQuadRes (curves/hash.go:178-223), the component-wise sign rule, then the MakeG*Point validation.
- * out = n uncompressed points (zeros where rejected), ok[i] = 1 / 0 = the reference's (Point, bool). */
+/* UnmarshalG1 / UnmarshalG2, compressed branches.  out = n uncompressed points (zeros where rejected), ok[i] = 1 / 0 = the
+ * reference's (Point, bool).
+ *   alt-bn128 (curves/altbn128.go:296-327, :329-376): square roots by calcQuadRes / calcComplexQuadRes (curves/hash.go:178-223),
+ *     the component-wise sign rule, then the MakeG*Point validation (G2: subgroup membership included).
+ *   BLS12-381 (curves/bls12_381.go:242-264, inputs of 48 / 96 bytes): the flag rules above (a clear compression flag, an
+ *     infinity flag with any other bit set, x >= p are refused), y = sqrt(x^3 + b) selected by the sort flag, then Check():
+ *     membership in the order-r subgroup, G1 and G2 alike. */
 int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok);
 
 /* ---- per-point operations backing the Go Point / PointT methods --------------------------- */

@@ -14,10 +14,19 @@ statement by statement, quirks included:
                      decompress_g2(..., subgroup=False) stops before that last test (what wire.hpp's g2_decompress
                      computes; the kernel applies g2_in_subgroup to its result).
 
-BLS12-381's compressed encodings come from the un-vendored dis2/bls12 and carry TODOs in the reference
-(curves/bls12_381.go:55,60,116,121): unpinned, not restated.
+BLS12-381 (second half of this file): Marshal / UnmarshalG1 / UnmarshalG2 of the reference hand the bytes to the un-vendored
+dis2/bls12 (curves/bls12_381.go:54-62,115-123,242-264) and say what layout they are meant to have -- "TODO Make this match
+ebfull/pairing marshalling" (:54,59,115,120).  ebfull/pairing's layout (the "ZCash" serialisation, also Appendix C of
+draft-irtf-cfrg-pairing-friendly-curves) is a published format, so THAT is what is restated here:
+  compressed G1  48 bytes: x big-endian; byte 0 bit 7 = 1 (compressed), bit 6 = infinity (all other bits zero), bit 5 = y is the
+                 lexicographically larger of {y, -y} (y > (p - 1) / 2)
+  compressed G2  96 bytes: x.c1 || x.c0 with the same three flag bits in byte 0; "larger" compares (c1, c0) lexicographically
+  decoding       flag checks, x < p, y = sqrt(x^3 + b) selected by the sort flag, then Check() = subgroup membership
+                 (curves/bls12_381.go:248,259).
+PARITY UNPINNED against dis2/bls12 itself (absent, no vector in the reference); pinned instead by the format's public
+known-answer values: the generators' encodings (tests/test_wire.py).
 """
-from .params import BN254
+from .params import BN254, BLS381
 
 Q = BN254.p
 _B2 = None
@@ -150,3 +159,125 @@ def decompress_g2(data, subgroup=True):
         if not Subgroup(BN254).in_subgroup(((xr, xi), (yr, yi))):
             return None, False
     return ((xr, xi), (yr, yi)), True
+
+
+# ================================================================================================================
+# BLS12-381: ebfull/pairing ("ZCash") layout -- see the header.  Points are Groups(BLS381) tuples, None = infinity.
+# ================================================================================================================
+P381 = BLS381.p
+_HALF381 = (P381 - 1) // 2
+
+
+def _sqrt381(a):
+    """square root in Fp (p = 3 mod 4) or None"""
+    a %= P381
+    r = pow(a, (P381 + 1) // 4, P381)
+    return r if r * r % P381 == a else None
+
+
+def _f2_sqrt381(a):
+    """square root in Fp2 = Fp[i] / (i^2 + 1) by the complex method, or None; which of the two roots is irrelevant (the
+    sort flag selects)."""
+    re, im = a[0] % P381, a[1] % P381
+    if im == 0:
+        r = _sqrt381(re)
+        if r is not None:
+            return (r, 0)
+        r = _sqrt381(-re)                                   # re a non-residue: the root is purely imaginary
+        return None if r is None else (0, r)
+    lam = _sqrt381(re * re + im * im)                       # the norm must be a square in Fp
+    if lam is None:
+        return None
+    inv2 = pow(2, -1, P381)
+    x0 = _sqrt381((re + lam) * inv2)
+    if x0 is None:
+        x0 = _sqrt381((re - lam) * inv2)
+    if x0 is None or x0 == 0:
+        return None
+    x1 = im * pow(2 * x0, -1, P381) % P381
+    ok = ((x0 * x0 - x1 * x1) % P381, 2 * x0 * x1 % P381) == (re, im)
+    return (x0, x1) if ok else None
+
+
+def _larger_fp(y):
+    return y > _HALF381
+
+
+def _larger_fp2(y):                                         # (re, im): compare c1 = im first, then c0
+    return _larger_fp(y[1]) if y[1] != 0 else _larger_fp(y[0])
+
+
+def bls_compress_g1(P):
+    if P is None:
+        return bytes([0xC0]) + bytes(47)
+    b = bytearray(P[0].to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if _larger_fp(P[1]) else 0)
+    return bytes(b)
+
+
+def bls_compress_g2(Q):
+    if Q is None:
+        return bytes([0xC0]) + bytes(95)
+    (xr, xi), y = Q
+    b = bytearray(xi.to_bytes(48, "big") + xr.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if _larger_fp2(y) else 0)
+    return bytes(b)
+
+
+def _bls_flags(data):
+    d = bytearray(data)
+    c, inf, srt = d[0] >> 7, (d[0] >> 6) & 1, (d[0] >> 5) & 1
+    d[0] &= 0x1F
+    return c, inf, srt, d
+
+
+def bls_decompress_g1(data, subgroup=True):
+    """-> (point or None for infinity, ok): UnmarshalG1 on 48 bytes (curves/bls12_381.go:242-251)."""
+    assert len(data) == 48
+    c, inf, srt, d = _bls_flags(data)
+    if not c:
+        return None, False                                  # 48 bytes that do not claim to be compressed
+    if inf:
+        return None, (srt == 0 and not any(d))              # infinity: every other bit must be zero
+    x = int.from_bytes(d, "big")
+    if x >= P381:
+        return None, False
+    y = _sqrt381(x * x * x + BLS381.b)
+    if y is None:
+        return None, False
+    if _larger_fp(y) != bool(srt):
+        y = P381 - y
+    P = (x, y)
+    if subgroup:
+        from .groups import Groups
+        if Groups(BLS381).g1_mul(P, BLS381.r) is not None:  # Check(): [r]P = infinity
+            return None, False
+    return P, True
+
+
+def bls_decompress_g2(data, subgroup=True):
+    """UnmarshalG2 on 96 bytes (curves/bls12_381.go:253-262)."""
+    assert len(data) == 96
+    c, inf, srt, d = _bls_flags(data)
+    if not c:
+        return None, False
+    if inf:
+        return None, (srt == 0 and not any(d))
+    xi, xr = int.from_bytes(d[:48], "big"), int.from_bytes(d[48:], "big")
+    if xi >= P381 or xr >= P381:
+        return None, False
+    from .groups import Groups
+    G = Groups(BLS381)
+    T = G.T
+    x = (xr, xi)
+    y = _f2_sqrt381(T.f2_add(T.f2_mul(T.f2_sqr(x), x), G.b2))
+    if y is None:
+        return None, False
+    if _larger_fp2(y) != bool(srt):
+        y = T.f2_neg(y)
+    Q = (x, y)
+    if subgroup:
+        from .subgroup import Subgroup
+        if not Subgroup(BLS381).in_subgroup(Q):
+            return None, False
+    return Q, True

@@ -130,9 +130,26 @@ static void TestKeySetAndGtMul(const CurveSystem* curve) {
   CHECK(e.first.Mul(k, true).Add(ek.first).first.Equals(curve->GetGTIdentity()), "e(g1, g2)^-k * e(k g1, g2) != 1");
 }
 
+// curves/curve_test.go:73-84 TestMarshal: Unmarshal(Marshal(P)) == P and Unmarshal(MarshalUncompressed(P)) == P, G1 and G2,
+// both curves (alt-bn128: the reference's own compressed format; BLS12-381: 48 / 96 bytes, ebfull/pairing layout)
+static void TestMarshal(const CurveSystem* curve) {
+  for (int j = 0; j < 4; ++j) {
+    Bytes k = randScalar();
+    Point p1 = curve->GetG1().Mul(k), p2 = curve->GetG2().Mul(k);
+    Bytes m1 = p1.Marshal(), m2 = p2.Marshal();
+    CHECK(2 * m1.size() == p1.raw.size() && 2 * m2.size() == p2.raw.size(), "Marshal: wrong length");
+    auto u1 = curve->UnmarshalG1(m1), u2 = curve->UnmarshalG2(m2);
+    CHECK(u1.second && u1.first.Equals(p1), "UnmarshalG1(Marshal(P)) != P");
+    CHECK(u2.second && u2.first.Equals(p2), "UnmarshalG2(Marshal(P)) != P");
+    auto w1 = curve->UnmarshalG1(p1.MarshalUncompressed()), w2 = curve->UnmarshalG2(p2.MarshalUncompressed());
+    CHECK(w1.second && w1.first.Equals(p1) && w2.second && w2.first.Equals(p2), "Unmarshal(MarshalUncompressed(P)) != P");
+  }
+  CHECK(!curve->UnmarshalG1(Bytes(7, 1)).second, "UnmarshalG1 accepted 7 bytes");
+}
+
 int main() {
   if (bgls_init(0) != 0) { std::printf("bgls_init: %s\n", bgls_last_error()); return 2; }
-  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); TestHAE(curve); TestKeySetAndGtMul(curve); }
+  for (const CurveSystem* curve : {Altbn128(), Bls12()}) { TestSingleSigner(curve); TestAggregation(curve); TestKoskMultiSig(curve); TestHAE(curve); TestKeySetAndGtMul(curve); TestMarshal(curve); }
   std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -7,6 +7,7 @@
                      curves/altbn128_test.go:26-38 (G2 generator coordinates).
  hae_<curve>.json    BLAKE2Xb outputs, hashed aggregation exponents and accept/reject cases of the HAE /
                      multiplicity flows (bgls/blsHAE.go, bgls/blsKosk.go:137-150) from the Python oracle.
+ wire_bls12.json     BLS12-381 compressed encodings (ebfull/pairing layout) and UnmarshalG1 / UnmarshalG2 decisions (curves/bls12_381.go:54-62,242-264)
  wire_altbn128.json  compressed point encodings and Unmarshal decisions (curves/altbn128.go:81-89,203-221,296-376)
                      from the Python oracle (oracle/pyref/wire.py).
  vectors_<curve>.json  outputs of the Python oracle (oracle/pyref) on seeded inputs: Miller / GT
@@ -232,9 +233,77 @@ def wire_vectors(seed):
     json.dump(v, open(os.path.join(HERE, "wire_altbn128.json"), "w"), indent=0)
 
 
+def wire_vectors_bls(seed):
+    """wire_bls12.json: BLS12-381 compressed forms in the ebfull/pairing layout the reference names as its target
+    (curves/bls12_381.go:54-62,115-123 "TODO Make this match ebfull/pairing marshalling") and the UnmarshalG1 / UnmarshalG2
+    decisions on 48 / 96 bytes (:242-264), from oracle/pyref/wire.py: valid points with both sort flags, infinity, flag
+    violations, non-canonical x, random x (about half have no point), points on the curve / twist outside the order-r
+    subgroup (tests/golden/subgroup_bls12.json).  The generators' encodings are the format's public known-answer values."""
+    from oracle.pyref import wire
+    c = BLS381
+    rnd = random.Random(seed)
+    G = Pairing(c).G
+    v = {"layout": "ebfull/pairing (ZCash): bit 7 compressed, bit 6 infinity, bit 5 y lexicographically larger; G2 = x.c1 || x.c0",
+         "g1": [], "g2": [], "g1_decode": [], "g2_decode": []}
+    v["g1"].append({"pt": G.g1_bytes(c.g1).hex(), "compressed": wire.bls_compress_g1(c.g1).hex(), "note": "generator"})
+    v["g2"].append({"pt": G.g2_bytes(c.g2).hex(), "compressed": wire.bls_compress_g2(c.g2).hex(), "note": "generator"})
+    for i in range(7):
+        P = G.g1_mul(c.g1, rnd.randrange(1, c.r)); Q = G.g2_mul(c.g2, rnd.randrange(1, c.r))
+        if i & 1:
+            P, Q = G.g1_neg(P), G.g2_neg(Q)
+        v["g1"].append({"pt": G.g1_bytes(P).hex(), "compressed": wire.bls_compress_g1(P).hex()})
+        v["g2"].append({"pt": G.g2_bytes(Q).hex(), "compressed": wire.bls_compress_g2(Q).hex()})
+    v["g1"].append({"pt": G.g1_bytes(None).hex(), "compressed": wire.bls_compress_g1(None).hex(), "note": "infinity"})
+    v["g2"].append({"pt": G.g2_bytes(None).hex(), "compressed": wire.bls_compress_g2(None).hex(), "note": "infinity"})
+    def dec(group, d, note=None):
+        # ok: Unmarshal's answer (Check() included); decoded / pt: the decoding before the subgroup test
+        f = wire.bls_decompress_g1 if group == 1 else wire.bls_decompress_g2
+        pt, d_ok = f(d, subgroup=False)
+        _, ok = f(d)
+        row = {"in": d.hex(), "ok": ok, "decoded": d_ok, "pt": (G.g1_bytes(pt) if group == 1 else G.g2_bytes(pt)).hex() if d_ok else None}
+        if note:
+            row["note"] = note
+        return row
+    for group, key in ((1, "g1"), (2, "g2")):
+        out = v[key + "_decode"]
+        for row in v[key]:
+            d = bytearray(bytes.fromhex(row["compressed"]))
+            out.append(dec(group, bytes(d)))
+            e = bytearray(d); e[0] ^= 0x20
+            out.append(dec(group, bytes(e), "sort flag flipped"))           # the other root (or: infinity with the sort flag set)
+            e = bytearray(d); e[0] &= 0x7F
+            out.append(dec(group, bytes(e), "compression flag clear"))
+        inf = bytearray(bytes.fromhex(v[key][-1]["compressed"])); inf[-1] = 1
+        out.append(dec(group, bytes(inf), "infinity flag with a non-zero bit"))
+        n = 48 * group
+        for i in range(16 // group):
+            d = bytearray(rnd.randbytes(n))
+            d[0] = 0x80 | rnd.choice((0, 0x20)) | (d[0] & 0x0F)              # x below p (whose top byte is 0x1a)
+            out.append(dec(group, bytes(d), "random x"))
+        big = bytearray((c.p + 5).to_bytes(48, "big")) + (bytearray((3).to_bytes(48, "big")) if group == 2 else bytearray())
+        big[0] |= 0x80
+        out.append(dec(group, bytes(big), "x >= p"))
+    # points on the curve / twist outside the order-r subgroup: decodable, refused by Check()
+    sub = json.load(open(os.path.join(HERE, "subgroup_bls12.json")))
+    for row in sub["g1_points"]:
+        P = G.g1_from_bytes(bytes.fromhex(row["pt"]))
+        if P is not None and not row["in_subgroup"]:
+            v["g1_decode"].append(dec(1, wire.bls_compress_g1(P), "cofactor point: " + row.get("note", "")))
+    for row in sub["points"]:
+        Q = G.g2_from_bytes(bytes.fromhex(row["pt"]))
+        if Q is not None and row["on_twist"] and not row["in_subgroup"]:
+            v["g2_decode"].append(dec(2, wire.bls_compress_g2(Q), "cofactor point: " + row.get("note", "")))
+    for key in ("g1_decode", "g2_decode"):
+        rows = v[key]
+        assert any(r["ok"] for r in rows) and any(r["decoded"] and not r["ok"] for r in rows) and any(not r["decoded"] for r in rows)
+    json.dump(v, open(os.path.join(HERE, "wire_bls12.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     if "--wire-only" in sys.argv:
-        wire_vectors(20261002); print("wire fixtures written"); sys.exit(0)
+        wire_vectors(20261002); wire_vectors_bls(20261003); print("wire fixtures written"); sys.exit(0)
+    if "--wire-bls-only" in sys.argv:
+        wire_vectors_bls(20261003); print("BLS12-381 wire fixture written"); sys.exit(0)
     if "--hae-only" in sys.argv:
         hae(BN254, 20260930); hae(BLS381, 20261001)
         print("hae fixtures written"); sys.exit(0)
@@ -244,4 +313,5 @@ if __name__ == "__main__":
     hae(BN254, 20260930)
     hae(BLS381, 20261001)
     wire_vectors(20261002)
+    wire_vectors_bls(20261003)
     print("golden fixtures written")

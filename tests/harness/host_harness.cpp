@@ -229,6 +229,32 @@ int ht_wire(int op, const uint8_t* in, uint8_t* out) {
     g2_to_bytes<C>(out, p);
     return 1;
   }
+  // BLS12-381, ebfull/pairing layout (wire.hpp second half): 4 / 5 compress G1 / G2, 6 / 7 decode 48 / 96 bytes (before Check())
+  typedef BLS381 B;
+  if (op == 4) {
+    Aff<F1<B>> p;
+    if (!g1_from_bytes<B>(p, in) || !aff_on_curve<F1<B>>(p)) return -1;
+    g1_compress_zc<B>(out, p);
+    return 1;
+  }
+  if (op == 5) {
+    Aff<F2<B>> p;
+    if (!g2_from_bytes<B>(p, in) || !aff_on_curve<F2<B>>(p)) return -1;
+    g2_compress_zc<B>(out, p);
+    return 1;
+  }
+  if (op == 6) {
+    Aff<F1<B>> p;
+    if (!g1_decompress_zc<B>(p, in)) return 0;
+    g1_to_bytes<B>(out, p);
+    return 1;
+  }
+  if (op == 7) {
+    Aff<F2<B>> p;
+    if (!g2_decompress_zc<B>(p, in)) return 0;
+    g2_to_bytes<B>(out, p);
+    return 1;
+  }
   return -1;
 }
 // one BLAKE2Xb expansion node (hashes.hpp blake2xb_node) from a 64-byte root
