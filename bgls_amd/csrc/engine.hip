@@ -33,6 +33,7 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 #include "finalexp.hpp"
 #include "miller_kernels.hpp"
 #include "launch.hpp"
+#include "launch_tail.hpp"
 #include "../../include/bgls_hip.h"
 
 using namespace bgls;
@@ -65,7 +66,7 @@ constexpr size_t MAX_BATCH = (size_t)1 << 30;
 constexpr size_t LAT_MAX = 128;
 
 // workspace slots
-enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_SEG_OFF, WS_SEG_KEYS, WS_EPI, WS_NUM };
+enum { WS_G1S = 0, WS_F_A, WS_F_B, WS_FLAGS, WS_TABLE, WS_IN_A, WS_IN_B, WS_IN_C, WS_IN_D, WS_OUT, WS_JAC_A, WS_JAC_B, WS_PART, WS_TMP, WS_TMP2, WS_H2C_LIST, WS_H2C_CNT, WS_H2C_PTS, WS_H2C_KIND, WS_HAE_ROOT, WS_HAE_T, WS_HAE_KEYS, WS_HAE_APK, WS_HAE_SIGN, WS_FLAGS2, WS_GEN_TMP, WS_LINES, WS_SUMJ, WS_QP, WS_MSM_AFF, WS_MSM_CNT, WS_MSM_START, WS_MSM_LIST, WS_SEG_OFF, WS_SEG_KEYS, WS_EPI, WS_TREE_S, WS_TREE_T, WS_NUM };
 
 struct Ctx {
   std::mutex mu;
@@ -75,6 +76,8 @@ struct Ctx {
   hipStream_t side = nullptr;                // a lone verification's independent stages run beside each other (fork / join with the two events)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
+  void* tick_ptr = nullptr;                  // the key-sum tree's ticket words (zeroed when allocated, left zero by every launch)
+  size_t tick_cap = 0;
   uint32_t* h_res = nullptr;                 // pinned host words {verdict, final-stage flags, caller flags} of the verification in flight
   bool res_pending = false;
   hipStream_t res_stream = nullptr;
@@ -404,6 +407,11 @@ struct Engine {
       return 0;
     }
     int rc;
+    // the epilogue kernels of the throughput shapes always raise a BLS12-381 product to the G1 cofactor: cleared hash points
+    // together with a signature pair would come out as prod^h * e(-sigma, g2) there.  No caller does that (every BLS12-381
+    // verification pairs uncleared points); refuse it rather than return a wrong GT value.
+    if (C::CURVE_ID == 1 && sig && !cofactor && npairs > LAT_MAX)
+      return fail(BGLS_ERR_ARG, "BLS12-381: a signature pair with cleared hash points is only served by the latency shape (<= 128 pairings)");
     const LineCoeffs<C>* gl = nullptr;
     if (sig && (rc = gen_lines(c, &gl))) return rc;
     void *pa, *pb;
@@ -623,8 +631,9 @@ struct Engine {
     int rc;
     if ((rc = c.get(WS_SUMJ, 4 * kl::jac_bytes<C>(group), &jac))) return rc;
     Scope sc(c, st, ST_SUM);                                   // one scope per key sum: the stage count equals the number of sums
-    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, src, false))) return rc;
-    kl::jac_to_bytes<C>(st, group, jac, 1, d_out);
+    bool bytes_done = false;
+    if ((rc = sum_points_jac(c, st, group, d_pts, n, jac, d_flags, src, false, d_out, &bytes_done))) return rc;
+    if (!bytes_done) kl::jac_to_bytes<C>(st, group, jac, 1, d_out);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -677,8 +686,10 @@ struct Engine {
   }
   // the same sum left in Jacobian form at d_jac (multi-device key sums exchange projective partials);
   // n == 0 gives the point at infinity (all-zero record: Z = 0)
+  // d_bytes != nullptr: the caller wants the affine wire bytes as well; where the one-launch tree (k_sumtree.hip) serves the
+  // sum it writes them itself and *bytes_done is set (no separate conversion launch)
   static int sum_points_jac(Ctx& c, hipStream_t st, int group, const uint8_t* d_pts, size_t n, void* d_jac, uint32_t* d_flags,
-                            int src = 0, bool own_scope = true) {
+                            int src = 0, bool own_scope = true, uint8_t* d_bytes = nullptr, bool* bytes_done = nullptr) {
     if (n == 0) {
       HIPCHK(hipMemsetAsync(d_jac, 0, kl::jac_bytes<C>(group), st));
       return 0;
@@ -710,7 +721,24 @@ struct Engine {
     scm.reset();
     void *a = ja, *b = jb;
     size_t cnt = partials;
+    static const bool one_launch_tree = [] { const char* e = getenv("BGLS_SUMTREE"); return !(e && e[0] == '0'); }();
     while (cnt > 1) {
+      if (group == BGLS_G2 && cnt <= 8192 && one_launch_tree) {
+        // the whole tree in ONE launch: a wave per pair of leaves climbs by tickets (k_sumtree.hip); the root's wave writes the
+        // Jacobian record and, if asked, the affine bytes
+        void *store, *tick;
+        if ((rc = c.get(WS_TREE_S, (cnt + 64) * JB, &store))) return rc;
+        if ((rc = c.get(WS_TREE_T, (size_t)(8192 + 64) * 4, &tick))) return rc;
+        if (tick != c.tick_ptr || c.ws[WS_TREE_T].second != c.tick_cap) {
+          HIPCHK(hipMemsetAsync(tick, 0, c.ws[WS_TREE_T].second, st));
+          c.tick_ptr = tick;
+          c.tick_cap = c.ws[WS_TREE_T].second;
+        }
+        kl::sum_tree<C>(st, a, cnt, store, (uint32_t*)tick, d_bytes, d_jac);
+        HIPCHK(hipGetLastError());
+        if (bytes_done) *bytes_done = d_bytes != nullptr;
+        return 0;
+      }
       // halving launches while there is parallelism to speak of, then 64 -> 1 per wave with lane shuffles
       if (group == BGLS_G2 && cnt <= 8192) {
         kl::sum_coop<C>(st, a, cnt, b);                    // few additions left: one wave per addition, ~12 us a level

@@ -15,7 +15,7 @@
 // lane holding a whole G2 point plus three piles (256 registers, 150-650 spilled) -- here half a point and one pile.
 //
 // Work per pairing in units of NL^2 multiplier instructions (NL = 10 / 14): producer 2 x (28 per doubling, 39 per
-// addition step), consumer 66 per line + 108 / 6 per squaring.  Same line coefficients and the same product order as the
+// addition step), consumer 66 per line + 84 / 6 per squaring (round 4: the squaring's cross terms in the Karatsuba form, rx.hpp).  Same line coefficients and the same product order as the
 // other kernels: the partial products are bit-identical to k_miller_ab64's.
 //
 // Replaces the n calls of CurveSystem.Pair behind PairingProduct: curves/curve.go:125-170, curves/altbn128.go:130-145,

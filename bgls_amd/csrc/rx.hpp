@@ -329,7 +329,16 @@ BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
 }
 
 // c = sum over up to four slots of A_t * B_t with doubled slots (the symmetric squaring of coop.hpp: at most six
-// term-equivalents per lane), schoolbook over i: the Karatsuba pile would leave the 64-bit budget on NL = 14.
+// term-equivalents per lane), Karatsuba over i in the two passes of ux_dot_k2p (round 4; schoolbook until then: 16 NL^2
+// multiplier instructions per lane and squaring, now 12):
+//   pass 1:  D = sum k a0 b0,  E = sum k a1 b1          ->  real part = D + BIAS_S6 - E
+//   pass 2:  X = -(D + E) + sum k (a0 + a1)(b0 + b1)    ->  imaginary part, in wrap-around arithmetic
+// The pile sum k (a0 + a1)(b0 + b1) ALONE would leave 64 bits on NL = 14 (six term-equivalents of four limb products: 2^64.4),
+// which is why round 3 kept the schoolbook form -- but it is never formed alone: X starts at -(D + E) mod 2^64 and every
+// intermediate value is taken mod 2^64; the FINAL column totals are those of sum k (a0 b1 + a1 b0), non-negative and inside
+// the budget the schoolbook cross pile already had (tools/gen_constants.py "sqr cross pile": 12 col + red + carry < 2^64 on
+// both curves), so the 64-bit result is exact.  The host build checks exactly that: the true cross pile is accumulated with
+// overflow checks next to the wrap-around one and the two must agree column by column.
 //   kind(t) = 0 (unused slot), 1 (plain) or 2 (doubled);  lda / ldb as above (halves are fetched one pair at a time so that
 //   two piles and two halves are all that is live)
 template <class C, class KD, class LA, class LB>
@@ -366,29 +375,46 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 2 * N; ++k) d[k] = d[k] + C::RX_BIAS_S6[k] - e[k];
+  for (int k = 0; k < 2 * N; ++k) {
+    const u64 dk = d[k], ek = e[k];
+    e[k] = dk + C::RX_BIAS_S6[k] - ek;
+    d[k] = 0 - (dk + ek);
+  }
   Ux2<C> r;
-  r.c0 = ux_redc<C>(d);
-  {
-    const Ux<C> a0 = scaled(0, 0), b1 = ldb(0, 1);
-    ux_acc_new<C>(e, a0, b1);
-  }
-  {
-    const Ux<C> a1 = scaled(0, 1), b0 = ldb(0, 0);
-    ux_acc<C>(e, a1, b0);
-  }
+  r.c0 = ux_redc<C>(e);
+#if RX_HOST_CHECK
+  u64 chk[2 * N];
+  for (int k = 0; k < 2 * N; ++k) chk[k] = 0;
+#endif
 #pragma unroll 1
-  for (int t = 1; t < 4; ++t) {
+  for (int t = 0; t < 4; ++t) {
+    Ux<C> sa, sb;
     {
-      const Ux<C> a0 = scaled(t, 0), b1 = ldb(t, 1);
-      ux_acc<C>(e, a0, b1);
+      const Ux<C> a0 = scaled(t, 0), a1 = scaled(t, 1);
+#pragma unroll
+      for (int q = 0; q < N; ++q) sa.v[q] = a0.v[q] + a1.v[q];
+#if RX_HOST_CHECK
+      ux_acc<C>(chk, a0, ldb(t, 1));    // the true cross pile sum k (a0 b1 + a1 b0), every accumulation checked
+      ux_acc<C>(chk, a1, ldb(t, 0));
+#endif
     }
     {
-      const Ux<C> a1 = scaled(t, 1), b0 = ldb(t, 0);
-      ux_acc<C>(e, a1, b0);
+      const Ux<C> b0 = ldb(t, 0), b1 = ldb(t, 1);
+#pragma unroll
+      for (int q = 0; q < N; ++q) sb.v[q] = b0.v[q] + b1.v[q];
     }
+#if RX_HOST_CHECK
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) d[i + j] += (u64)sa.v[i] * sb.v[j];          // mod 2^64 on purpose
+#else
+    ux_acc<C>(d, sa, sb);
+#endif
   }
-  r.c1 = ux_redc<C>(e);
+#if RX_HOST_CHECK
+  for (int k = 0; k < 2 * N; ++k)
+    if (chk[k] != d[k]) g_rx_overflow = 1;                                      // the wrap-around pile is the true cross pile
+#endif
+  r.c1 = ux_redc<C>(d);
   return r;
 }
 

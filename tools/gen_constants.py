@@ -222,7 +222,9 @@ def main():
             assert 3 * scol[k] + red[k] + carry < (1 << 64), ("S pile", k)                 # sum (a0+a1)(b0+b1), three terms
             assert 3 * col[k] + b3[k] + red[k] + carry < (1 << 64), ("D + BIAS", k)
             assert 6 * col[k] + b6[k] + red[k] + carry < (1 << 64), ("sqr D + BIAS", k)
-            assert 12 * col[k] + red[k] + carry < (1 << 64), ("sqr cross pile", k)          # six term-equivalents x (a0 b1 + a1 b0)
+            # six term-equivalents x (a0 b1 + a1 b0): the FINAL totals of the squaring's cross pile, which rx.hpp's ux_sqr_dot forms as
+            # -(D + E) + sum (a0 + a1)(b0 + b1) mod 2^64 (Karatsuba; the sum alone would not fit on 14 limbs, it is never formed alone)
+            assert 12 * col[k] + red[k] + carry < (1 << 64), ("sqr cross pile", k)
         o += "  static constexpr uint64_t RX_BIAS_D3[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b3))
         o += "  static constexpr uint64_t RX_BIAS_S6[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b6))
         if b2x3 is not None:
