@@ -316,7 +316,7 @@ struct Engine {
     const size_t groups = n_pad / ng;
     if ((rc = c.get(WS_LINES, n_pad * ps.point_bytes, &ptab))) return rc;
     if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-    if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
       Scope sc(c, st, ST_MILLER);
       kl::prep_points<C>(st, (const Aff<G1F>*)g1s, d_kinf, n, n_pad, (uint32_t*)ptab);
@@ -378,10 +378,14 @@ struct Engine {
     return 0;
   }
 
-  // product of the per-group partial products (w-basis Fp12 arrays, 6 Fp2 each) down to one
+  // product of the per-group partial products (w-basis Fp12 arrays, 6 Fp2 each) down to one.  Fan-in REDUCE_R per pass: a pass
+  // costs a launch boundary plus R - 1 dependent products (~11 us each on six lanes); three per pass is the shortest chain at
+  // the sizes that matter (65 partials of an n = 64 verification: 4 passes x 2 products instead of 4 x 3, 1.73 -> 1.69 ms;
+  // 10 240 of a 2^16 batch: 0.24 -> 0.22 ms).  The second buffer (b) must hold count / REDUCE_R + 1 products.
+  static constexpr int REDUCE_R = 3;
   static int reduce(Ctx& c, hipStream_t st, Fp2<C>* a, Fp2<C>* b, size_t cnt, Fp2<C>** out) {
     Scope sc(c, st, ST_REDUCE);
-    const int R = 4;                       // each pass costs R-1 dependent products of latency: keep the tree shallow per pass
+    const int R = REDUCE_R;
     while (cnt > 1) {
       const size_t nout = (cnt + R - 1) / R;
       kl::reduce_coop<C>(st, a, cnt, R, b);
@@ -423,7 +427,7 @@ struct Engine {
       const bool sig_block = sig && !cofactor;
       const size_t blocks = npairs + (sig_block ? 1 : 0);
       if ((rc = c.get(WS_F_A, (blocks + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-      if ((rc = c.get(WS_F_B, (blocks / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      if ((rc = c.get(WS_F_B, (blocks / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       {
         Scope sc(c, st, ST_MILLER);
         // k_miller_latx: the same two-wave block on the carry-free limbs (BGLS_LATX=0 keeps k_miller_lat: A/B runs)
@@ -454,13 +458,15 @@ struct Engine {
       // resident blocks with the machine to itself (there the slowest block is the launch: 5.5 instead of 7.2 ms for 61 440
       // BLS12-381 pairings), in steady state it costs 3-6 % (measured at 2^20, four verifications in flight)
       const size_t nb = np64 ? nb64 : nb60, NPB = np64 ? 64 : 60, groups = nb * 10;
-      const int xmode = g_x60_rot.load() >= 0 ? (g_x60_rot.load() & 15) : ((nb <= RES && !throughput_mode()) ? 8 : 0);
+      static const int stagger = [] { const char* e = getenv("BGLS_X60_STAGGER"); return e ? atoi(e) : 0; }();      // ticks of 10 ns per quarter step (0: off)
+      int xmode = g_x60_rot.load() >= 0 ? (g_x60_rot.load() & 15) : ((nb <= RES && !throughput_mode()) ? 8 : 0);
+      if (stagger > 0 && nb <= RES && !throughput_mode()) xmode |= 32 | ((stagger & 0xFFFF) << 8);
       constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take up to 57 / 49 KB per block)
       void* park;
       const size_t pblocks = nb < XB ? nb : XB;
       if ((rc = c.get(WS_QP, np64 ? kl::miller_x_park_bytes<C, 64>(pblocks) : kl::miller_x_park_bytes<C, 60>(pblocks), &park))) return rc;
       if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-      if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      if ((rc = c.get(WS_F_B, (groups / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       {
         Scope sc(c, st, ST_MILLER);
         for (size_t blk0 = 0; blk0 < nb; blk0 += XB) {
@@ -486,7 +492,7 @@ struct Engine {
       void* tab;
       if ((rc = c.get(WS_LINES, kl::lines_bytes<C>(variant, max_pad), &tab))) return rc;
       if ((rc = c.get(WS_F_A, (groups_total + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-      if ((rc = c.get(WS_F_B, (groups_total / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+      if ((rc = c.get(WS_F_B, (groups_total / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
       size_t gdone = 0;
       {
         Scope sc(c, st, ST_MILLER);
@@ -509,7 +515,7 @@ struct Engine {
         void* qp;
         if ((rc = c.get(WS_QP, kl::miller_qp_bytes<C>(nb60 < 8192 ? nb60 : 8192), &qp))) return rc;
         if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-        if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+        if ((rc = c.get(WS_F_B, (groups / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
         {
           Scope sc(c, st, ST_MILLER);
           for (size_t blk0 = 0; blk0 < nb60; blk0 += 8192) {
@@ -532,7 +538,7 @@ struct Engine {
     constexpr size_t AB = 16384;                        // blocks per launch: 2^20 pairings; the parked operands of a launch take 200 / 300 MB
     if ((rc = c.get(WS_QP, kl::miller_qp_bytes<C>(nb64 < AB ? nb64 : AB), &qp))) return rc;
     if ((rc = c.get(WS_F_A, (groups + 1) * 6 * sizeof(Fp2<C>), &pa))) return rc;
-    if ((rc = c.get(WS_F_B, (groups / 4 + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
+    if ((rc = c.get(WS_F_B, (groups / REDUCE_R + 2) * 6 * sizeof(Fp2<C>), &pb))) return rc;
     {
       Scope sc(c, st, ST_MILLER);
       for (size_t blk0 = 0; blk0 < nb64; blk0 += AB) {

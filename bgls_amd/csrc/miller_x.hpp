@@ -68,7 +68,10 @@ struct MX {
   // the hash points' coordinates (-yP, xP per pairing, read by both lanes of its pair at every step) live in LDS where a
   // quarter of a CU's 160 KB has room for them next to the groups, else in the lanes' global workspace (BLS12-381, NP = 64)
   static constexpr int PQ = 10 * GROUP_DW;            // [NP pairings][2] halves
-  static constexpr bool P_IN_LDS = (10 * GROUP_DW + NP * 2 * HS) * 4 <= 40960;
+#ifndef MX_P_LDS_LIMIT
+#define MX_P_LDS_LIMIT 40960
+#endif
+  static constexpr bool P_IN_LDS = (10 * GROUP_DW + NP * 2 * HS) * 4 <= MX_P_LDS_LIMIT;
   static constexpr int BLOCK_BYTES = (10 * GROUP_DW + (P_IN_LDS ? NP * 2 * HS : 0)) * 4;
   static constexpr int NPARK_Q = C::CURVE_ID == 0 ? 6 : 2;                  // xq yq [x1 y1 x2 y2]
   static constexpr int NPARK = NPARK_Q + (P_IN_LDS ? 0 : 2);                // ... nyP xP   (PS dwords each)
@@ -251,7 +254,7 @@ struct MxPark {
 // steady state and is gone.)
 template <class C, int DBG = 0, int NP = 60>
 __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
-                                                       int rot_mode) {
+                                                       int rot_mode, u32* rec_dbg) {
   typedef MX<C, NP> K;
   constexpr int NL = C::RX_NL;
   constexpr int PPW = NP / 2;                                    // pairings (lane pairs at work) per producer wave: 30 / 32
@@ -266,22 +269,43 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
   extern __shared__ u32 lds_roles[];
   const int rmode = rot_mode & 3;
   int role;
+  if constexpr (DBG == 3) {          // development tools only (tools/mb_lone.hip): where and when every wave runs; rec_dbg is the record buffer (nullptr in the library)
+    if (lane == 0) {
+      u32* rec = rec_dbg + ((size_t)blockIdx.x * 3 + w) * 8;
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      rec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      rec[2] = (u32)t; rec[3] = (u32)(t >> 32);
+    }
+  }
   if (rmode == 0) {
-    const int simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u);      // HW_REG_HW_ID bits 5:4
+    const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);                             // HW_REG_HW_ID
+    const int simd = (int)((hw >> 4) & 3u);                                               // bits 5:4
     if (lane == 0) lds_roles[w] = (u32)simd;
     __syncthreads();
     const int s0 = (int)lds_roles[0], s1 = (int)lds_roles[1], s2 = (int)lds_roles[2];
-    __syncthreads();                                           // the words are reused by the accumulator region
     int cw = 2;                                                // fallback: wave 2
     if (s0 != s1 && s0 != s2 && s1 != s2) {
       const int want = (6 - (s0 + s1 + s2) + 1) & 3;
       cw = s0 == want ? 0 : (s1 == want ? 1 : 2);
     }
+    __syncthreads();                                           // the words are reused by the accumulator region
     role = w == cw ? 2 : (w > cw ? w - 1 : w);
   } else {
     const int rot = rmode == 2 ? (int)(blockIdx.x % 3u) : 0;
     role = w + rot;
     if (role >= 3) role -= 3;
+  }
+  // rot_mode & 32: STAGGER.  A lone round of resident blocks starts in lock-step: on every SIMD the consumer of one block and
+  // the producers of two others are in the same phase of a step for the whole loop, so the producers' bursts collide and the
+  // consumer then runs alone (a lone wave issues a quarter-rate instruction every 5.3 clocks instead of 4).  The four blocks of
+  // a CU are blocks b, b + 256, b + 512, b + 768 of a 1024-block launch (dealt round-robin over 8 XCDs x 32 CUs): delaying
+  // block b by (b / 256 mod 4) quarter steps puts them a quarter step apart, as they are in steady state of a long launch.
+  if (rot_mode & 32) {
+    const unsigned q = (blockIdx.x >> 8) & 3u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)q * (unsigned)((rot_mode >> 8) & 0xFFFF);      // ticks of 10 ns per quarter step
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
   if (role < 2) {
     // ---------------------------------------------------------------- producer: PPW pairings, one per lane pair
@@ -473,6 +497,14 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
         if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w
       }
       out[((size_t)blockIdx.x * 10 + g) * 6 + j] = r;
+    }
+  }
+  if constexpr (DBG == 3) {
+    if (lane == 0) {
+      u32* rec = rec_dbg + ((size_t)blockIdx.x * 3 + w) * 8;
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      rec[4] = (u32)t; rec[5] = (u32)(t >> 32);
+      rec[6] = (u32)role;
     }
   }
 }

@@ -24,6 +24,7 @@ prof bls_x60_1048576 $SEQ --n 1048576 --curve bls12
 prof bn_x64_65536 $SEQ --n 65536
 prof bls_x64_65536 $SEQ --n 65536 --curve bls12
 prof multisig_1048576 --only multisig --n 1048576 --in-flight 1 --reps 1 --steps 5 --warmup 2
+prof multisig_keyset_1048576 --only multisig --key-set --n 1048576 --in-flight 1 --reps 1 --steps 5 --warmup 2
 prof default_overlapped --no-cpu-baseline --no-records --reps 1 --steps 5 --warmup 2
 prof bn_small_64 --only small --n 64
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -168,10 +168,10 @@ static double time_x60(size_t n, int rot, int reps) {
   CHK(hipMemcpy(g1s, h1.data(), n * sizeof(Aff<F1<C>>), hipMemcpyHostToDevice));
   hipEvent_t a, b;
   CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-  k_miller_x60<C, DBG, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+  k_miller_x60<C, DBG, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot, nullptr);
   CHK(hipDeviceSynchronize());
   CHK(hipEventRecord(a));
-  for (int r = 0; r < reps; ++r) k_miller_x60<C, DBG, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+  for (int r = 0; r < reps; ++r) k_miller_x60<C, DBG, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot, nullptr);
   CHK(hipEventRecord(b));
   CHK(hipEventSynchronize(b));
   float ms;

@@ -36,7 +36,7 @@ static void time_x(const char* name, size_t n, int rot, int reps) {
   CHK(hipFuncSetAttribute((const void*)k_miller_x60<C, 0, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, K::BLOCK_BYTES));
   std::vector<hipEvent_t> ev(reps + 1);
   for (auto& e : ev) CHK(hipEventCreate(&e));
-  for (int w = 0; w < 2; ++w) k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+  for (int w = 0; w < 2; ++w) k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot, nullptr);
   CHK(hipDeviceSynchronize());
   std::vector<float> ms(reps);
   const char* gap = getenv("MB_GAP_US");                  // idle time before every launch (a lone verification starts on an idle GPU)
@@ -45,7 +45,7 @@ static void time_x(const char* name, size_t n, int rot, int reps) {
       CHK(hipDeviceSynchronize());
       usleep(atoi(gap));
       CHK(hipEventRecord(ev[0]));
-      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot, nullptr);
       CHK(hipEventRecord(ev[1]));
       CHK(hipDeviceSynchronize());
       CHK(hipEventElapsedTime(&ms[r], ev[0], ev[1]));
@@ -53,7 +53,7 @@ static void time_x(const char* name, size_t n, int rot, int reps) {
   } else {
     CHK(hipEventRecord(ev[0]));
     for (int r = 0; r < reps; ++r) {
-      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot);
+      k_miller_x60<C, 0, NP><<<(unsigned)nb, K::THREADS, K::BLOCK_BYTES>>>(g1s, g2s, n, out, flags, park, rot, nullptr);
       CHK(hipEventRecord(ev[r + 1]));
     }
     CHK(hipDeviceSynchronize());
