@@ -458,9 +458,7 @@ struct Engine {
       // resident blocks with the machine to itself (there the slowest block is the launch: 5.5 instead of 7.2 ms for 61 440
       // BLS12-381 pairings), in steady state it costs 3-6 % (measured at 2^20, four verifications in flight)
       const size_t nb = np64 ? nb64 : nb60, NPB = np64 ? 64 : 60, groups = nb * 10;
-      static const int stagger = [] { const char* e = getenv("BGLS_X60_STAGGER"); return e ? atoi(e) : 0; }();      // ticks of 10 ns per quarter step (0: off)
-      int xmode = g_x60_rot.load() >= 0 ? (g_x60_rot.load() & 15) : ((nb <= RES && !throughput_mode()) ? 8 : 0);
-      if (stagger > 0 && nb <= RES && !throughput_mode()) xmode |= 32 | ((stagger & 0xFFFF) << 8);
+      const int xmode = g_x60_rot.load() >= 0 ? (g_x60_rot.load() & 15) : ((nb <= RES && !throughput_mode()) ? 8 : 0);
       constexpr size_t XB = 32768;                      // blocks per launch (the lanes' parked operands take up to 57 / 49 KB per block)
       void* park;
       const size_t pblocks = nb < XB ? nb : XB;

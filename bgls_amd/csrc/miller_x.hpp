@@ -296,17 +296,6 @@ __global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, co
     role = w + rot;
     if (role >= 3) role -= 3;
   }
-  // rot_mode & 32: STAGGER.  A lone round of resident blocks starts in lock-step: on every SIMD the consumer of one block and
-  // the producers of two others are in the same phase of a step for the whole loop, so the producers' bursts collide and the
-  // consumer then runs alone (a lone wave issues a quarter-rate instruction every 5.3 clocks instead of 4).  The four blocks of
-  // a CU are blocks b, b + 256, b + 512, b + 768 of a 1024-block launch (dealt round-robin over 8 XCDs x 32 CUs): delaying
-  // block b by (b / 256 mod 4) quarter steps puts them a quarter step apart, as they are in steady state of a long launch.
-  if (rot_mode & 32) {
-    const unsigned q = (blockIdx.x >> 8) & 3u;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)q * (unsigned)((rot_mode >> 8) & 0xFFFF);      // ticks of 10 ns per quarter step
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
   if (role < 2) {
     // ---------------------------------------------------------------- producer: PPW pairings, one per lane pair
     if (rot_mode & 8) __builtin_amdgcn_s_setprio(3);
