@@ -75,6 +75,44 @@ def test_config4_multisig_2pow20_altbn128(gpu_lib):
     assert coracle.verify_multi(cid, sig, apk_b, 1, msg) == 1
 
 
+@pytest.mark.parametrize("cid,fp", [(0, 32), (1, 48)])
+def test_key_sum_tree_shapes_match_the_oracle(gpu_lib, cid, fp):
+    """AggregatePoints (curves/curve.go:73-121) on G2 at sizes that give the one-launch tree (k_sumtree.hip) every shape: one
+    partial, two, odd counts whose single nodes pass through levels unpaired, counts around the 128-key blocks of the main pass,
+    the 3072-partial cap -- same bytes as the oracle's sequential additions and as (sum sk) g2; with the point at infinity and a
+    repeated key (P + P in the tree: the doubling case of the group law) among the inputs; and the same sums with the tree as one
+    launch per level (BGLS_SUMTREE=0 is read once per process, so that form runs in the legacy-path tests)."""
+    lib = gpu_lib
+    rnd = random.Random(77 + cid)
+    nmax = 70000
+    sks = [rnd.randrange(1, ORDER[cid]) for _ in range(nmax)]
+    keys = bytes(gen_keys(lib, cid, fp, sks))
+    g2 = out(4 * fp); lib.bgls_generator(cid, 2, g2)
+    PT = 4 * fp
+    for n in (1, 2, 3, 127, 128, 129, 255, 257, 300, 385, 600, 641, 1000, 4097, 65535, 70000):
+        got = out(PT)
+        assert lib.bgls_aggregate_points(cid, 2, B(keys[:n * PT]), n, got) == 0
+        assert bytes(got) == coracle.scale_point(cid, 2, bytes(g2), sum(sks[:n]) % ORDER[cid]), n
+        if n <= 1000:
+            assert bytes(got) == coracle.aggregate_points(cid, 2, keys[:n * PT], n), n
+    # infinity among the keys, the same key twice in one pair of leaves and across blocks, a key and its negation
+    n = 700
+    pts = bytearray(keys[:n * PT])
+    pts[5 * PT:6 * PT] = bytes(PT)                                   # infinity
+    pts[129 * PT:130 * PT] = pts[128 * PT:129 * PT]                  # neighbours equal
+    pts[400 * PT:401 * PT] = pts[10 * PT:11 * PT]                    # equal keys in different blocks
+    neg = coracle.scale_point(cid, 2, bytes(pts[20 * PT:21 * PT]), ORDER[cid] - 1)
+    pts[500 * PT:501 * PT] = neg                                     # P and -P
+    got = out(PT)
+    assert lib.bgls_aggregate_points(cid, 2, B(bytes(pts)), n, got) == 0
+    assert bytes(got) == coracle.aggregate_points(cid, 2, bytes(pts), n)
+    # two blocks whose sums are equal: the tree's first addition is a doubling
+    two = keys[:128 * PT] * 2
+    got = out(PT)
+    assert lib.bgls_aggregate_points(cid, 2, B(two), 256, got) == 0
+    assert bytes(got) == coracle.scale_point(cid, 2, bytes(g2), 2 * sum(sks[:128]) % ORDER[cid])
+
+
 def test_config5_bls12_2pow20_in_8_shards(gpu_lib):
     import torch
     lib, cid, fp, n, shards = gpu_lib, 1, 48, N20, 8

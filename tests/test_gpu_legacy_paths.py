@@ -1,5 +1,5 @@
 """GPU tier: the kernels that round 3 replaced stay selectable for A/B measurements (BGLS_FINALX=0: 36-lane final exponentiation
-on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue).  The switches are read once
+on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue, BGLS_SUMTREE=0: k_sum_coop per level instead of k_sum_tree).  The switches are read once
 per process, so each combination runs in a child process: PairingProduct of a handful of pairings (the latency path: k_miller_lat(x)
 + reduce + final exponentiation) must give the C oracle's GT bytes, and a 300-key aggregate of public keys the oracle's point."""
 import json
@@ -34,7 +34,7 @@ for cname, cid, fp in (("altbn128", 0, 32), ("bls12", 1, 48)):
     o = (ctypes.c_uint8 * (12 * fp))()
     assert L.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
     res[cname + "_gt"] = bytes(o) == coracle.pairing_product(cid, a, b, n, threads=4)
-    m = 300
+    m = 700                                                    # six blocks of the lane-pair main pass: a tree of six partials
     keys = [coracle.scale_point(cid, 2, g2, rnd.randrange(1, 1 << 250)) for _ in range(16)]
     pts = b"".join(keys[i %% 16] for i in range(m))            # repeated keys: the doubling branch of the mixed addition
     s = (ctypes.c_uint8 * (4 * fp))()
@@ -58,8 +58,8 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {}],
-                         ids=["32-bit tails and key sum", "one-lane key sum", "defaults"])
+@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {}],
+                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
     golden = os.path.join(ROOT, "tests", "golden")
     code = CHILD % (ROOT, golden)
