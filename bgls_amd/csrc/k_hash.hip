@@ -367,7 +367,15 @@ void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn,
   auto grid = [&](double expect_items, int lpm) {
     double lanes = expect_items * lpm * 2.0 + 512.0;
     size_t b = (size_t)(lanes / 64.0) + 1;
-    return (unsigned)(b > 8192 ? 8192 : b);
+    // Never more blocks than the chip holds at once (162 registers: three one-wave blocks per SIMD, 3072 in all; the kernels walk
+    // their work lists with grid-stride loops).  Round 4: a launch that OVERSUBSCRIBES the chip leaves the workgroup distributor in
+    // a state in which a later launch that fills the chip EXACTLY -- the 1024 blocks of a lone 2^16 Miller launch, four per CU --
+    // is dealt three blocks on some CUs and stalls on the rest until the first blocks finish (the same wave-cycles in 1.5x the
+    // time; it survives host synchronisation and intervening small kernels).  The 4105 blocks of the second round did that to
+    // 45 % of the lone alt-bn128 2^16 verifications: Miller stage 6.6 instead of 4.4 ms (tools/exp/pp_lone.sh: 11 of 24 launches
+    // slow with a cap of 4096 or 8192 blocks, 0 of 24 with 3072 or 2048).
+    const size_t cap = 3072;
+    return (unsigned)(b > cap ? cap : b);
   };
   const double N = (double)n;
   if (lean || n >= ((size_t)1 << 17)) {
