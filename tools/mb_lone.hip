@@ -91,6 +91,17 @@ static void run(size_t n, int rot, int launches, int pre) {
       else per_cu[cu]++;
       for (int w = 0; w < 3; ++w) if (h[(b * 3 + w) * 8 + 6] == 2) cons_simd[cu].push_back((h[(b * 3 + w) * 8] >> 4) & 3);
     }
+    {   // slot occupancy: sum of block residencies / (4 slots x CUs x launch duration); and over the steady part (10 % .. 80 % of the launch)
+      double tot = 0, steady = 0;
+      const double T = (t1 - t0) * us, a = 0.1 * T, b = 0.8 * T;
+      for (size_t blk = 0; blk < nb; ++blk) {
+        const double st = (ts(blk * 3, 2) - t0) * us, en = (ts(blk * 3, 4) - t0) * us;
+        tot += en - st;
+        const double lo = st > a ? st : a, hi = en < b ? en : b;
+        if (hi > lo) steady += hi - lo;
+      }
+      printf("  slot occupancy %.3f overall, %.3f in the steady part; blocks %zu\n", tot / (4.0 * 256 * T), steady / (4.0 * 256 * (b - a)), nb);
+    }
     int hist[8] = {0};
     for (auto& kv : per_cu) hist[std::min(kv.second, 7)]++;
     int dup = 0;
@@ -104,7 +115,7 @@ static void run(size_t n, int rot, int launches, int pre) {
 int main(int argc, char** argv) {
   const int curve = argc > 1 ? atoi(argv[1]) : 0, np = argc > 2 ? atoi(argv[2]) : 64, rot = argc > 3 ? atoi(argv[3]) : 8, launches = argc > 4 ? atoi(argv[4]) : 12;
   const int pre = argc > 5 ? atoi(argv[5]) : 0;
-  const size_t n = (size_t)1024 * np;
+  const size_t n = (size_t)(argc > 6 ? atoi(argv[6]) : 1024) * np;
   if (curve == 0 && np == 64) run<BN254, 64>(n, rot, launches, pre);
   else if (curve == 0) run<BN254, 60>(n, rot, launches, pre);
   else if (np == 64) run<BLS381, 64>(n, rot, launches, pre);
