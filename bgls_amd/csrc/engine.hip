@@ -212,6 +212,14 @@ int miller_shape() {
   return v < 0 ? 0 : v;
 }
 
+// BLS12-381 G1 scalar multiplications at the seam on the carry-free limbs (k_g1x.hip; measured at 2^18 points: Sign 55 -> 43 ms,
+// ScalePoints 36 -> 29 ms, identical bytes; alt-bn128 gains nothing -- ten 28-bit limbs against eight 32-bit ones -- and keeps the
+// 32-bit kernels); BGLS_G1X=0 keeps them on BLS12-381 as well (A/B runs)
+bool g1x() {
+  static const bool on = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // G2 key sums on the carry-free 28-bit-limb form.  Mode 2 (default): one key sum partial per LANE PAIR (k_sumpair.hip,
 // rx_jacpair.hpp: half of every Fp2 value per lane, three waves per SIMD).  Mode 1: one partial per lane (k_sumx.hip; measured
 // at 2^20 keys, main pass + tree: BLS12-381 1.20 vs 1.30 ms for the 32-bit form, alt-bn128 0.66 vs 0.60 ms -- one lane cannot
@@ -1075,7 +1083,8 @@ int scale_points_t(int group, const uint8_t* pts, const uint8_t* scalars, const 
   HIPCHK(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, st));
   if (signs) HIPCHK(hipMemcpyAsync(d_sg, signs, n, hipMemcpyHostToDevice, st));
   const uint8_t* sg = signs ? (const uint8_t*)d_sg : nullptr;
-  kl::scale<C>(st, group, (const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out, (uint32_t*)d_flags, 32);
+  if (group == BGLS_G1 && C::CURVE_ID == 1 && g1x()) kl::scale_g1x<C>(st, (const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out, (uint32_t*)d_flags, 32);
+  else kl::scale<C>(st, group, (const uint8_t*)d_in, (const uint8_t*)d_sc, sg, n, (uint8_t*)d_out, (uint32_t*)d_flags, 32);
   HIPCHK(hipGetLastError());
   uint32_t f = 0;
   HIPCHK(hipMemcpyAsync(out, d_out, n * PB, hipMemcpyDeviceToHost, st));
@@ -1686,7 +1695,8 @@ int sign_batch_t(const uint8_t* sks, const uint8_t* blob, const uint64_t* off, s
   HIPCHK(hipMemcpyAsync(d_sc, sks, n * 32, hipMemcpyHostToDevice, st));
   MsgView mv = {(const uint8_t*)d_blob, (const uint64_t*)d_off, 0, 0};
   if ((rc = E::hash_to_g1(c, st, mv, n, (Aff<F1<C>>*)d_g1s, (uint32_t*)d_flags))) return rc;
-  kl::scale_aff<C>(st, BGLS_G1, (const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  if (C::CURVE_ID == 1 && g1x()) kl::scale_aff_g1x<C>(st, (const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
+  else kl::scale_aff<C>(st, BGLS_G1, (const Aff<F1<C>>*)d_g1s, (const uint8_t*)d_sc, n, (uint8_t*)d_out);
   HIPCHK(hipGetLastError());
   uint32_t f = 0;
   HIPCHK(hipMemcpyAsync(out, d_out, n * E::G1B, hipMemcpyDeviceToHost, st));

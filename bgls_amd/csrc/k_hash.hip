@@ -1,9 +1,11 @@
 // Hashing kernels: duplicate-message scan and hash-to-G1 for both curves (see h2c.hpp for the algorithms and
 // their reference citations), plus the BLAKE2Xb expansion of the hashed-aggregation exponents.
+#include <stdlib.h>
 #include "dev_common.hpp"
 #include "h2c.hpp"
 #include "launch.hpp"
 #include "rx_pow.hpp"
+#include "rx_jac1.hpp"
 
 using namespace bgls;
 
@@ -270,6 +272,36 @@ __global__ void __launch_bounds__(64) k_bls_combine(size_t n, const Jac<F1<BLS38
   out[i] = jac_to_aff<F>(jac_add<F>(r, special));
 }
 
+// k_bls_combine<false> with the 126-bit cofactor multiplication on the carry-free limbs (rx_jac1.hpp; round 4): the public
+// HashToG1 (curves/bls12_381.go:349-376) clears the cofactor per message -- 125 doublings + 42 mixed additions of the NAF
+// chain, 1 337 field products -- and that chain is what this kernel moves off the 32-bit Montgomery form (51 ms per 2^20
+// messages there).  Sum of the two encodings, normalisation and the rare special outcomes stay as they were; same chain,
+// same group law, same bytes (the reference's 11 KATs).
+__global__ void __launch_bounds__(64) k_bls_combine_x(size_t n, const Jac<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+  typedef BLS381 C;
+  typedef F1<C> F;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac<F> sw = jac_inf<F>(), special = jac_inf<F>();
+  const Aff<F> g1 = {fp_load<C>(C::G1X), fp_load<C>(C::G1Y), false};
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t kind = kinds[2 * i + k];
+    if (kind == H2C_SW) sw = jac_add<F>(sw, pts[2 * i + k]);
+    else if (kind == H2C_PLUS_G1) special = jac_add_aff<F>(special, g1);
+    else if (kind == H2C_MINUS_G1) special = jac_add_aff<F>(special, aff_neg<F>(g1));
+  }
+  const Aff1<C> S = aff1_from_mont<C>(jac_to_aff<F>(sw));
+  const Aff1<C> nS = aff1_neg<C>(S);
+  Jac1<C> r = jac1_inf<C>();
+#pragma unroll 1
+  for (int d = 0; d < C::COFACTOR_NAF_LEN; ++d) {
+    r = jac1_dbl<C>(r);
+    const int dig = C::COFACTOR_NAF[d];
+    if (dig != 0) r = jac1_madd<C>(r, dig > 0 ? S : nS);
+  }
+  out[i] = jac_to_aff<F>(jac_add<F>(jac1_to_mont<C>(r), special));
+}
+
 // The verification path's combine (RAW) with the normalisation shared: a thread sums the two encodings of KB consecutive
 // messages, parks the Jacobian sums in the work-item array, and inverts the product of their Z coordinates once
 // (Montgomery's trick: the binary-Euclid inversion is ~240 field products' worth of divergent work, the trick costs 3 per
@@ -411,7 +443,11 @@ void h2c_bls(hipStream_t st, MsgView mv, size_t n, Jac<F1<BLS381>>* pts, uint32_
   k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, pts, kinds);
   if (raw && n >= ((size_t)1 << 18)) k_bls_combine_raw_batched<4><<<nblk((n + 3) / 4, 64), 64, 0, st>>>(n, pts, kinds, out);
   else if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
-  else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  else {
+    static const bool g1x = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();      // BGLS_G1X=0: the 32-bit chain (A/B runs)
+    if (g1x) k_bls_combine_x<<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+    else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  }
 }
 
 void blake2x_expand(hipStream_t st, const uint64_t* root, uint32_t xof_len, uint8_t* out) {

@@ -1,4 +1,4 @@
-// Launchers of k_sumtree.hip (declared apart from launch.hpp, which every unit includes: only engine.hip needs these).
+// Launchers of k_sumtree.hip and k_g1x.hip (declared apart from launch.hpp, which every unit includes: only engine.hip needs these).
 #pragma once
 #include "dev_common.hpp"
 
@@ -9,6 +9,10 @@ namespace kl {
 // wire bytes (d_bytes != nullptr) and / or as one Jacobian record (d_jac != nullptr).  store: cnt Jacobian records of scratch,
 // tickets: cnt words, zero on entry and zero again on exit.
 template <class C> void sum_tree(hipStream_t st, const void* in, size_t cnt, void* store, uint32_t* tickets, uint8_t* d_bytes, void* d_jac);
+
+// ---- k_g1x.hip: scalar multiplications on G1, one point per lane on the carry-free limbs (rx_jac1.hpp)
+template <class C> void scale_aff_g1x(hipStream_t st, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out);
+template <class C> void scale_g1x(hipStream_t st, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out, uint32_t* flags, int sbytes);
 
 }  // namespace kl
 }  // namespace bgls
