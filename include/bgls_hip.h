@@ -254,6 +254,16 @@ int bgls_final_verify_collect(int curve);
  * the neighbours fill it.  Results are identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the
  * environment. */
 int bgls_set_throughput_mode(int on);
+/* Environment switches, each read ONCE per process.  None changes a result: they select between kernels that compute the same
+ * bytes and exist for A/B measurements and for the legacy-path tests (tests/test_gpu_legacy_paths.py, tests/test_gpu_x60.py).
+ *   BGLS_THROUGHPUT=1     = bgls_set_throughput_mode(1)
+ *   BGLS_MILLER_SHAPE, BGLS_X60_ROT, BGLS_X_NP=60|64          see bgls_set_miller_shape below
+ *   BGLS_FINALX=0         final exponentiation on 32-bit limbs (k_final36)      BGLS_LATX=0   latency Miller kernel on 32-bit limbs
+ *   BGLS_EPIX=0           verification epilogue on 32-bit limbs (k_cofactor_epilogue)
+ *   BGLS_SUMX=0|1|2       G2 key sums: 32-bit limbs / one lane / lane pairs (default 2);  BGLS_SUM_WAVES = waves of their main pass
+ *   BGLS_SUMTREE=0        the tree above a key sum's partials as one launch per level instead of one launch
+ *   BGLS_G1X=0            BLS12-381 G1 scalar multiplications (Sign, ScalePoints, HashToG1's cofactor clearing) on 32-bit limbs
+ *   BGLS_NO_RCCL=1        host exchange between the devices of a key set instead of RCCL */
 /* Shape of the Miller stage.  0 (default): automatic -- up to 128 pairings the latency kernel; above, k_miller_x60 (carry-free
  * 28-bit limbs, lane-pair point steps) with 60 pairings per block, or with 64 per block where that saves a nearly empty last
  * round of the 1024 resident blocks outside throughput mode (61 441..65 536 pairings: exactly 2^16 is one round).  1..3:
