@@ -302,6 +302,60 @@ __global__ void __launch_bounds__(64) k_bls_combine_x(size_t n, const Jac<F1<BLS
   out[i] = jac_to_aff<F>(jac_add<F>(jac1_to_mont<C>(r), special));
 }
 
+// a^(p - 2) on the carry-free limbs: the inverse of a canonical non-zero a (the same element as fp_inv's binary Euclid)
+template <class C>
+__device__ __forceinline__ Fp<C> rx_inv_pow(const Fp<C>& a, i32* tab) {
+  constexpr int N = C::RX_NL;
+  const int lane = threadIdx.x & 63;
+  auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
+  auto st = [&](int e, int i, i32 v) { tab[(e * N + i) * 64 + lane] = v; };
+  auto word = [&](int k) { return C::EXP_INV[k]; };
+  const Sx<C, SX_T> r = sx_pow_sw<C, RXP_W, 32 * C::L>(ux_to_sx<C>(to_ux<C>(a)), word, ld, st);
+  Ux<C> u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];
+  return from_ux<C>(u);
+}
+
+// k_bls_combine<true> on the carry-free limbs (round 4), for the batches that k_bls_combine_raw_batched does not take (below 2^18
+// messages: a lone 2^16 verification, n = 64, the one message of a multi-signature).  There the kernel is a few lone waves and
+// every field product of the 32-bit form is a dependent carry chain (~5 us each on BLS12-381): the general addition A + B, the
+// binary-Euclid inversion and the normalisation took 0.71 ms for 2^16 messages.  Here the addition is rx_jac1.hpp's and the
+// inverse is Z^(p - 2) on the same limbs (a uniform chain of 380 squarings instead of ~760 divergent shift / subtract steps).
+// Same point, same affine bytes.
+__global__ void __launch_bounds__(64) k_bls_combine_raw_x(size_t n, const Jac<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
+  typedef BLS381 C;
+  typedef F1<C> F;
+  __shared__ i32 tab[rxp_lds_words<C>()];
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;                                       // the table is one column per lane: no block-level step follows
+  const Aff1<C> g1 = aff1_from_mont<C>(Aff<F>{fp_load<C>(C::G1KX), fp_load<C>(C::G1KY), false});
+  Jac1<C> sw = jac1_inf<C>();
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t kind = kinds[2 * i + k];
+    if (kind == H2C_SW) {
+      const Jac<F> q = pts[2 * i + k];
+      Jac1<C> qx;
+      qx.X = sx_as<SX_F, C>(sx_from_mont<C>(q.X));
+      qx.Y = sx_as<SX_F, C>(sx_from_mont<C>(q.Y));
+      qx.Z = sx_as<SX_F, C>(sx_from_mont<C>(q.Z));
+      qx.inf = jac_is_inf<F>(q);
+      sw = jac1_add<C>(sw, qx);
+    } else if (kind == H2C_PLUS_G1) {
+      sw = jac1_madd<C>(sw, g1);
+    } else if (kind == H2C_MINUS_G1) {
+      sw = jac1_madd<C>(sw, aff1_neg<C>(g1));
+    }
+  }
+  if (sw.inf) {
+    out[i] = {fp_zero<C>(), fp_zero<C>(), true};
+    return;
+  }
+  const Sx<C, SX_T> zi = sx_from_mont<C>(rx_inv_pow<C>(sx_to_mont<C>(sw.Z), tab));
+  const Sx<C, SX_T> zi2 = s1_sqr<C>(zi);
+  out[i] = {sx_to_mont<C>(s1_mul<C>(sw.X, zi2)), sx_to_mont<C>(s1_mul<C>(s1_mul<C>(sw.Y, zi2), zi)), false};
+}
+
 // The verification path's combine (RAW) with the normalisation shared: a thread sums the two encodings of KB consecutive
 // messages, parks the Jacobian sums in the work-item array, and inverts the product of their Z coordinates once
 // (Montgomery's trick: the binary-Euclid inversion is ~240 field products' worth of divergent work, the trick costs 3 per
@@ -442,7 +496,11 @@ void h2c_bls(hipStream_t st, MsgView mv, size_t n, Jac<F1<BLS381>>* pts, uint32_
   const size_t items = 2 * n;
   k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, pts, kinds);
   if (raw && n >= ((size_t)1 << 18)) k_bls_combine_raw_batched<4><<<nblk((n + 3) / 4, 64), 64, 0, st>>>(n, pts, kinds, out);
-  else if (raw) k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  else if (raw) {
+    static const bool g1x = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();
+    if (g1x) k_bls_combine_raw_x<<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+    else k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
+  }
   else {
     static const bool g1x = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();      // BGLS_G1X=0: the 32-bit chain (A/B runs)
     if (g1x) k_bls_combine_x<<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
