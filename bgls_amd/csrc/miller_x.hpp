@@ -252,8 +252,11 @@ struct MxPark {
 // results, used to time the two roles separately.
 // (Round 3's variant with two consumer waves per block -- 20 partial products, the squaring done twice -- measured slower in
 // steady state and is gone.)
+#ifndef MX_WAVES
+#define MX_WAVES 3          // waves per SIMD the register allocation is made for (tools: -DMX_WAVES=4 tries five blocks per CU)
+#endif
 template <class C, int DBG = 0, int NP = 60>
-__global__ void __launch_bounds__(192, 3) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
+__global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* park,
                                                        int rot_mode, u32* rec_dbg) {
   typedef MX<C, NP> K;
   constexpr int NL = C::RX_NL;
