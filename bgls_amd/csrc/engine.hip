@@ -391,12 +391,20 @@ struct Engine {
   // the sizes that matter (65 partials of an n = 64 verification: 4 passes x 2 products instead of 4 x 3, 1.73 -> 1.69 ms;
   // 10 240 of a 2^16 batch: 0.24 -> 0.22 ms).  The second buffer (b) must hold count / REDUCE_R + 1 products.
   static constexpr int REDUCE_R = 3;
+  static constexpr size_t REDUCE_FX_MAX = 12288;
   static int reduce(Ctx& c, hipStream_t st, Fp2<C>* a, Fp2<C>* b, size_t cnt, Fp2<C>** out) {
     Scope sc(c, st, ST_REDUCE);
     const int R = REDUCE_R;
+    // passes with at most REDUCE_FX_MAX products left run one product per BLOCK on the carry-free 36-lane form (k_reduce_fx:
+    // ~2-3 us per dependent product instead of 11 / 22 us); BGLS_REDUCEX=0 keeps k_reduce_coop everywhere (A/B runs)
+    static const bool rfx = [] { const char* e = getenv("BGLS_REDUCEX"); return !(e && e[0] == '0'); }();
+    static const int rfx_r = [] { const char* e = getenv("BGLS_REDUCEX_R"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 12 ? v : 10; }();      // >= REDUCE_R: the second buffer is sized for that
     while (cnt > 1) {
-      const size_t nout = (cnt + R - 1) / R;
-      kl::reduce_coop<C>(st, a, cnt, R, b);
+      const bool fx = rfx && cnt <= REDUCE_FX_MAX;
+      const int Rp = fx ? rfx_r : R;                          // operands converted side by side into LDS slots (at most 12), then a bare chain of ~1.5 us products: fewer, longer passes
+      const size_t nout = (cnt + Rp - 1) / Rp;
+      if (fx) kl::reduce_fx<C>(st, a, cnt, Rp, b);
+      else kl::reduce_coop<C>(st, a, cnt, Rp, b);
       Fp2<C>* t = a;
       a = b;
       b = t;

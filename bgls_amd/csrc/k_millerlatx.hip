@@ -12,6 +12,7 @@
 #include "finalx.hpp"
 #include "rx_jacpair.hpp"
 #include "launch.hpp"
+#include "launch_tail.hpp"
 
 namespace bgls {
 
@@ -330,7 +331,38 @@ __global__ void __launch_bounds__(64) k_epilogue_bx(const Fp2<C>* tmp, uint8_t* 
   }
 }
 
+// out[G] = prod in[G R .. min(count, (G + 1) R))  (w-basis Fp12 arrays in the library's Montgomery form) on the two-wave 36-lane
+// product of finalx.hpp (fx_mul): the passes of the reduce stage where few products are left and each pass is a chain of
+// dependent ones.  k_reduce_coop (six lanes per product, 32-bit limbs: ~11 us per alt-bn128 product, ~22 us per BLS12-381 one)
+// stays for the wide first passes of big batches, where lanes matter and latency does not.
+template <class C>
+__global__ void __launch_bounds__(128) k_reduce_fx(const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
+  typedef FX<C> E;
+  const int tid = threadIdx.x;
+  const size_t G = blockIdx.x, lo = G * (size_t)R;
+  const int nin = (int)((lo + R < count ? lo + R : count) - lo);          // 1 .. R <= 12 operands, one LDS slot each
+  // all operands are fetched and converted side by side (one coefficient per lane), then the products are a bare chain
+  for (int idx = tid; idx < 6 * nin; idx += 128) {
+    const int part = idx / 6, coeff = idx % 6;
+    const Fp2<C> v = in[(lo + part) * 6 + coeff];
+    fx_put<C>(part, coeff, X2<C, SX_T>{sx_from_mont<C>(v.c0), sx_from_mont<C>(v.c1)});
+  }
+  __syncthreads();
+  for (int k = 1; k < nin; ++k) fx_mul<C>(0, 0, k);
+  if (tid < 6) {
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(0, tid, 0));
+    out[G * 6 + tid] = Fp2<C>{sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
+  }
+}
+
 namespace kl {
+template <class C>
+void reduce_fx(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out) {
+  const size_t nout = (count + R - 1) / R;
+  k_reduce_fx<C><<<(unsigned)nout, 128, FX<C>::LDS_BYTES, st>>>(in, count, R, out);
+}
+template void reduce_fx<BN254>(hipStream_t, const Fp2<BN254>*, size_t, int, Fp2<BN254>*);
+template void reduce_fx<BLS381>(hipStream_t, const Fp2<BLS381>*, size_t, int, Fp2<BLS381>*);
 template <class C>
 void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
                         uint32_t* flags) {

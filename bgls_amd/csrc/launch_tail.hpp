@@ -14,5 +14,8 @@ template <class C> void sum_tree(hipStream_t st, const void* in, size_t cnt, voi
 template <class C> void scale_aff_g1x(hipStream_t st, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out);
 template <class C> void scale_g1x(hipStream_t st, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n, uint8_t* out, uint32_t* flags, int sbytes);
 
+// ---- k_millerlatx.hip: the narrow passes of the reduce stage on the two-wave 36-lane product (finalx.hpp)
+template <class C> void reduce_fx(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out);
+
 }  // namespace kl
 }  // namespace bgls
