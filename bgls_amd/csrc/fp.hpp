@@ -27,6 +27,8 @@ namespace bgls {
 
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
 
 BGLS_HD u32 addc(u32 a, u32 b, u32& c) {
   u32 co;
@@ -391,9 +393,10 @@ BGLS_FN Fp<C> fp_pow_w4(const Fp<C>& a, const u32* e) {
 
 // Modular inverse by the binary extended Euclidean algorithm (0 -> 0).  The inverse is unique, so
 // this returns the same field element as the reference's big.Int ModInverse / a^(p-2)
-// (curves/hash.go:109,139) at a fraction of the cost of an exponentiation.
+// (curves/hash.go:109,139) at a fraction of the cost of an exponentiation.  Since round 4 fp_inv is the division-step form
+// below (fp_inv_ds); this one stays for the host-side cross-check and the microbenchmark (tools/mb_inv.hip).
 template <class C>
-BGLS_FN Fp<C> fp_inv(const Fp<C>& a) {
+BGLS_FN Fp<C> fp_inv_euclid(const Fp<C>& a) {
   constexpr int L = C::L;
   if (fp_is_zero<C>(a)) return a;
   u32 u[L], v[L];
@@ -449,6 +452,173 @@ BGLS_FN Fp<C> fp_inv(const Fp<C>& a) {
   Fp<C> r = is_one(u) ? x1 : x2;        // (a R)^-1 as a plain residue
   const Fp<C> r2 = fp_load<C>(C::R2);
   return fp_mul_inl<C>(fp_mul_inl<C>(r, r2), r2);   // -> a^-1 R
+}
+
+// Modular inverse by BATCHED DIVISION STEPS (Bernstein-Yang "safegcd" in the form libsecp256k1 made familiar: half-delta
+// division steps, 30 per batch on the low words, one 2 x 2 transition matrix per batch applied to the full-width numbers).
+// Round 4: fp_inv's binary Euclid is two nested data-dependent loops -- a lone lane needs ~110 us (alt-bn128) / ~250 us
+// (BLS12-381) for it, a wave whose 64 lanes hold different values 300 / 610 us (tools/mb_inv.hip), and every latency-bound
+// record pays one or two of them (the easy part of the final exponentiation, the to-affine step of a key sum).  Here the
+// control flow does not depend on the data at all: a batch is 30 branch-free steps on two 32-bit words and four rows of
+// multiply-adds over NW signed 30-bit limbs, and the only loop condition (g = 0 on every active lane) is wave-uniform.
+// Invariants: d a = f, e a = g (mod p); f = p, g = a, d = 0, e = 1 at the start; at the end g = 0, f = +-1 and a^-1 = f d.
+// Same field element as fp_inv (the inverse is unique); 0 -> 0.
+template <class C>
+BGLS_FN Fp<C> fp_inv_ds(const Fp<C>& a) {
+  constexpr int L = C::L;
+  constexpr int NW = (32 * L + 29) / 30 + ((32 * L) % 30 == 0 ? 1 : 0);      // 9 limbs for 256 bits, 13 for 384: a sign bit to spare
+  constexpr i32 M30 = (i32)((1u << 30) - 1u);
+  static_assert(30 * NW >= 32 * L + 2, "limbs hold (-2p, 2p)");
+  auto limb = [](const u32* w, int i) -> i32 {                               // bits [30 i, 30 i + 30) of an L-word number
+    const int bit = 30 * i, q = bit >> 5, sh = bit & 31;
+    if (q >= L) return 0;
+    u64 x = w[q];
+    if (q + 1 < L) x |= (u64)w[q + 1] << 32;
+    return (i32)((u32)(x >> sh) & (u32)M30);
+  };
+  i32 f[NW], g[NW], d[NW], e[NW], m[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    m[i] = limb(C::P, i);
+    f[i] = m[i];
+    g[i] = limb(a.v, i);
+    d[i] = 0;
+    e[i] = i == 0 ? 1 : 0;
+  }
+  u32 minv = C::P[0];                                                         // p^-1 mod 2^32 by Newton's iteration (p odd)
+  minv *= 2u - C::P[0] * minv;
+  minv *= 2u - C::P[0] * minv;
+  minv *= 2u - C::P[0] * minv;
+  minv *= 2u - C::P[0] * minv;
+  minv *= 2u - C::P[0] * minv;
+  i32 zeta = -1;
+  for (int batch = 0; batch < 64; ++batch) {                                  // 590 steps suffice for 256 bits, ~870 for 384: 20 / 29 batches
+    i32 u = 1, v = 0, q = 0, r = 1;
+    {
+      u32 fl = (u32)f[0] | ((u32)f[1] << 30), gl = (u32)g[0] | ((u32)g[1] << 30);
+#pragma unroll
+      for (int i = 0; i < 30; ++i) {
+        i32 c1 = zeta >> 31;
+        const i32 c2 = -(i32)(gl & 1u);
+        const u32 x = (fl ^ (u32)c1) - (u32)c1;
+        const i32 y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+        gl += x & (u32)c2;
+        q += y & c2;
+        r += z & c2;
+        c1 &= c2;
+        zeta = (zeta ^ c1) - 1;
+        fl += gl & (u32)c1;
+        u += q & c1;
+        v += r & c1;
+        gl >>= 1;
+        u = (i32)((u32)u << 1);
+        v = (i32)((u32)v << 1);
+      }
+    }
+    // 2^30 (f', g') = (u f + v g, q f + r g);  (d', e') = the same combination divided by 2^30 modulo p
+    {
+      const i32 sd = d[NW - 1] >> 31, se = e[NW - 1] >> 31;
+      i32 md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+      i64 cd = (i64)u * d[0] + (i64)v * e[0], ce = (i64)q * d[0] + (i64)r * e[0];
+      md -= (i32)((minv * (u32)cd + (u32)md) & (u32)M30);
+      me -= (i32)((minv * (u32)ce + (u32)me) & (u32)M30);
+      cd += (i64)m[0] * md;
+      ce += (i64)m[0] * me;
+      cd >>= 30;
+      ce >>= 30;
+#pragma unroll
+      for (int i = 1; i < NW; ++i) {
+        cd += (i64)u * d[i] + (i64)v * e[i] + (i64)m[i] * md;
+        ce += (i64)q * d[i] + (i64)r * e[i] + (i64)m[i] * me;
+        d[i - 1] = (i32)cd & M30;
+        e[i - 1] = (i32)ce & M30;
+        cd >>= 30;
+        ce >>= 30;
+      }
+      d[NW - 1] = (i32)cd;
+      e[NW - 1] = (i32)ce;
+    }
+    u32 gnz;
+    {
+      i64 cf = (i64)u * f[0] + (i64)v * g[0], cg = (i64)q * f[0] + (i64)r * g[0];
+      cf >>= 30;
+      cg >>= 30;
+      gnz = 0;
+#pragma unroll
+      for (int i = 1; i < NW; ++i) {
+        cf += (i64)u * f[i] + (i64)v * g[i];
+        cg += (i64)q * f[i] + (i64)r * g[i];
+        f[i - 1] = (i32)cf & M30;
+        g[i - 1] = (i32)cg & M30;
+        gnz |= (u32)g[i - 1];
+        cf >>= 30;
+        cg >>= 30;
+      }
+      f[NW - 1] = (i32)cf;
+      g[NW - 1] = (i32)cg;
+      gnz |= (u32)g[NW - 1];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(gnz != 0) == 0ull) break;                                    // wave-uniform: every active lane is done
+#else
+    if (gnz == 0) break;
+#endif
+  }
+  // f = +-1 (gcd): a^-1 = f d, d in (-2p, p).  Bring sign(f) d + 2p into 32-bit words and subtract p while it is >= p.
+  u32 fone = (u32)f[0] ^ 1u, fmone = (u32)(f[0] ^ M30);
+#pragma unroll
+  for (int i = 1; i < NW; ++i) { fone |= (u32)f[i]; fmone |= (u32)(f[i] ^ (i == NW - 1 ? -1 : M30)); }
+  if (fone != 0 && fmone != 0) return fp_zero<C>();                           // a = 0 (f stays p): no inverse
+  const i32 sf = fone == 0 ? 0 : -1;                                          // negate d when f = -1
+  i64 c = 0;
+  u32 w[L + 1];
+  {
+    // value = sum (sign d_i + 2 m_i) 2^(30 i), accumulated into 32-bit words
+    u64 acc = 0;
+    int have = 0, wi = 0;
+    i64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      carry += (i64)((d[i] ^ sf) - sf) + 2 * (i64)m[i];
+      const u32 lo = (u32)carry & (u32)M30;                                   // 30 bits of the non-negative total
+      carry >>= 30;
+      acc |= (u64)lo << have;
+      have += 30;
+      if (have >= 32) {
+        if (wi <= L) w[wi] = (u32)acc;
+        ++wi;
+        acc >>= 32;
+        have -= 32;
+      }
+    }
+    acc |= (u64)(u32)carry << have;                                           // what is left above the last limb (small, non-negative)
+    while (wi <= L) { w[wi++] = (u32)acc; acc >>= 32; }
+    (void)c;
+  }
+  Fp<C> rr;
+#pragma unroll
+  for (int j = 0; j < L; ++j) rr.v[j] = w[j];
+  u32 top = w[L];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                                               // value < 4p: at most three subtractions
+    u32 bw = 0;
+    u32 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = subb(rr.v[j], C::P[j], bw);
+    const bool ge = top != 0 || bw == 0;
+    if (ge) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) rr.v[j] = t[j];
+      top -= bw;
+    }
+  }
+  const Fp<C> r2 = fp_load<C>(C::R2);
+  return fp_mul_inl<C>(fp_mul_inl<C>(rr, r2), r2);                            // (a R)^-1 -> a^-1 R
+}
+// THE inverse of the library (0 -> 0)
+template <class C>
+BGLS_HD Fp<C> fp_inv(const Fp<C>& a) {
+  return fp_inv_ds<C>(a);
 }
 
 // Legendre symbol (a/p) by the binary Jacobi algorithm: +1, -1, or 0 for a == 0.  Decides exactly what

@@ -302,33 +302,17 @@ __global__ void __launch_bounds__(64) k_bls_combine_x(size_t n, const Jac<F1<BLS
   out[i] = jac_to_aff<F>(jac_add<F>(jac1_to_mont<C>(r), special));
 }
 
-// a^(p - 2) on the carry-free limbs: the inverse of a canonical non-zero a (the same element as fp_inv's binary Euclid)
-template <class C>
-__device__ __forceinline__ Fp<C> rx_inv_pow(const Fp<C>& a, i32* tab) {
-  constexpr int N = C::RX_NL;
-  const int lane = threadIdx.x & 63;
-  auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
-  auto st = [&](int e, int i, i32 v) { tab[(e * N + i) * 64 + lane] = v; };
-  auto word = [&](int k) { return C::EXP_INV[k]; };
-  const Sx<C, SX_T> r = sx_pow_sw<C, RXP_W, 32 * C::L>(ux_to_sx<C>(to_ux<C>(a)), word, ld, st);
-  Ux<C> u;
-#pragma unroll
-  for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];
-  return from_ux<C>(u);
-}
-
 // k_bls_combine<true> on the carry-free limbs (round 4), for the batches that k_bls_combine_raw_batched does not take (below 2^18
 // messages: a lone 2^16 verification, n = 64, the one message of a multi-signature).  There the kernel is a few lone waves and
 // every field product of the 32-bit form is a dependent carry chain (~5 us each on BLS12-381): the general addition A + B, the
 // binary-Euclid inversion and the normalisation took 0.71 ms for 2^16 messages.  Here the addition is rx_jac1.hpp's and the
-// inverse is Z^(p - 2) on the same limbs (a uniform chain of 380 squarings instead of ~760 divergent shift / subtract steps).
-// Same point, same affine bytes.
+// inverse is fp_inv's division-step form (uniform control flow: 62 us for a wave of 64 different values where the binary
+// Euclid took 670 and Z^(p - 2) on these limbs 510, tools/mb_inv.hip).  Same point, same affine bytes.
 __global__ void __launch_bounds__(64) k_bls_combine_raw_x(size_t n, const Jac<F1<BLS381>>* pts, const uint32_t* kinds, Aff<F1<BLS381>>* out) {
   typedef BLS381 C;
   typedef F1<C> F;
-  __shared__ i32 tab[rxp_lds_words<C>()];
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;                                       // the table is one column per lane: no block-level step follows
+  if (i >= n) return;
   const Aff1<C> g1 = aff1_from_mont<C>(Aff<F>{fp_load<C>(C::G1KX), fp_load<C>(C::G1KY), false});
   Jac1<C> sw = jac1_inf<C>();
   for (int k = 0; k < 2; ++k) {
@@ -351,7 +335,7 @@ __global__ void __launch_bounds__(64) k_bls_combine_raw_x(size_t n, const Jac<F1
     out[i] = {fp_zero<C>(), fp_zero<C>(), true};
     return;
   }
-  const Sx<C, SX_T> zi = sx_from_mont<C>(rx_inv_pow<C>(sx_to_mont<C>(sw.Z), tab));
+  const Sx<C, SX_T> zi = sx_from_mont<C>(fp_inv<C>(sx_to_mont<C>(sw.Z)));
   const Sx<C, SX_T> zi2 = s1_sqr<C>(zi);
   out[i] = {sx_to_mont<C>(s1_mul<C>(sw.X, zi2)), sx_to_mont<C>(s1_mul<C>(s1_mul<C>(sw.Y, zi2), zi)), false};
 }

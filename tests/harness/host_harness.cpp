@@ -51,6 +51,7 @@ static int fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 6: r = fp_sqrt_candidate<C>(x); break;
     case 7: return fp_jacobi<C>(x) + 10;
     case 8: return fp_jacobi<C>(fp_from_mont<C>(x)) + 10;
+    case 9: r = fp_inv_euclid<C>(x); break;          // the binary Euclid fp_inv was until round 4 (cross-check of the division-step form)
     default: return -1;
   }
   fp_to_be<C>(out, fp_from_mont<C>(r));

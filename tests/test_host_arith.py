@@ -25,13 +25,20 @@ def test_fp_and_fp2(host_harness, curve):
     T = Pairing(c).T
     rnd = random.Random(7)
     ops = ((0, lambda a, b: a * b % p), (1, lambda a, b: a * a % p), (2, lambda a, b: (a + b) % p), (3, lambda a, b: (a - b) % p),
-           (4, lambda a, b: (-a) % p), (5, lambda a, b: pow(a, p - 2, p)), (6, lambda a, b: pow(a, (p + 1) // 4, p)))
+           (4, lambda a, b: (-a) % p), (5, lambda a, b: pow(a, p - 2, p)), (6, lambda a, b: pow(a, (p + 1) // 4, p)),
+           (9, lambda a, b: pow(a, p - 2, p)))          # 5: fp_inv (batched division steps since round 4), 9: the binary Euclid it replaced
     samples = [(0, 0), (1, p - 1), (p - 1, p - 1), (p - 1, 1), (2, (p + 1) // 2)] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(24)]
     for op, fn in ops:
         for a, b in samples:
             o = out(n)
             assert lib.ht_fp_op(cid, op, B(a.to_bytes(n, "big")), B(b.to_bytes(n, "big")), o) == 0
             assert int.from_bytes(bytes(o), "big") == fn(a, b), (op, a, b)
+    # the inverse on many more values: small, p - small, powers of two (long runs of division steps without a swap), random
+    inv_samples = list(range(0, 40)) + [p - k for k in range(1, 40)] + [1 << k for k in range(1, p.bit_length() - 1, 7)] + [rnd.randrange(p) for _ in range(600)]
+    for a in inv_samples:
+        o = out(n)
+        assert lib.ht_fp_op(cid, 5, B(a.to_bytes(n, "big")), B(bytes(n)), o) == 0
+        assert int.from_bytes(bytes(o), "big") == pow(a, p - 2, p), a
     # Legendre symbol by the binary Jacobi algorithm == Euler criterion (hash.go:254-265), on the Montgomery
     # residue (op 7) and on the plain residue (op 8)
     for a in [0, 1, 2, 3, 4, p - 1, p - 2, (p + 1) // 2, 1 << 64, (1 << 200) + 12345] + [rnd.randrange(p) for _ in range(200)]:
