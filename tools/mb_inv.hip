@@ -53,6 +53,7 @@ static int run(const char* name) {
   return 0;
 }
 int main() {
+
   run<BN254, 0>("alt-bn128 fp_inv (binary Euclid)");
   run<BN254, 1>("alt-bn128 a^(p-2), carry-free");
   run<BN254, 2>("alt-bn128 division steps");
