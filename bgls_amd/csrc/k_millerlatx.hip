@@ -278,11 +278,14 @@ __global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, cons
 // generator's pre-computed lines for the signature pair (the latency-form Miller block above), block 1 raises rest to h on the
 // one-wave 36-lane product (general squarings: rest is not unitary before the final exponentiation) -- and a second, one-wave
 // launch multiplies the two and serialises the result.  tmp: 12 Fp2 (w-basis, the library's Montgomery form).
+// first_role: the role of block 0.  A launch of two blocks (first_role 0) runs both chains side by side; a launch of ONE block runs
+// the signature pair alone (first_role 0) -- it depends on nothing but sigma, so a verification with the machine to itself walks
+// it on the context's side stream while the messages are hashed -- or rest^h alone (first_role 1).
 template <class C>
 __global__ void __launch_bounds__(128) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
-                                                     uint32_t* flags) {
+                                                     uint32_t* flags, int first_role) {
   typedef FX<C> E;
-  if (blockIdx.x == 0) {
+  if ((int)blockIdx.x + first_role == 0) {
     if (sig != nullptr) {
       miller_latx_block<C>(sig, nullptr, 0, 0, gen_lines, tmp, flags, 0);      // (-sigma, g2): pair "n" of an empty batch
     } else if (threadIdx.x < 6) {
@@ -366,9 +369,21 @@ template void reduce_fx<BLS381>(hipStream_t, const Fp2<BLS381>*, size_t, int, Fp
 template <class C>
 void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
                         uint32_t* flags) {
-  k_epilogue_ax<C><<<2, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags);
+  k_epilogue_ax<C><<<2, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, 0);
   k_epilogue_bx<C><<<1, 64, FX<C>::LDS_BYTES, st>>>(tmp, out);
 }
+// the two chains as separate launches: part 1 = the signature pair only (tmp[0..5]), part 2 = rest^h (tmp[6..11]) and the product
+template <class C>
+void cofactor_epiloguex_part(hipStream_t st, int part, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out) {
+  if (part == 1) {
+    k_epilogue_ax<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, nullptr, 0);
+  } else {
+    k_epilogue_ax<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, nullptr, 1);
+    k_epilogue_bx<C><<<1, 64, FX<C>::LDS_BYTES, st>>>(tmp, out);
+  }
+}
+template void cofactor_epiloguex_part<BN254>(hipStream_t, int, const Fp2<BN254>*, const Aff<F1<BN254>>*, const LineCoeffs<BN254>*, Fp2<BN254>*, uint8_t*);
+template void cofactor_epiloguex_part<BLS381>(hipStream_t, int, const Fp2<BLS381>*, const Aff<F1<BLS381>>*, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint8_t*);
 template void cofactor_epiloguex<BN254>(hipStream_t, const Fp2<BN254>*, const Aff<F1<BN254>>*, const LineCoeffs<BN254>*, Fp2<BN254>*, uint8_t*, uint32_t*);
 template void cofactor_epiloguex<BLS381>(hipStream_t, const Fp2<BLS381>*, const Aff<F1<BLS381>>*, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint8_t*, uint32_t*);
 template <class C>

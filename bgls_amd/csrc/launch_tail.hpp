@@ -16,6 +16,8 @@ template <class C> void scale_g1x(hipStream_t st, const uint8_t* pts, const uint
 
 // ---- k_millerlatx.hip: the narrow passes of the reduce stage on the two-wave 36-lane product (finalx.hpp)
 template <class C> void reduce_fx(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* out);
+// the verification epilogue's two chains as separate launches (1: the signature pair, 2: rest^h and the product of the two)
+template <class C> void cofactor_epiloguex_part(hipStream_t st, int part, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out);
 
 }  // namespace kl
 }  // namespace bgls
