@@ -167,6 +167,65 @@ __device__ __noinline__ void fx_mul1(int dst, int a, int b) {
   wave_sync();
 }
 
+// hand-over words of fx_mul2w: one lane calls this before the block's first barrier; dynamic LDS = FX::LDS_BYTES + FX2W_EXTRA_BYTES
+constexpr int FX2W_EXTRA_BYTES = 16;
+template <class C>
+__device__ __forceinline__ void fx_mul2w_init() {
+  extern __shared__ u32 lds[];
+  lds[FX<C>::LDS_DW] = 0;
+  lds[FX<C>::LDS_DW + 1] = 0;
+}
+// The two-wave product WITHOUT block barriers (round 4): for a block whose third wave does something else and must not be
+// dragged into the product's barriers (k_miller_latx: the accumulator on waves 0 and 1, the point steps on wave 2).  The two
+// stages of fx_mul are separated by hand-overs through two LDS words instead: wave 1 publishes "my half-products of product
+// number `epoch` are stored", wave 0 (whose lanes 0..11 add the terms up) publishes "coefficients of product `epoch` are
+// stored"; each side spins on the other's word.  Both waves call it the same number of times with their own copy of `epoch`.
+template <class C>
+__device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32& epoch) {
+  typedef FX<C> E;
+  extern __shared__ u32 lds[];
+  u32* const s_flag = lds + E::LDS_DW;                      // two words behind the slots: the caller zeroes them (fx_mul2w_init) and sizes the block's LDS for them
+  const int tid = threadIdx.x, lane = tid & 63, h = (tid >> 6) & 1;
+  ++epoch;
+  if (lane < 36) {
+    const int j = lane / 6, t = lane % 6;
+    int k = j - t;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(a, t, 0));
+    const int yo = E::coef(b, k, wrap);
+    const Sx<C, SX_T> ya = fx_ld<C>(yo + (h ? E::HS : 0)), yb = fx_ld<C>(yo + (h ? 0 : E::HS));      // y0 y1 | y1 y0
+    const i32 sg = h ? 0 : -1;                                                                        // - a1 b1 on the real half
+    const i32* const cols[2] = {ya.v, yb.v};
+    const Sx<C, SX_T> p = sx_montr<C, 2, 2 * SX_T * SX_T>(cols, [&](int q, int i) { return q == 0 ? x.c0.v[i] : (x.c1.v[i] ^ sg) - sg; });
+    fx_st<C>(E::SCR + lane * E::ES + h * E::HS, p);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (h == 1) {
+    if (lane == 0) __hip_atomic_store(&s_flag[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return;
+  }
+  while (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane < 12) {
+    const int j = lane >> 1, hh = lane & 1;
+    const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
+    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
+    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
+    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
+    Sx<C, SX_T> other;
+#pragma unroll
+    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
+    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&s_flag[1], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  wave_sync();
+}
+
 template <class C>
 __device__ __forceinline__ void fx_conj(int dst, int a) {           // a^(p^6): w -> -w
   typedef FX<C> E;

@@ -7,6 +7,7 @@
 // the rows of a carry-free product are independent multiplier instructions, where the 32-bit form walks a carry chain: a
 // round costs ~1 500 clocks instead of ~6 000.  Block `n` (when sig_at >= 0) is the (-sigma, g2) pair on the pre-computed
 // generator lines.  out: one w-basis Fp12 (6 Fp2, the library's 32-bit Montgomery form) per block.
+#include <stdlib.h>
 #include "dev_common.hpp"
 #include "pairing.hpp"
 #include "finalx.hpp"
@@ -18,7 +19,9 @@ namespace bgls {
 
 // one block = one pairing: pair `blk` of the batch (blk == n with sig_at >= 0: the (-sigma, g2) pair); the six w-basis coefficients
 // of the Miller value go to out[blk * 6 ..]
-template <class C>
+// AW = waves of the accumulator: 1 (round 3: the one-wave product fx_mul1, ~3.5 us on alt-bn128) or 2 (round 4: fx_mul2w, the
+// two-wave product with LDS hand-overs instead of block barriers, ~1.6 us); the point steps run on wave AW.
+template <class C, int AW>
 __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
                                                   const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, size_t blk) {
   typedef FX<C> E;
@@ -51,6 +54,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
     }
   };
   if (wave == 0) {
+    if (AW == 2 && lane == 63) fx_mul2w_init<C>();
     if (lane < 6) {
       const Sx<C, SX_T> zero = ux_to_sx<C>(ux_zero<C>());
       const X2<C, SX_T> z2 = {zero, zero}, one = {sx_const<C>(C::RX_ONE), zero};
@@ -58,7 +62,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
       fx_put<C>(S_L0, lane, z2);
       fx_put<C>(S_L1, lane, z2);
     }
-  } else if (lane < 2) {
+  } else if (wave == AW && lane < 2) {
     // lane pair 0 parses this block's pair (block n: -sigma against the generator)
     Aff<F1<C>> P = g1s[is_sig ? (size_t)sig_at : blk];
     AffP<C> Q;
@@ -88,7 +92,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
   }
   __syncthreads();
   const bool valid = s_valid != 0;
-  if (wave == 1) {
+  if (wave == AW) {
     // ------------------------------------------------ producer: point steps on lane pairs, or generator lines
     const Sx<C, SX_T> xP = LD(PT0), yP = LD(PT1);                        // own halves of (xP, 0), (yP, 0)
     Sx<C, SX_T> xPs, yPs;                                                // the same scalars on both lanes (the odd lane holds zero)
@@ -236,14 +240,19 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
   } else {
     // ------------------------------------------------ consumer: f <- f^2 * line, one Fp12 on 36 lanes
     int buf = 0;
+    u32 epoch = 0;
+    auto mul = [&](int dst, int a, int b) {
+      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, epoch);
+      else fx_mul1<C>(dst, a, b);
+    };
     auto fold = [&]() {
       __syncthreads();                                        // the line of this step is complete
-      if (valid) fx_mul1<C>(S_F, S_F, buf ? S_L1 : S_L0);
+      if (valid) mul(S_F, S_F, buf ? S_L1 : S_L0);
       buf ^= 1;
     };
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      if (i > 1 && valid) fx_mul1<C>(S_F, S_F, S_F);
+      if (i > 1 && valid) mul(S_F, S_F, S_F);
       fold();
       if (C::LOOP_NAF[i] != 0) fold();
     }
@@ -251,7 +260,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
       fold();
       fold();
     } else {
-      if (lane < 24) {                                        // x < 0: conjugate (w -> -w)
+      if (wave == 0 && lane < 24) {                           // x < 0: conjugate (w -> -w)
         const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
         Sx<C, SX_T> v = fx_ld<C>(E::coef(S_F, k, xi) + h * HS);
         if (k & 1) v = sx_neg<C>(v);
@@ -259,17 +268,17 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
       }
       wave_sync();
     }
-    if (lane < 6) {
+    if (wave == 0 && lane < 6) {
       const X2<C, SX_T> x = fx_ld2<C>(E::coef(S_F, lane, 0));
       out[blk * 6 + lane] = Fp2<C>{sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
     }
   }
 }
 
-template <class C>
-__global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
-                                                     const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
-  miller_latx_block<C>(g1s, g2s, n, sig_at, gen_lines, out, flags, blockIdx.x);
+template <class C, int AW>
+__global__ void __launch_bounds__(64 * (AW + 1)) k_miller_latx(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
+                                                               const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags) {
+  miller_latx_block<C, AW>(g1s, g2s, n, sig_at, gen_lines, out, flags, blockIdx.x);
 }
 
 // ---- epilogue of a batch verification on the same arithmetic (replaces k_cofactor_epilogue of k_tail.inc): partial product =
@@ -281,19 +290,19 @@ __global__ void __launch_bounds__(128) k_miller_latx(const Aff<F1<C>>* g1s, cons
 // first_role: the role of block 0.  A launch of two blocks (first_role 0) runs both chains side by side; a launch of ONE block runs
 // the signature pair alone (first_role 0) -- it depends on nothing but sigma, so a verification with the machine to itself walks
 // it on the context's side stream while the messages are hashed -- or rest^h alone (first_role 1).
-template <class C>
-__global__ void __launch_bounds__(128) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
-                                                     uint32_t* flags, int first_role) {
+template <class C, int AW>
+__global__ void __launch_bounds__(64 * (AW + 1)) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
+                                                               uint32_t* flags, int first_role) {
   typedef FX<C> E;
   if ((int)blockIdx.x + first_role == 0) {
     if (sig != nullptr) {
-      miller_latx_block<C>(sig, nullptr, 0, 0, gen_lines, tmp, flags, 0);      // (-sigma, g2): pair "n" of an empty batch
+      miller_latx_block<C, AW>(sig, nullptr, 0, 0, gen_lines, tmp, flags, 0);  // (-sigma, g2): pair "n" of an empty batch
     } else if (threadIdx.x < 6) {
       tmp[threadIdx.x] = threadIdx.x == 0 ? f2_one<C>() : f2_zero<C>();
     }
     return;
   }
-  if (threadIdx.x >= 64) return;
+  if (threadIdx.x >= 64 * AW) return;                       // rest^h on the accumulator's waves (a wave that has ended does not count at a barrier)
   const int lane = threadIdx.x;
   enum { S_BASE = 0, S_ACC = 1 };
   if (lane < 6) {
@@ -302,11 +311,17 @@ __global__ void __launch_bounds__(128) k_epilogue_ax(const Fp2<C>* rest, const A
     fx_put<C>(S_BASE, lane, x);
     fx_put<C>(S_ACC, lane, x);
   }
-  wave_sync();
+  if (AW == 2 && lane == 63) fx_mul2w_init<C>();
+  if constexpr (AW == 2) __syncthreads(); else wave_sync();
   if constexpr (C::CURVE_ID == 1) {
+    u32 epoch = 0;
+    auto mul = [&](int dst, int a, int b) {
+      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, epoch);
+      else fx_mul1<C>(dst, a, b);
+    };
     for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
-      fx_mul1<C>(S_ACC, S_ACC, S_ACC);
-      if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) fx_mul1<C>(S_ACC, S_ACC, S_BASE);
+      mul(S_ACC, S_ACC, S_ACC);
+      if ((C::COFACTOR[i >> 5] >> (i & 31)) & 1u) mul(S_ACC, S_ACC, S_BASE);
     }
   }
   if (lane < 6) {
@@ -366,19 +381,30 @@ void reduce_fx(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* ou
 }
 template void reduce_fx<BN254>(hipStream_t, const Fp2<BN254>*, size_t, int, Fp2<BN254>*);
 template void reduce_fx<BLS381>(hipStream_t, const Fp2<BLS381>*, size_t, int, Fp2<BLS381>*);
+// BGLS_LATX2=0 keeps the one-wave accumulator (round 3's block of two waves): A/B runs and the legacy-path tests
+static bool latx_two_waves() {
+  static const bool on = [] { const char* e = getenv("BGLS_LATX2"); return !(e && e[0] == '0'); }();
+  return on;
+}
+template <class C>
+static void launch_epilogue_ax(hipStream_t st, unsigned blocks, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint32_t* flags,
+                               int first_role) {
+  if (latx_two_waves()) k_epilogue_ax<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
+  else k_epilogue_ax<C, 1><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
+}
 template <class C>
 void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
                         uint32_t* flags) {
-  k_epilogue_ax<C><<<2, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, 0);
+  launch_epilogue_ax<C>(st, 2, rest, sig, gen_lines, tmp, flags, 0);
   k_epilogue_bx<C><<<1, 64, FX<C>::LDS_BYTES, st>>>(tmp, out);
 }
 // the two chains as separate launches: part 1 = the signature pair only (tmp[0..5]), part 2 = rest^h (tmp[6..11]) and the product
 template <class C>
 void cofactor_epiloguex_part(hipStream_t st, int part, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out) {
   if (part == 1) {
-    k_epilogue_ax<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, nullptr, 0);
+    launch_epilogue_ax<C>(st, 1, rest, sig, gen_lines, tmp, nullptr, 0);
   } else {
-    k_epilogue_ax<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, nullptr, 1);
+    launch_epilogue_ax<C>(st, 1, rest, sig, gen_lines, tmp, nullptr, 1);
     k_epilogue_bx<C><<<1, 64, FX<C>::LDS_BYTES, st>>>(tmp, out);
   }
 }
@@ -390,7 +416,8 @@ template <class C>
 void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at, const LineCoeffs<C>* gen_lines, Fp2<C>* out,
                  uint32_t* flags) {
   const unsigned blocks = (unsigned)(n + (sig_at >= 0 ? 1 : 0));
-  k_miller_latx<C><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
+  if (latx_two_waves()) k_miller_latx<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
+  else k_miller_latx<C, 1><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
 }
 template void miller_latx<BN254>(hipStream_t, const Aff<F1<BN254>>*, const uint8_t*, size_t, long long, const LineCoeffs<BN254>*, Fp2<BN254>*, uint32_t*);
 template void miller_latx<BLS381>(hipStream_t, const Aff<F1<BLS381>>*, const uint8_t*, size_t, long long, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint32_t*);

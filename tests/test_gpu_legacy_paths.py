@@ -62,8 +62,8 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {"BGLS_G1X": "0"}, {"BGLS_REDUCEX": "0"}, {}],
-                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "32-bit G1 scalar multiplications", "six-lane reduce passes", "defaults"])
+@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {"BGLS_G1X": "0"}, {"BGLS_REDUCEX": "0"}, {"BGLS_LATX2": "0"}, {}],
+                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "32-bit G1 scalar multiplications", "six-lane reduce passes", "one-wave accumulator in the latency Miller kernel", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
     golden = os.path.join(ROOT, "tests", "golden")
     code = CHILD % (ROOT, golden)
