@@ -31,6 +31,7 @@ struct FX {
   static constexpr int SCR_DW = 36 * ES;              // 36 lanes x one reduced Fp2 product
   static constexpr int LDS_DW = SCR + SCR_DW;
   static constexpr int LDS_BYTES = LDS_DW * 4;
+  static constexpr int LDS_BYTES_PAIR = (LDS_DW + SCR_DW) * 4;   // fx_mul_pair: a second region of half-products
   __device__ static __forceinline__ int coef(int slot, int k, int xi) { return slot * SLOT + (2 * k + xi) * ES; }
 };
 
@@ -104,7 +105,7 @@ template <class C>
 __device__ __noinline__ void fx_mul(int dst, int a, int b) {
   typedef FX<C> E;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
-  if (lane < 36) {
+  if (lane < 36 && tid < 128) {                              // waves 0 and 1 (a larger block's other waves only meet the barriers)
     const int j = lane / 6, t = lane % 6;
     int k = j - t;
     const int wrap = k < 0 ? 1 : 0;
@@ -121,6 +122,45 @@ __device__ __noinline__ void fx_mul(int dst, int a, int b) {
   if (tid < 12) {
     const int j = tid >> 1, hh = tid & 1;
     const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
+    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
+    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
+    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
+    Sx<C, SX_T> other;
+#pragma unroll
+    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
+    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
+  }
+  __syncthreads();
+}
+
+// TWO independent products side by side in a block of four waves (k_finalx): waves 0, 1 compute d0 <- a0 b0 and waves 2, 3
+// d1 <- a1 b1 (d1 < 0: nothing) between the same two barriers, i.e. in the time of one product.  Every operand is read before the
+// first barrier and every result written after it, so a destination may be any of the four operands.  The second product's
+// half-products use a second scratch region behind the first: dynamic LDS = FX::LDS_BYTES_PAIR.
+template <class C>
+__device__ __noinline__ void fx_mul_pair(int d0, int a0, int b0, int d1, int a1, int b1) {
+  typedef FX<C> E;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = w & 1, g = w >> 1;
+  const int dst = g ? d1 : d0, a = g ? a1 : a0, b = g ? b1 : b0;
+  const int scr = E::SCR + g * E::SCR_DW;
+  if (lane < 36 && dst >= 0) {
+    const int j = lane / 6, t = lane % 6;
+    int k = j - t;
+    const int wrap = k < 0 ? 1 : 0;
+    k += 6 * wrap;
+    const X2<C, SX_T> x = fx_ld2<C>(E::coef(a, t, 0));
+    const int yo = E::coef(b, k, wrap);
+    const Sx<C, SX_T> ya = fx_ld<C>(yo + (h ? E::HS : 0)), yb = fx_ld<C>(yo + (h ? 0 : E::HS));
+    const i32 sg = h ? 0 : -1;
+    const i32* const cols[2] = {ya.v, yb.v};
+    const Sx<C, SX_T> p = sx_montr<C, 2, 2 * SX_T * SX_T>(cols, [&](int q, int i) { return q == 0 ? x.c0.v[i] : (x.c1.v[i] ^ sg) - sg; });
+    fx_st<C>(scr + lane * E::ES + h * E::HS, p);
+  }
+  __syncthreads();
+  if (lane < 12 && h == 0 && dst >= 0) {
+    const int j = lane >> 1, hh = lane & 1;
+    const int o = scr + (6 * j) * E::ES + hh * E::HS;
     const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
     const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
     const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
@@ -179,14 +219,14 @@ __device__ __forceinline__ void fx_mul2w_init() {
 // dragged into the product's barriers (k_miller_latx: the accumulator on waves 0 and 1, the point steps on wave 2).  The two
 // stages of fx_mul are separated by hand-overs through two LDS words instead: wave 1 publishes "my half-products of product
 // number `epoch` are stored", wave 0 (whose lanes 0..11 add the terms up) publishes "coefficients of product `epoch` are
-// stored"; each side spins on the other's word.  Both waves call it the same number of times with their own copy of `epoch`.
+// stored"; each side spins on the other's word.  `epoch` = the number of this product, 1, 2, .. (both waves count their calls; by
+// value: a reference parameter of a function that is not inlined lives in scratch memory, and the spin loops then re-read it from there).
 template <class C>
-__device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32& epoch) {
+__device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32 epoch) {
   typedef FX<C> E;
   extern __shared__ u32 lds[];
   u32* const s_flag = lds + E::LDS_DW;                      // two words behind the slots: the caller zeroes them (fx_mul2w_init) and sizes the block's LDS for them
   const int tid = threadIdx.x, lane = tid & 63, h = (tid >> 6) & 1;
-  ++epoch;
   if (lane < 36) {
     const int j = lane / 6, t = lane % 6;
     int k = j - t;
@@ -277,19 +317,35 @@ __device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
   fx_conj<C>(sB, a);
   fx_mul<C>(dst, sB, sA);
 }
-// dst <- a^e, public exponent with its top bit at nbits-1; dst != a
+// dst <- a^e, public exponent with its top bit at nbits-1; dst != a; sq: a free slot.  Right to left on the two halves of a
+// four-wave block (fx_mul_pair): waves 0, 1 walk the squarings a^(2^i) in `sq` while waves 2, 3 multiply the ones the exponent
+// selects into dst, so the chain is nbits products long whatever the exponent's weight (left to right on one pair of waves:
+// nbits - 1 squarings AND weight - 1 products, one after the other; alt-bn128's u: 89 against 63).
 template <class C>
-__device__ __noinline__ void fx_pow(int dst, int a, const u32* e, int nbits) {
+__device__ __noinline__ void fx_pow(int dst, int a, const u32* e, int nbits, int sq) {
   typedef FX<C> E;
   const int lane = threadIdx.x;
-  if (lane < 24) {
-    const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
-    fx_st<C>(E::coef(dst, k, xi) + h * E::HS, fx_ld<C>(E::coef(a, k, xi) + h * E::HS));
-  }
-  __syncthreads();
-  for (int i = nbits - 2; i >= 0; --i) {
-    fx_mul<C>(dst, dst, dst);
-    if ((e[i >> 5] >> (i & 31)) & 1u) fx_mul<C>(dst, dst, a);
+  auto copy = [&](int d, int s) {
+    if (lane < 24) {
+      const int k = lane >> 2, xi = (lane >> 1) & 1, h = lane & 1;
+      fx_st<C>(E::coef(d, k, xi) + h * E::HS, fx_ld<C>(E::coef(s, k, xi) + h * E::HS));
+    }
+    __syncthreads();
+  };
+  copy(sq, a);
+  bool have = false;
+  for (int i = 0; i < nbits; ++i) {
+    const bool bit = (e[i >> 5] >> (i & 31)) & 1u;
+    const bool more = i + 1 < nbits;
+    if (bit && !have) {
+      copy(dst, sq);
+      have = true;
+      if (more) fx_mul_pair<C>(sq, sq, sq, -1, 0, 0);
+    } else if (more) {
+      fx_mul_pair<C>(sq, sq, sq, bit ? dst : -1, dst, sq);
+    } else if (bit) {
+      fx_mul_pair<C>(dst, dst, sq, -1, 0, 0);
+    }
   }
 }
 
@@ -304,48 +360,44 @@ __device__ __noinline__ void fx_final_exp() {
   fx_mul<C>(FE_F, FE_U, FE_T);
   if constexpr (C::CURVE_ID == 0) {
     // hard part, y0..y6 vectorial chain (pairing.hpp final_exp)
-    fx_pow<C>(FE_A, FE_F, C::U_ABS, C::U_BITS);     // ft1
-    fx_pow<C>(FE_B, FE_A, C::U_ABS, C::U_BITS);     // ft2
-    fx_pow<C>(FE_C, FE_B, C::U_ABS, C::U_BITS);     // ft3
+    fx_pow<C>(FE_A, FE_F, C::U_ABS, C::U_BITS, FE_T0);     // ft1
+    fx_pow<C>(FE_B, FE_A, C::U_ABS, C::U_BITS, FE_T0);     // ft2
+    fx_pow<C>(FE_C, FE_B, C::U_ABS, C::U_BITS, FE_T0);     // ft3
+    // (independent products of the chain run two at a time on the two halves of the block)
     fx_frob<C>(FE_Y0, FE_F, 1);
     fx_frob<C>(FE_T, FE_F, 2);
-    fx_mul<C>(FE_Y0, FE_Y0, FE_T);
+    fx_frob<C>(FE_U, FE_B, 1);
+    fx_mul_pair<C>(FE_Y0, FE_Y0, FE_T, FE_Y4, FE_A, FE_U);
     fx_frob<C>(FE_T, FE_F, 3);
-    fx_mul<C>(FE_Y0, FE_Y0, FE_T);
+    fx_frob<C>(FE_U, FE_C, 1);
+    fx_mul_pair<C>(FE_Y0, FE_Y0, FE_T, FE_Y6, FE_C, FE_U);
+    fx_conj<C>(FE_Y4, FE_Y4);
+    fx_conj<C>(FE_Y6, FE_Y6);
     fx_conj<C>(FE_Y1, FE_F);
     fx_frob<C>(FE_Y2, FE_B, 2);
     fx_frob<C>(FE_Y3, FE_A, 1);
     fx_conj<C>(FE_Y3, FE_Y3);
-    fx_frob<C>(FE_T, FE_B, 1);
-    fx_mul<C>(FE_Y4, FE_A, FE_T);
-    fx_conj<C>(FE_Y4, FE_Y4);
     fx_conj<C>(FE_Y5, FE_B);
-    fx_frob<C>(FE_T, FE_C, 1);
-    fx_mul<C>(FE_Y6, FE_C, FE_T);
-    fx_conj<C>(FE_Y6, FE_Y6);
-    fx_mul<C>(FE_T0, FE_Y6, FE_Y6);
+    fx_mul_pair<C>(FE_T0, FE_Y6, FE_Y6, FE_T1, FE_Y3, FE_Y5);
     fx_mul<C>(FE_T0, FE_T0, FE_Y4);
     fx_mul<C>(FE_T0, FE_T0, FE_Y5);
-    fx_mul<C>(FE_T1, FE_Y3, FE_Y5);
-    fx_mul<C>(FE_T1, FE_T1, FE_T0);
-    fx_mul<C>(FE_T0, FE_T0, FE_Y2);
+    fx_mul_pair<C>(FE_T1, FE_T1, FE_T0, FE_T0, FE_T0, FE_Y2);
     fx_mul<C>(FE_T1, FE_T1, FE_T1);
     fx_mul<C>(FE_T1, FE_T1, FE_T0);
     fx_mul<C>(FE_T1, FE_T1, FE_T1);
-    fx_mul<C>(FE_T0, FE_T1, FE_Y1);
-    fx_mul<C>(FE_T1, FE_T1, FE_Y0);
+    fx_mul_pair<C>(FE_T0, FE_T1, FE_Y1, FE_T1, FE_T1, FE_Y0);
     fx_mul<C>(FE_T0, FE_T0, FE_T0);
     fx_mul<C>(FE_F, FE_T1, FE_T0);
   } else {
     // (p^4 - p^2 + 1)/r = c (x + p)(x^2 + p^2 - 1) + 1,  c = (x-1)^2/3,  x < 0
-    fx_pow<C>(FE_A, FE_F, C::COFACTOR, C::COFACTOR_BITS);   // a = f^c
-    fx_pow<C>(FE_T, FE_A, C::U_ABS, C::U_BITS);
+    fx_pow<C>(FE_A, FE_F, C::COFACTOR, C::COFACTOR_BITS, FE_T0);   // a = f^c
+    fx_pow<C>(FE_T, FE_A, C::U_ABS, C::U_BITS, FE_T0);
     fx_conj<C>(FE_T, FE_T);                                 // a^x
     fx_frob<C>(FE_U, FE_A, 1);
     fx_mul<C>(FE_B, FE_T, FE_U);                            // b = a^x a^p
-    fx_pow<C>(FE_T, FE_B, C::U_ABS, C::U_BITS);
+    fx_pow<C>(FE_T, FE_B, C::U_ABS, C::U_BITS, FE_T0);
     fx_conj<C>(FE_T, FE_T);                                 // b^x
-    fx_pow<C>(FE_U, FE_T, C::U_ABS, C::U_BITS);
+    fx_pow<C>(FE_U, FE_T, C::U_ABS, C::U_BITS, FE_T0);
     fx_conj<C>(FE_U, FE_U);                                 // b^(x^2)
     fx_frob<C>(FE_T, FE_B, 2);
     fx_mul<C>(FE_U, FE_U, FE_T);

@@ -1,5 +1,6 @@
 // Final exponentiation of a verification on the carry-free limbs (finalx.hpp): product of `count` serialised partials, the
-// exponent (p^12 - 1) / r, comparison with one.  Same interface and results as k_final36 (k_tail.inc), which it replaces in
+// exponent (p^12 - 1) / r, comparison with one.  One block of FOUR waves: a product occupies two of them, and the powers by the
+// curve parameter and the hard part's chain keep two independent products in flight (fx_mul_pair).  Same interface and results as k_final36 (k_tail.inc), which it replaces in
 // Engine::finish; own translation unit (both curves).
 #include "dev_common.hpp"
 #include "finalx.hpp"
@@ -8,7 +9,7 @@
 namespace bgls {
 
 template <class C>
-__global__ void __launch_bounds__(128) k_finalx(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict,
+__global__ void __launch_bounds__(256) k_finalx(const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict,
                                                uint32_t* flags) {
   typedef FX<C> E;
   const int lane = threadIdx.x;
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(128) k_finalx(const uint8_t* partials, size_t 
 namespace kl {
 template <class C>
 void finalx(hipStream_t st, const uint8_t* partials, size_t count, int do_final_exp, uint8_t* gt_out, uint32_t* verdict, uint32_t* flags) {
-  k_finalx<C><<<1, 128, FX<C>::LDS_BYTES, st>>>(partials, count, do_final_exp, gt_out, verdict, flags);
+  k_finalx<C><<<1, 256, FX<C>::LDS_BYTES_PAIR, st>>>(partials, count, do_final_exp, gt_out, verdict, flags);
 }
 template void finalx<BN254>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, uint32_t*, uint32_t*);
 template void finalx<BLS381>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, uint32_t*, uint32_t*);

@@ -12,10 +12,24 @@
 #include "pairing.hpp"
 #include "finalx.hpp"
 #include "rx_jacpair.hpp"
+#include "constants_latx_gen.hpp"
 #include "launch.hpp"
 #include "launch_tail.hpp"
 
 namespace bgls {
+
+#ifdef LATX_DBG
+// development only (tools/exp/latx_steps.sh): 100 MHz time stamps of the hand-overs, [block 0 | the signature block][producer before /
+// after the barrier, consumer before / after][event]
+__device__ unsigned long long g_latx_t[2][4][160];
+__device__ unsigned long long g_latx_c[2][4][160];    // the same events on the shader clock (s_memtime)
+#define LATX_T(kind, idx) do { if ((threadIdx.x & 63) == 0 && (idx) < 160) { g_latx_t[is_sig ? 1 : 0][kind][idx] = wall_clock64(); g_latx_c[is_sig ? 1 : 0][kind][idx] = clock64(); } } while (0)
+__device__ unsigned long long g_latx_r[12][160];      // shader clock inside the general block's point steps
+#define LATX_R(k) do { if (!is_sig && (threadIdx.x & 63) == 0 && step < 160) g_latx_r[k][step] = clock64(); } while (0)
+#else
+#define LATX_T(kind, idx) do { } while (0)
+#define LATX_R(k) do { } while (0)
+#endif
 
 // one block = one pairing: pair `blk` of the batch (blk == n with sig_at >= 0: the (-sigma, g2) pair); the six w-basis coefficients
 // of the Miller value go to out[blk * 6 ..]
@@ -26,9 +40,12 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
                                                   const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, size_t blk) {
   typedef FX<C> E;
   constexpr int ES = E::ES, HS = E::HS, N = C::RX_NL;
-  enum { S_F = 0, S_L0 = 2, S_L1 = 3, S_PA = 4 };                      // accumulator, two line buffers, producer scratch (slots 4, 5: 24 Fp2)
-  enum { PX = 0, PY, PZ, PQX, PQY, PB, PC, PS, PJ, PM, PE, PZN, PXN, PG, PE2, PT0, PT1, PU0, PU1, PD, PGG, PV0, PV1, PN };
-  static_assert(PN <= 24, "producer scratch fits two slots");
+  enum { S_F = 0, S_L0 = 2, S_L1 = 3, S_PA = 4 };                      // accumulator, two line buffers, producer scratch (slots 4..7: 48 Fp2)
+  enum { PX = 0, PY, PZ, PZT, PZU, PQX, PQY, PT0, PT1,                // the point (Zt = beta Z, Zu = xi beta Z, see the steps), Q, (xP, 0), (yP, 0)
+         PB, PC, PS, PJ, PM, PE, PW, PV, PG, PE2,                       // doubling: round 1 (consecutive, in product order), round 2
+         PU0, PU1, PD, PC2, PLT, PZL, PXL, PZH, PLY, PZTL, PV0, PV1, PZUL,   // addition: round 1, round 2 (consecutive, in product order)
+         PN0, PNEND = PN0 + 5 };                                        // addition: round 3
+  static_assert(PNEND <= 48, "producer scratch fits four slots");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool is_sig = sig_at >= 0 && blk == n;
   const int pbase = E::coef(S_PA, 0, 0);
@@ -40,18 +57,12 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
   auto ST = [&](int e, const Sx<C, SX_T>& v, bool active) {
     if (active) fx_st<C>(pbase + e * ES + (odd ? HS : 0), v);
   };
-  // own half of line coefficient `which` into line buffer `buf`, plain and xi multiple:
+  // own half of line coefficient `which` into line buffer `buf`.  The line is the product's FIRST factor (fx_mul*: term t of
+  // coefficient j is a_t b_(j-t), only b is read as a xi multiple where the index wraps), so no xi multiple of it is formed.
   // D-type  k = 0: c0 yP, 1: c1 xP, 3: c2;   M-type  0: c2, 2: c1 xP, 3: c0 yP
   auto put_line = [&](int buf, int which, const Sx<C, SX_T>& v, bool active) {
     const int k = which == 0 ? (C::TWIST_D ? 0 : 3) : which == 1 ? (C::TWIST_D ? 1 : 2) : (C::TWIST_D ? 3 : 0);
-    Sx<C, SX_T> other;
-#pragma unroll
-    for (int i = 0; i < N; ++i) other.v[i] = pair_swap1(v.v[i]);
-    const Sx<C, SX_T> z = fx_mulxi_half<C>(v, other, odd);
-    if (active) {
-      fx_st<C>(E::coef(buf ? S_L1 : S_L0, k, 0) + (odd ? HS : 0), v);
-      fx_st<C>(E::coef(buf ? S_L1 : S_L0, k, 1) + (odd ? HS : 0), z);
-    }
+    if (active) fx_st<C>(E::coef(buf ? S_L1 : S_L0, k, 0) + (odd ? HS : 0), v);
   };
   if (wave == 0) {
     if (AW == 2 && lane == 63) fx_mul2w_init<C>();
@@ -85,6 +96,8 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
     }
     const Sx<C, SX_T> zero = ux_to_sx<C>(ux_zero<C>());
     ST(PX, Q.x, true); ST(PY, Q.y, true); ST(PZ, pair_one<C>(odd), true);
+    ST(PZT, sx_const<C>(odd ? LatxK<C>::BETA_IM : LatxK<C>::BETA_RE), true);
+    ST(PZU, sx_const<C>(odd ? LatxK<C>::XIBETA_IM : LatxK<C>::XIBETA_RE), true);
     ST(PQX, Q.x, true); ST(PQY, Q.y, true);
     ST(PT0, odd ? zero : ux_to_sx<C>(to_ux<C>(P.x)), true);             // (xP, 0), (yP, 0): Fp2 operands of the scaling products
     ST(PT1, odd ? zero : ux_to_sx<C>(to_ux<C>(P.y)), true);
@@ -103,8 +116,10 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
     }
     int buf = 0, step = 0;
     auto publish = [&]() {                                    // line of this step is in the buffer: hand it over
+      LATX_T(0, step);
       ++step;
       __syncthreads();
+      LATX_T(1, step - 1);
       buf ^= 1;
     };
     auto F = [&](const auto& v) { return sx_normf<C>(v); };                      // any bound below 128 -> almost tight
@@ -119,90 +134,102 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
       wave_sync();
       publish();
     };
+    // The point steps are those of rx_pair.hpp / pairing.hpp rearranged for a LONE wave, where what counts is the length of the
+    // instruction stream (a round of independent products costs the same whether 3 or 12 lane pairs work in it, and every lane
+    // executes whatever any lane needs): the same values mod p, hence the same Miller value.
+    //  - the doubling step's E = 3 b' Z^2 was a product by a constant in a round of its own between Z^2 and the products that
+    //    need E.  3 b' = xi beta^2 on both curves (constants_latx_gen.hpp), so with Zt = beta Z and Zu = xi beta Z carried beside
+    //    Z, E = Zu Zt is one of the products of the first round; Zt' = B (2 Y Zt), Zu' = B (2 Y Zu).  Two rounds instead of 3.
+    //  - the addition step's X', Y', Z' are written out as sums of products of values two rounds deep
+    //    (X' = D (D - 2 X la) + (Z la) C, Y' = (la th)(3 X la - D) - (Z th) C - D (la Y), Z' = (Z la) D, with D = la^2,
+    //    C = th^2), each product on its own lane pair and the sums formed where they are read.  Three rounds instead of 4.
+    //  - the factors of a round's products are small integer combinations of scratch entries (B - 3 E, (B + 3 E) / 2, S - B - C,
+    //    ..): instead of every lane forming every combination and selecting its own, a lane forms ONE combination
+    //    c0 e0 + c1 e1 + c2 e2 with its own entries and coefficients (lin3).
+    // own half of c0 [e0] + c1 [e1] + c2 [e2], halved mod p when `half` (sx_half); |c0| + |c1| + |c2| <= 5
+    auto lin3 = [&](int e0, int c0, int e1, int c1, int e2, int c2, bool half) {
+      const Sx<C, SX_T> v0 = LD(e0), v1 = LD(e1), v2 = LD(e2);
+      i32 t[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) t[i] = c0 * v0.v[i] + c1 * v1.v[i] + c2 * v2.v[i];
+      const i32 hm = half ? -(t[0] & 1) : 0, sh = half ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) t[i] += (i32)C::RX_P[i] & hm;
+      Sx<C, 96> r;
+#pragma unroll
+      for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> sh) + (i + 1 < N ? (t[i + 1] & sh) << 27 : 0);
+      return r;
+    };
     auto dbl_step = [&]() {
-      const Sx<C, SX_T> X = LD(PX), Y = LD(PY), Z = LD(PZ);
-      {   // round 1: B = Y^2, C = Z^2, S = (Y+Z)^2, J = X^2, M = X Y
-        const Sx<C, SX_F> yz = F(sx_add<C>(Y, Z));
-        const Sx<C, SX_F> a = q == 0 ? T(Y) : q == 1 ? T(Z) : q == 2 ? yz : T(X);
-        const Sx<C, SX_F> b = q == 3 ? T(X) : q == 4 ? T(Y) : a;
-        const int dst = q == 0 ? PB : q == 1 ? PC : q == 2 ? PS : q == 3 ? PJ : PM;
-        ST(dst, pair_mul<C>(a, b, odd), q < 5);
-        wave_sync();
-      }
-      const Sx<C, SX_T> B = LD(PB), Cc = LD(PC);
-      const Sx<C, SX_F> H = F(sx_sub<C>(LD(PS), sx_add<C>(B, Cc)));
-      {   // round 2: E = 3b' C, ZN = B H, line c1 xP = 3J xP, line c0 yP = -H yP
-        const Sx<C, SX_F> j3 = F(sx_mulc<3, C>(LD(PJ)));
-        const Sx<C, SX_F> a = q == 0 ? T(sx_const<C>(odd ? C::RX_B2X3_IM : C::RX_B2X3_RE)) : q == 1 ? T(B) : q == 2 ? j3 : sx_neg<C>(H);
-        const Sx<C, SX_F> b = q == 0 ? T(Cc) : q == 1 ? H : q == 2 ? T(xP) : T(yP);
+      LATX_R(0);
+      {   // round 1: B = Y^2, C = Z^2, S = (Y+Z)^2, J = X^2, M = X Y, E = Zu Zt, W = Y Zt, V = Y Zu
+        const int ia = q == 0 ? PY : q == 1 ? PZ : q == 2 ? PY : q == 3 ? PX : q == 4 ? PX : q == 5 ? PZU : PY;
+        const int ib = q == 2 ? PZ : q == 4 ? PY : (q == 5 || q == 6) ? PZT : q == 7 ? PZU : ia;
+        const Sx<C, SX_T> A1 = LD(ia), A2 = LD(ib);
+        const Sx<C, SX_F> sum = F(sx_add<C>(A1, A2));
+        const Sx<C, SX_F> a = sx_select<C>(q == 2, sum, T(A1)), b = sx_select<C>(q == 2, sum, T(A2));
+        LATX_R(1);
         const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
-        ST(PE, r, q == 0);
-        ST(PZN, r, q == 1);
-        put_line(buf, q == 2 ? 1 : 0, r, q == 2 || q == 3);
+        LATX_R(2);
+        ST(PB + q, r, q < 8);                                 // PB, PC, PS, PJ, PM, PE, PW, PV are consecutive
         wave_sync();
       }
-      const Sx<C, SX_T> Ev = LD(PE);
-      const Sx<C, SX_F> Fv = F(sx_mulc<3, C>(Ev));
-      {   // round 3: XN = (M/2)(B - Fv), G^2 with G = (B + Fv)/2, E^2
-        const Sx<C, SX_F> hm = F(sx_half<C>(q == 0 ? T(LD(PM)) : F(sx_add<C>(B, Fv))));
-        const Sx<C, SX_F> a = q == 2 ? T(Ev) : hm;
-        const Sx<C, SX_F> b = q == 0 ? F(sx_sub<C>(B, Fv)) : a;
-        const int dst = q == 0 ? PXN : q == 1 ? PG : PE2;
-        ST(dst, pair_mul<C>(a, b, odd), q < 3);
+      LATX_R(3);
+      {   // round 2: Z' = B H, Zt' = B 2W, Zu' = B 2V, line c1 xP = 3J xP, line c0 yP = -H yP   (H = S - B - C = 2 Y Z),
+          //          X' = (M/2)(B - 3E), G^2 with G = (B + 3E)/2, E^2
+        const bool one = q < 3 || q == 5 || q == 7;           // a is one entry as it stands
+        const int a0 = q < 3 ? PB : q == 3 ? PJ : q == 4 ? PS : q == 5 ? PM : q == 6 ? PB : PE;
+        const Sx<C, SX_F> a = F(lin3(a0, q == 3 ? 3 : q == 4 ? -1 : 1, q == 4 ? PB : PE, one ? 0 : q == 3 ? 0 : q == 4 ? 1 : 3, PC, q == 4 ? 1 : 0,
+                                     q == 5 || q == 6));
+        const int b0 = q == 0 ? PS : q == 1 ? PW : q == 2 ? PV : q == 3 ? PT0 : q == 4 ? PT1 : PB;
+        const Sx<C, SX_F> bb = F(lin3(b0, (q == 1 || q == 2) ? 2 : 1, q == 0 ? PB : PE, q == 0 ? -1 : q == 5 ? -3 : 0, PC, q == 0 ? -1 : 0, false));
+        const Sx<C, SX_F> b = sx_select<C>(q >= 6, a, bb);
+        LATX_R(4);
+        const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
+        LATX_R(5);
+        // nothing in this round reads X, Z, Zt, Zu: the new coordinates go straight to their places
+        ST(q == 0 ? PZ : q == 1 ? PZT : q == 2 ? PZU : q == 5 ? PX : q == 6 ? PG : PE2, r, q < 3 || (q >= 5 && q < 8));
+        put_line(buf, q == 3 ? 1 : 0, r, q == 3 || q == 4);
         wave_sync();
       }
-      {
-        const Sx<C, SX_T> xn = LD(PXN), zn = LD(PZN);
-        const Sx<C, SX_T> yn = sx_norm<C>(sx_sub<C>(LD(PG), sx_mulc<3, C>(LD(PE2))));
-        const Sx<C, SX_T> c2 = sx_norm<C>(sx_sub<C>(Ev, B));
-        wave_sync();
-        ST(PX, xn, q == 0); ST(PZ, zn, q == 0); ST(PY, yn, q == 0);
-        put_line(buf, 2, c2, q == 1);
+      LATX_R(6);
+      {   // Y' = G^2 - 3 E^2, line c2 = E - B
+        const Sx<C, SX_T> v = sx_norm<C>(lin3(q == 0 ? PG : PE, 1, q == 0 ? PE2 : PB, q == 0 ? -3 : -1, PB, 0, false));
+        ST(PY, v, q == 0);
+        put_line(buf, 2, v, q == 1);
       }
       wave_sync();
+      LATX_R(7);
       publish();
     };
     auto add_step = [&](const Sx<C, SX_T>& xq, const Sx<C, SX_T>& yq) {
-      const Sx<C, SX_T> X = LD(PX), Y = LD(PY), Z = LD(PZ);
       {   // round 1: yq Z, xq Z
-        ST(q == 0 ? PU0 : PU1, pair_mul<C>(q == 0 ? yq : xq, Z, odd), q < 2);
+        ST(q == 0 ? PU0 : PU1, pair_mul<C>(q == 0 ? yq : xq, LD(PZ), odd), q < 2);
         wave_sync();
       }
-      const Sx<C, SX_F> th = F(sx_sub<C>(Y, LD(PU0))), la = F(sx_sub<C>(X, LD(PU1)));
-      {   // round 2: C = th^2, D = la^2, th xq, la yq, line c0 yP = la yP
-        const Sx<C, SX_F> a = (q == 0 || q == 2) ? th : la;
-        const Sx<C, SX_F> b = q == 0 ? th : q == 1 ? la : q == 2 ? T(xq) : q == 3 ? T(yq) : T(yP);
+      const Sx<C, SX_F> th = F(sx_sub<C>(LD(PY), LD(PU0))), la = F(sx_sub<C>(LD(PX), LD(PU1)));
+      {   // round 2: D = la^2, C = th^2, la th, la Z, la X, th Z, la Y, la Zt, th xq, la yq, la Zu, line c0 yP = la yP, line c1 xP = -th xP
+        const Sx<C, SX_F> a = (q == 1 || q == 5 || q == 8) ? th : q == 12 ? sx_neg<C>(th) : la;
+        const int ib = q == 3 ? PZ : q == 4 ? PX : q == 5 ? PZ : q == 6 ? PY : q == 7 ? PZT : q == 10 ? PZU : q == 11 ? PT1 : PT0;
+        const Sx<C, SX_F> b = q == 0 ? la : q < 3 ? th : q == 8 ? T(xq) : q == 9 ? T(yq) : T(LD(ib));
         const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
-        const int dst = q == 0 ? PC : q == 1 ? PD : q == 2 ? PV0 : PV1;
-        ST(dst, r, q < 4);
-        put_line(buf, 0, r, q == 4);
+        ST(PD + q, r, q < 11);                                // PD, PC2, PLT, PZL, PXL, PZH, PLY, PZTL, PV0, PV1, PZUL are consecutive
+        put_line(buf, q == 11 ? 0 : 1, r, q == 11 || q == 12);
         wave_sync();
       }
-      const Sx<C, SX_T> D = LD(PD);
-      {   // round 3: E = la D, Fv = Z C, G = X D, line c1 xP = -th xP
-        const Sx<C, SX_F> a = q == 0 ? la : q == 1 ? T(Z) : q == 2 ? T(X) : sx_neg<C>(th);
-        const Sx<C, SX_T> b = q == 1 ? LD(PC) : q == 3 ? xP : D;
-        const Sx<C, SX_T> r = pair_mul<C>(a, b, odd);
-        const int dst = q == 0 ? PE : q == 1 ? PS : PGG;
-        ST(dst, r, q < 3);
-        put_line(buf, 1, r, q == 3);
-        put_line(buf, 2, sx_norm<C>(sx_sub<C>(LD(PV0), LD(PV1))), q == 4);
+      {   // round 3: D (D - 2 XL), ZL C, LT (3 XL - D), ZH C, D LY, Z' = ZL D, Zt' = ZTL D, Zu' = ZUL D
+        const int ia = q == 0 ? PD : q == 1 ? PZL : q == 2 ? PLT : q == 3 ? PZH : q == 4 ? PD : q == 5 ? PZL : q == 6 ? PZTL : PZUL;
+        const int b0 = (q == 1 || q == 3) ? PC2 : q == 2 ? PXL : q == 4 ? PLY : PD;
+        const Sx<C, SX_F> b = F(lin3(b0, q == 2 ? 3 : 1, q == 0 ? PXL : PD, q == 0 ? -2 : q == 2 ? -1 : 0, PD, 0, false));
+        const Sx<C, SX_T> r = pair_mul<C>(T(LD(ia)), b, odd);
+        ST(q < 5 ? PN0 + q : q == 5 ? PZ : q == 6 ? PZT : PZU, r, q < 8);
         wave_sync();
       }
-      const Sx<C, SX_T> Ev = LD(PE), G = LD(PGG);
-      const Sx<C, SX_F> Hh = F(sx_sub<C>(sx_add<C>(Ev, LD(PS)), sx_mulc<2, C>(G)));
-      {   // round 4: XN = la Hh, ZN = Z E, th (G - Hh), E Y
-        const Sx<C, SX_F> a = q == 0 ? la : q == 1 ? T(Z) : q == 2 ? th : T(Ev);
-        const Sx<C, SX_F> b = q == 0 ? Hh : q == 1 ? T(Ev) : q == 2 ? F(sx_sub<C>(G, Hh)) : T(Y);
-        const int dst = q == 0 ? PXN : q == 1 ? PZN : q == 2 ? PU0 : PU1;
-        ST(dst, pair_mul<C>(a, b, odd), q < 4);
-        wave_sync();
-      }
-      {
-        const Sx<C, SX_T> xn = LD(PXN), zn = LD(PZN);
-        const Sx<C, SX_T> yn = sx_norm<C>(sx_sub<C>(LD(PU0), LD(PU1)));
-        wave_sync();
-        ST(PX, xn, q == 0); ST(PZ, zn, q == 0); ST(PY, yn, q == 0);
+      {   // X' = N0 + N1, Y' = N2 - N3 - N4, line c2 = th xq - la yq
+        const Sx<C, SX_T> v = sx_norm<C>(lin3(q == 0 ? PN0 : q == 1 ? PN0 + 2 : PV0, 1, q == 0 ? PN0 + 1 : q == 1 ? PN0 + 3 : PV1, q == 0 ? 1 : -1,
+                                              PN0 + 4, q == 1 ? -1 : 0, false));
+        ST(q == 0 ? PX : PY, v, q < 2);
+        put_line(buf, 2, v, q == 2);
       }
       wave_sync();
       publish();
@@ -242,12 +269,17 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
     int buf = 0;
     u32 epoch = 0;
     auto mul = [&](int dst, int a, int b) {
-      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, epoch);
+      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, ++epoch);
       else fx_mul1<C>(dst, a, b);
     };
+    int nfold = 0;
+    (void)nfold;
     auto fold = [&]() {
+      if (wave == 0) LATX_T(2, nfold);
       __syncthreads();                                        // the line of this step is complete
-      if (valid) mul(S_F, S_F, buf ? S_L1 : S_L0);
+      if (wave == 0) LATX_T(3, nfold);
+      ++nfold;
+      if (valid) mul(S_F, buf ? S_L1 : S_L0, S_F);
       buf ^= 1;
     };
 #pragma unroll 1
@@ -316,7 +348,7 @@ __global__ void __launch_bounds__(64 * (AW + 1)) k_epilogue_ax(const Fp2<C>* res
   if constexpr (C::CURVE_ID == 1) {
     u32 epoch = 0;
     auto mul = [&](int dst, int a, int b) {
-      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, epoch);
+      if constexpr (AW == 2) fx_mul2w<C>(dst, a, b, ++epoch);
       else fx_mul1<C>(dst, a, b);
     };
     for (int i = C::COFACTOR_BITS - 2; i >= 0; --i) {
@@ -423,3 +455,10 @@ template void miller_latx<BN254>(hipStream_t, const Aff<F1<BN254>>*, const uint8
 template void miller_latx<BLS381>(hipStream_t, const Aff<F1<BLS381>>*, const uint8_t*, size_t, long long, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint32_t*);
 }  // namespace kl
 }  // namespace bgls
+#ifdef LATX_DBG
+extern "C" int bgls_dbg_latx_dump(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out + 4 * 4 * 160, HIP_SYMBOL(bgls::g_latx_r), sizeof(bgls::g_latx_r));
+  (void)hipMemcpyFromSymbol(out + 2 * 4 * 160, HIP_SYMBOL(bgls::g_latx_c), sizeof(bgls::g_latx_c));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bgls::g_latx_t), sizeof(bgls::g_latx_t));
+}
+#endif

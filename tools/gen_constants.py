@@ -312,6 +312,37 @@ def main():
         f.write(txt)
     print("wrote", os.path.normpath(OUT), len(txt), "bytes")
 
+    # ---- constants of the latency Miller kernel alone (k_millerlatx.hip), in a header of their own so that a change here does
+    # not rebuild every unit: beta with 3 b' = xi beta^2 (b' = the twist's constant) and xi beta, R' form of rx.hpp.  The kernel
+    # carries Zt = beta Z and Zu = xi beta Z beside Z, so that the doubling step's E = 3 b' Z^2 = Zu Zt is one of the products of
+    # the FIRST round instead of a product by a constant in a round of its own.
+    def sqrt_fp(a, p):
+        assert p % 4 == 3
+        s = pow(a, (p + 1) // 4, p)
+        return s if s * s % p == a % p else None
+    def lat(cname, p, N, xi, b2x3, beta):
+        f2 = F2(p)
+        assert f2.mul(xi, f2.mul(beta, beta)) == (b2x3[0] % p, b2x3[1] % p), cname
+        Rp = 1 << (28 * N)
+        lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) for i in range(N)]
+        o = "template <>\nstruct LatxK<%s> {\n" % cname
+        o += arr("BETA_RE", lim(beta[0] * Rp % p)) + arr("BETA_IM", lim(beta[1] * Rp % p))
+        bx = f2.mul(xi, beta)
+        o += arr("XIBETA_RE", lim(bx[0] * Rp % p)) + arr("XIBETA_IM", lim(bx[1] * Rp % p))
+        return o + "};\n"
+    xinv = f2bn.inv((9, 1))
+    beta_bn = (3 * xinv[0] % p_bn, 3 * xinv[1] % p_bn)                       # 9 / xi = xi (3 / xi)^2
+    s12 = sqrt_fp(12, p_bls)
+    beta_bls = (s12, 0) if s12 is not None else (0, sqrt_fp(-12 % p_bls, p_bls))      # 12 xi = xi sqrt(12)^2
+    t2 = "// GENERATED by tools/gen_constants.py -- do not edit.\n#pragma once\n#include \"constants_gen.hpp\"\n\nnamespace bgls {\n\n"
+    t2 += "template <class C>\nstruct LatxK;\n"
+    t2 += lat("BN254", p_bn, 10, (9, 1), bn_b2x3, beta_bn) + lat("BLS381", p_bls, 14, (1, 1), (12, 12), beta_bls)
+    t2 += "}  // namespace bgls\n"
+    out2 = os.path.join(os.path.dirname(OUT), "constants_latx_gen.hpp")
+    with open(out2, "w") as f:
+        f.write(t2)
+    print("wrote", os.path.normpath(out2), len(t2), "bytes")
+
 
 if __name__ == "__main__":
     main()
