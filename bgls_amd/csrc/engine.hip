@@ -775,7 +775,7 @@ struct Engine {
         // the whole tree in ONE launch: a wave per pair of leaves climbs by tickets (k_sumtree.hip); the root's wave writes the
         // Jacobian record and, if asked, the affine bytes
         void *store, *tick;
-        if ((rc = c.get(WS_TREE_S, (cnt + 64) * JB, &store))) return rc;
+        if ((rc = c.get(WS_TREE_S, std::max((cnt + 64) * JB, kl::sum_tree_store_bytes<C>(cnt)), &store))) return rc;
         if ((rc = c.get(WS_TREE_T, (size_t)(8192 + 64) * 4, &tick))) return rc;
         if (tick != c.tick_ptr || c.ws[WS_TREE_T].second != c.tick_cap) {
           HIPCHK(hipMemsetAsync(tick, 0, c.ws[WS_TREE_T].second, st));

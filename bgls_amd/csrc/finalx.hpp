@@ -17,6 +17,7 @@
 #pragma once
 #include "finalexp.hpp"
 #include "rx_jac.hpp"
+#include "constants_latx_gen.hpp"
 
 namespace bgls {
 
@@ -286,16 +287,16 @@ __device__ __noinline__ void fx_frob(int dst, int a, int kk) {      // a^(p^kk),
     X2<C, SX_T> v = fx_ld2<C>(E::coef(a, lane, 0));
     if (kk & 1) v.c1 = sx_neg<C>(v.c1);
     if (lane != 0) {
-      const Fp2<C> g = gamma_const<C>(kk, lane);
-      const X2<C, SX_T> gx = {sx_from_mont<C>(g.c0), sx_from_mont<C>(g.c1)};
+      const u32* g = LatxK<C>::FROB_GAMMA + ((kk - 1) * 6 + lane) * 2 * C::RX_NL;      // gamma_kk[lane] in this form
+      const X2<C, SX_T> gx = {sx_const<C>(g), sx_const<C>(g + C::RX_NL)};
       v = x2_mul<C>(v, gx);
     }
     fx_put<C>(dst, lane, v);
   }
   __syncthreads();
 }
-// dst <- a^-1 through norms (as finalexp.hpp fe_inv): four cooperative products, two Frobenius maps and ONE Fp2 inversion, taken
-// in the library's 32-bit form (binary Euclid) on the lanes that need it.  Uses FE_X, FE_Y5, FE_Y6 as scratch.
+// dst <- a^-1 through norms (as finalexp.hpp fe_inv): four cooperative products, two Frobenius maps and ONE Fp inversion, taken
+// in the library's 32-bit form (fp_inv) on the lanes that need it.  Uses FE_X, FE_Y5, FE_Y6 as scratch.
 template <class C>
 __device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
   typedef FX<C> E;
@@ -307,9 +308,12 @@ __device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
   fx_mul<C>(sA, sA, sB);                  // M = N^(p^2) N^(p^4)
   fx_mul<C>(sB, sN, sA);                  // Norm(N) in Fp2: only coefficient 0
   if (lane < 6) {
+    // 1 / d = conj(d) / (d0^2 + d1^2): the norm and the two products on these limbs, ONE value through the 32-bit form and back
     const X2<C, SX_T> d = fx_ld2<C>(E::coef(sB, 0, 0));
-    const Fp2<C> dinv = f2_inv<C>(Fp2<C>{sx_to_mont<C>(d.c0), sx_to_mont<C>(d.c1)});
-    const X2<C, SX_T> di = {sx_from_mont<C>(dinv.c0), sx_from_mont<C>(dinv.c1)};
+    const X2<C, SX_T> dc = {d.c0, sx_norm<C>(sx_neg<C>(d.c1))};
+    const X2<C, SX_T> nn = x2_mul<C>(d, dc);
+    const Sx<C, SX_T> ni = sx_from_mont<C>(fp_inv<C>(sx_to_mont<C>(nn.c0)));
+    const X2<C, SX_T> di = x2_mul<C>(dc, X2<C, SX_T>{ni, ux_to_sx<C>(ux_zero<C>())});
     const X2<C, SX_T> m = fx_ld2<C>(E::coef(sA, lane, 0));
     fx_put<C>(sA, lane, x2_mul<C>(m, di));                         // N^-1 (every lane touches its own coefficient only)
   }

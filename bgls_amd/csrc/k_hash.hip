@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1
     for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
     const Fp<C> xc = fp_to_mont<C>(h);
     const Fp<C> yc = fp_add<C>(fp_mul<C>(fp_sqr<C>(xc), xc), fp_load<C>(C::B));
-    bool ok = fp_jacobi<C>(yc) >= 0 && c < 256u && !done;
+    // every lane takes the square root of its own candidate and squares it back instead of asking for the Legendre symbol
+    // first: the sixteen exponentiations are one instruction stream, and the accepted lane has its y already
+    const Fp<C> rc = rx_sqrt_pow<C, false>(yc, tab);
+    bool ok = fp_eq<C>(fp_sqr<C>(rc), yc) && c < 256u && !done;
     if (first) {
       sign = __shfl(d[7] & 1u, grp * 16 + 15);          // last digest byte of the 0xFF-prefixed hash, low bit
       if (sub == 15) ok = false;                         // counter 255 is tried in its turn, not in round 0
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1
     if (!done && field) {
       mine = sub == (int)__builtin_ctz(field);
       done = true;
-      if (mine) { x = xc; y2 = yc; }
+      if (mine) { x = xc; y2 = rc; }
     }
     base = first ? 15u : base + 16u;
     first = false;
@@ -178,11 +181,7 @@ __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1
     }
     return;
   }
-  if (mine) {
-    Fp<C> r = rx_sqrt_pow<C, false>(y2, tab);
-    if (sign) r = fp_neg<C>(r);
-    out[i] = {x, r, false};
-  }
+  if (mine) out[i] = {x, sign ? fp_neg<C>(y2) : y2, false};
 }
 
 // BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,

@@ -203,10 +203,12 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
       publish();
     };
     auto add_step = [&](const Sx<C, SX_T>& xq, const Sx<C, SX_T>& yq) {
+      LATX_R(0);
       {   // round 1: yq Z, xq Z
         ST(q == 0 ? PU0 : PU1, pair_mul<C>(q == 0 ? yq : xq, LD(PZ), odd), q < 2);
         wave_sync();
       }
+      LATX_R(1);
       const Sx<C, SX_F> th = F(sx_sub<C>(LD(PY), LD(PU0))), la = F(sx_sub<C>(LD(PX), LD(PU1)));
       {   // round 2: D = la^2, C = th^2, la th, la Z, la X, th Z, la Y, la Zt, th xq, la yq, la Zu, line c0 yP = la yP, line c1 xP = -th xP
         const Sx<C, SX_F> a = (q == 1 || q == 5 || q == 8) ? th : q == 12 ? sx_neg<C>(th) : la;
@@ -217,6 +219,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
         put_line(buf, q == 11 ? 0 : 1, r, q == 11 || q == 12);
         wave_sync();
       }
+      LATX_R(2);
       {   // round 3: D (D - 2 XL), ZL C, LT (3 XL - D), ZH C, D LY, Z' = ZL D, Zt' = ZTL D, Zu' = ZUL D
         const int ia = q == 0 ? PD : q == 1 ? PZL : q == 2 ? PLT : q == 3 ? PZH : q == 4 ? PD : q == 5 ? PZL : q == 6 ? PZTL : PZUL;
         const int b0 = (q == 1 || q == 3) ? PC2 : q == 2 ? PXL : q == 4 ? PLY : PD;
@@ -225,6 +228,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
         ST(q < 5 ? PN0 + q : q == 5 ? PZ : q == 6 ? PZT : PZU, r, q < 8);
         wave_sync();
       }
+      LATX_R(3);
       {   // X' = N0 + N1, Y' = N2 - N3 - N4, line c2 = th xq - la yq
         const Sx<C, SX_T> v = sx_norm<C>(lin3(q == 0 ? PN0 : q == 1 ? PN0 + 2 : PV0, 1, q == 0 ? PN0 + 1 : q == 1 ? PN0 + 3 : PV1, q == 0 ? 1 : -1,
                                               PN0 + 4, q == 1 ? -1 : 0, false));
@@ -232,6 +236,7 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
         put_line(buf, 2, v, q == 2);
       }
       wave_sync();
+      LATX_R(4);
       publish();
     };
     const Sx<C, SX_T> qx = LD(PQX), qy = LD(PQY);

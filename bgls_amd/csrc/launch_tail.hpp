@@ -6,9 +6,10 @@ namespace bgls {
 namespace kl {
 
 // The tree above a key sum's main pass in ONE launch (k_sumtree.hip): cnt Jacobian partial sums (G2) -> their sum, as affine
-// wire bytes (d_bytes != nullptr) and / or as one Jacobian record (d_jac != nullptr).  store: cnt Jacobian records of scratch,
+// wire bytes (d_bytes != nullptr) and / or as one Jacobian record (d_jac != nullptr).  store: sum_tree_store_bytes(cnt) of scratch,
 // tickets: cnt words, zero on entry and zero again on exit.
 template <class C> void sum_tree(hipStream_t st, const void* in, size_t cnt, void* store, uint32_t* tickets, uint8_t* d_bytes, void* d_jac);
+template <class C> size_t sum_tree_store_bytes(size_t cnt);
 
 // ---- k_g1x.hip: scalar multiplications on G1, one point per lane on the carry-free limbs (rx_jac1.hpp)
 template <class C> void scale_aff_g1x(hipStream_t st, const Aff<F1<C>>* g1_pts, const uint8_t* scalars, size_t n, uint8_t* out);

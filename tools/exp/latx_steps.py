@@ -42,5 +42,7 @@ for blk in range(2):
 r = [[buf[2560 + k * 160 + i] for i in range(160)] for k in range(12)]
 print("doubling steps of the general block, shader clocks between the stamps 0..7 (loads | product 1 | store+sync | middle | product 2 | store+line+sync | tail):")
 for i in range(160):
-    if r[0][i] and r[7][i] > r[0][i]:
+    if r[0][i] and r[4][i] > r[0][i] and not (r[7][i] > r[0][i] and r[5][i] > r[4][i]):
+        print("  add %3d " % i + " ".join("%6d" % (r[k + 1][i] - r[k][i]) for k in range(4)), " total", r[4][i] - r[0][i])
+    elif r[0][i] and r[7][i] > r[0][i]:
         print("  %3d " % i + " ".join("%6d" % (r[k + 1][i] - r[k][i]) for k in range(7)), " total", r[7][i] - r[0][i])

@@ -329,6 +329,16 @@ def main():
         o += arr("BETA_RE", lim(beta[0] * Rp % p)) + arr("BETA_IM", lim(beta[1] * Rp % p))
         bx = f2.mul(xi, beta)
         o += arr("XIBETA_RE", lim(bx[0] * Rp % p)) + arr("XIBETA_IM", lim(bx[1] * Rp % p))
+        # the Frobenius constants of finalx.hpp (fx_frob) in this form: gamma_j[k] = xi^(k (p^j - 1)/6), [j-1][k][re, im][N] -- the
+        # same values as GAMMA of constants_gen.hpp, whose 32-bit Montgomery form cost two conversions per coefficient and map
+        g = []
+        for j in (1, 2, 3):
+            g1 = f2.pow(xi, (p ** j - 1) // 6)
+            cur = (1, 0)
+            for k in range(6):
+                g += lim(cur[0] * Rp % p) + lim(cur[1] * Rp % p)
+                cur = f2.mul(cur, g1)
+        o += arr("FROB_GAMMA", g)
         return o + "};\n"
     xinv = f2bn.inv((9, 1))
     beta_bn = (3 * xinv[0] % p_bn, 3 * xinv[1] % p_bn)                       # 9 / xi = xi (3 / xi)^2
