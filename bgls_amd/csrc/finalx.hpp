@@ -68,9 +68,11 @@ __device__ __forceinline__ X2<C, SX_T> fx_ld2(int off) {
 }
 
 // this half of xi * (re + i im), carry-normalised: the real half is XI_RE re - im, the imaginary half XI_RE im + re
-// (alt-bn128: xi = 9 + i, BLS12-381: 1 + i).  `mine` is the own half, `other` the other one; tight in, tight out.
-template <class C>
-__device__ __forceinline__ Sx<C, SX_T> fx_mulxi_half(const Sx<C, SX_T>& mine, const Sx<C, SX_T>& other, bool is_im) {
+// (alt-bn128: xi = 9 + i, BLS12-381: 1 + i).  `mine` is the own half, `other` the other one; any limbs in (sums of a few tight
+// values as well: the carry is 64 bits wide), tight out -- the carry-normalised limbs of an integer are unique, so the result does
+// not depend on how the operands were represented.
+template <class C, int LA>
+__device__ __forceinline__ Sx<C, SX_T> fx_mulxi_half(const Sx<C, LA>& mine, const Sx<C, LA>& other, bool is_im) {
   constexpr int N = C::RX_NL;
   const i32 sgn = is_im ? 1 : -1;
   Sx<C, SX_T> r;
@@ -93,6 +95,30 @@ __device__ __forceinline__ void fx_put(int slot, int k, const X2<C, SX_T>& v) {
   fx_st<C>(E::coef(slot, k, 0) + E::HS, v.c1);
   fx_st<C>(E::coef(slot, k, 1), fx_mulxi_half<C>(v.c0, v.c1, false));
   fx_st<C>(E::coef(slot, k, 1) + E::HS, fx_mulxi_half<C>(v.c1, v.c0, true));
+}
+
+// Second stage of a product, shared by the two waves of the pair that computed its half-products (at `scr`): lanes 0..11 of BOTH
+// waves add the six terms of coefficient half (j, hh) up; the wave with h == 0 carry-normalises the sum and stores the coefficient,
+// the wave with h == 1 forms its xi multiple from the raw sums (the other half's from the neighbour lane) and stores that.  The
+// two instruction streams are each about half of what one wave did alone (round 4: the second wave used to wait here).
+template <class C>
+__device__ __forceinline__ void fx_stage2(int dst, int scr, int lane, int h) {
+  typedef FX<C> E;
+  if (lane < 12) {
+    const int j = lane >> 1, hh = lane & 1;
+    const int o = scr + (6 * j) * E::ES + hh * E::HS;
+    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
+    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
+    const auto raw = sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5));
+    if (h == 0) {
+      fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, sx_norm<C>(raw));
+    } else {
+      auto other = raw;
+#pragma unroll
+      for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, raw.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+      fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(raw, other, hh == 1));
+    }
+  }
 }
 
 // dst <- a * b (all 128 threads must call).  Lane 6j + t of wave h: half h of the reduced product a_t * b_(j - t) (the xi multiple
@@ -120,18 +146,7 @@ __device__ __noinline__ void fx_mul(int dst, int a, int b) {
     fx_st<C>(E::SCR + lane * E::ES + h * E::HS, p);
   }
   __syncthreads();
-  if (tid < 12) {
-    const int j = tid >> 1, hh = tid & 1;
-    const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
-    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
-    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
-    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
-    Sx<C, SX_T> other;
-#pragma unroll
-    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
-    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
-  }
+  if (tid < 128) fx_stage2<C>(dst, E::SCR, lane, h);
   __syncthreads();
 }
 
@@ -159,18 +174,7 @@ __device__ __noinline__ void fx_mul_pair(int d0, int a0, int b0, int d1, int a1,
     fx_st<C>(scr + lane * E::ES + h * E::HS, p);
   }
   __syncthreads();
-  if (lane < 12 && h == 0 && dst >= 0) {
-    const int j = lane >> 1, hh = lane & 1;
-    const int o = scr + (6 * j) * E::ES + hh * E::HS;
-    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
-    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
-    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
-    Sx<C, SX_T> other;
-#pragma unroll
-    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
-    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
-  }
+  if (dst >= 0) fx_stage2<C>(dst, scr, lane, h);
   __syncthreads();
 }
 
@@ -215,12 +219,14 @@ __device__ __forceinline__ void fx_mul2w_init() {
   extern __shared__ u32 lds[];
   lds[FX<C>::LDS_DW] = 0;
   lds[FX<C>::LDS_DW + 1] = 0;
+  lds[FX<C>::LDS_DW + 2] = 0;
+  lds[FX<C>::LDS_DW + 3] = 0;
 }
 // The two-wave product WITHOUT block barriers (round 4): for a block whose third wave does something else and must not be
 // dragged into the product's barriers (k_miller_latx: the accumulator on waves 0 and 1, the point steps on wave 2).  The two
-// stages of fx_mul are separated by hand-overs through two LDS words instead: wave 1 publishes "my half-products of product
-// number `epoch` are stored", wave 0 (whose lanes 0..11 add the terms up) publishes "coefficients of product `epoch` are
-// stored"; each side spins on the other's word.  `epoch` = the number of this product, 1, 2, .. (both waves count their calls; by
+// stages of fx_mul are separated by hand-overs through four LDS words instead: each wave publishes "my half-products of product
+// number `epoch` are stored" and, after its part of the second stage (fx_stage2), "my part of product `epoch` is stored"; each
+// side spins on the other's word.  `epoch` = the number of this product, 1, 2, .. (both waves count their calls; by
 // value: a reference parameter of a function that is not inlined lives in scratch memory, and the spin loops then re-read it from there).
 template <class C>
 __device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32 epoch) {
@@ -241,30 +247,17 @@ __device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32 epoch) {
     const Sx<C, SX_T> p = sx_montr<C, 2, 2 * SX_T * SX_T>(cols, [&](int q, int i) { return q == 0 ? x.c0.v[i] : (x.c1.v[i] ^ sg) - sg; });
     fx_st<C>(E::SCR + lane * E::ES + h * E::HS, p);
   }
+  // both waves: "my half-products of product `epoch` are stored" -> wait for the other's -> my part of the second stage ->
+  // "my part of product `epoch` is stored" -> wait for the other's
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (h == 1) {
-    if (lane == 0) __hip_atomic_store(&s_flag[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(&s_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return;
-  }
-  while (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+  if (lane == 0) __hip_atomic_store(&s_flag[h], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&s_flag[1 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane < 12) {
-    const int j = lane >> 1, hh = lane & 1;
-    const int o = E::SCR + (6 * j) * E::ES + hh * E::HS;
-    const Sx<C, SX_T> t0 = fx_ld<C>(o), t1 = fx_ld<C>(o + E::ES), t2 = fx_ld<C>(o + 2 * E::ES);
-    const Sx<C, SX_T> t3 = fx_ld<C>(o + 3 * E::ES), t4 = fx_ld<C>(o + 4 * E::ES), t5 = fx_ld<C>(o + 5 * E::ES);
-    const Sx<C, SX_T> mine = sx_norm<C>(sx_add<C>(sx_add<C>(sx_add<C>(t0, t1), sx_add<C>(t2, t3)), sx_add<C>(t4, t5)));
-    Sx<C, SX_T> other;
-#pragma unroll
-    for (int i = 0; i < C::RX_NL; ++i) other.v[i] = __builtin_amdgcn_update_dpp(0, mine.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-    fx_st<C>(E::coef(dst, j, 0) + hh * E::HS, mine);
-    fx_st<C>(E::coef(dst, j, 1) + hh * E::HS, fx_mulxi_half<C>(mine, other, hh == 1));
-  }
+  fx_stage2<C>(dst, E::SCR, lane, h);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_store(&s_flag[1], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  wave_sync();
+  if (lane == 0) __hip_atomic_store(&s_flag[2 + h], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&s_flag[3 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 template <class C>

@@ -262,6 +262,7 @@ int bgls_set_throughput_mode(int on);
  *   BGLS_EPIX=0           verification epilogue on 32-bit limbs (k_cofactor_epilogue)
  *   BGLS_SUMX=0|1|2       G2 key sums: 32-bit limbs / one lane / lane pairs (default 2);  BGLS_SUM_WAVES = waves of their main pass
  *   BGLS_SUMTREE=0        the tree above a key sum's partials as one launch per level instead of one launch
+ *   BGLS_SUMTREEX=0       that one-launch tree with its additions on 32-bit limbs (round 4's first form) instead of carry-free lane pairs
  *   BGLS_G1X=0            BLS12-381 G1 scalar multiplications (Sign, ScalePoints, HashToG1's cofactor clearing) on 32-bit limbs
  *   BGLS_LATX2=0          the latency Miller kernel / epilogue with a one-wave accumulator (round 3's two-wave block)
  *   BGLS_SIG_EARLY=0      the signature pair of a lone large verification behind its reduce stage instead of beside its hashing

@@ -1,5 +1,5 @@
 """GPU tier: the kernels that round 3 replaced stay selectable for A/B measurements (BGLS_FINALX=0: 36-lane final exponentiation
-on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue, BGLS_SUMTREE=0: k_sum_coop per level instead of k_sum_tree, BGLS_G1X=0: BLS12-381 Sign / ScalePoints / HashToG1 cofactor clearing on 32-bit limbs, BGLS_REDUCEX=0: every reduce pass on k_reduce_coop).  The switches are read once
+on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue, BGLS_SUMTREE=0: k_sum_coop per level instead of k_sum_tree, BGLS_SUMTREEX=0: the tree's additions on 32-bit limbs (k_sum_tree) instead of k_sum_tree_x, BGLS_G1X=0: BLS12-381 Sign / ScalePoints / HashToG1 cofactor clearing on 32-bit limbs, BGLS_REDUCEX=0: every reduce pass on k_reduce_coop).  The switches are read once
 per process, so each combination runs in a child process: PairingProduct of a handful of pairings (the latency path: k_miller_lat(x)
 + reduce + final exponentiation) must give the C oracle's GT bytes, and a 300-key aggregate of public keys the oracle's point."""
 import json
@@ -62,8 +62,8 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {"BGLS_G1X": "0"}, {"BGLS_REDUCEX": "0"}, {"BGLS_LATX2": "0"}, {}],
-                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "32-bit G1 scalar multiplications", "six-lane reduce passes", "one-wave accumulator in the latency Miller kernel", "defaults"])
+@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {"BGLS_SUMTREEX": "0"}, {"BGLS_G1X": "0"}, {"BGLS_REDUCEX": "0"}, {"BGLS_LATX2": "0"}, {}],
+                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "key-sum tree with 32-bit additions", "32-bit G1 scalar multiplications", "six-lane reduce passes", "one-wave accumulator in the latency Miller kernel", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
     golden = os.path.join(ROOT, "tests", "golden")
     code = CHILD % (ROOT, golden)
