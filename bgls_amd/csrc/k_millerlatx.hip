@@ -328,14 +328,36 @@ __global__ void __launch_bounds__(64 * (AW + 1)) k_miller_latx(const Aff<F1<C>>*
 // the signature pair alone (first_role 0) -- it depends on nothing but sigma, so a verification with the machine to itself walks
 // it on the context's side stream while the messages are hashed -- or rest^h alone (first_role 1).
 template <class C, int AW>
-__global__ void __launch_bounds__(64 * (AW + 1)) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
-                                                               uint32_t* flags, int first_role) {
+__global__ void __launch_bounds__(AW == 2 ? 256 : 128) k_epilogue_ax(const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp,
+                                                                     uint32_t* flags, int first_role) {
   typedef FX<C> E;
   if ((int)blockIdx.x + first_role == 0) {
+    if (threadIdx.x >= 64 * (AW + 1)) return;               // the Miller block is AW + 1 waves
     if (sig != nullptr) {
       miller_latx_block<C, AW>(sig, nullptr, 0, 0, gen_lines, tmp, flags, 0);  // (-sigma, g2): pair "n" of an empty batch
     } else if (threadIdx.x < 6) {
       tmp[threadIdx.x] = threadIdx.x == 0 ? f2_one<C>() : f2_zero<C>();
+    }
+    return;
+  }
+  if constexpr (AW == 2) {
+    // round 4b: rest^h on FOUR waves, right to left -- the squarings on one pair of waves, the products the cofactor's bits select
+    // on the other (finalx.hpp fx_pow / fx_mul_pair): 126 products deep instead of 125 squarings and 60 products one after the other
+    const int lane = threadIdx.x;
+    enum { S_BASE = 0, S_ACC = 1, S_SQ = 2 };
+    if (lane < 6) {
+      const Fp2<C> v = rest[lane];
+      fx_put<C>(S_BASE, lane, X2<C, SX_T>{sx_from_mont<C>(v.c0), sx_from_mont<C>(v.c1)});
+    }
+    __syncthreads();
+    int res = S_BASE;
+    if constexpr (C::CURVE_ID == 1) {
+      fx_pow<C>(S_ACC, S_BASE, C::COFACTOR, C::COFACTOR_BITS, S_SQ);
+      res = S_ACC;
+    }
+    if (lane < 6) {
+      const X2<C, SX_T> x = fx_ld2<C>(E::coef(res, lane, 0));
+      tmp[6 + lane] = Fp2<C>{sx_to_mont<C>(x.c0), sx_to_mont<C>(x.c1)};
     }
     return;
   }
@@ -423,10 +445,11 @@ static bool latx_two_waves() {
   static const bool on = [] { const char* e = getenv("BGLS_LATX2"); return !(e && e[0] == '0'); }();
   return on;
 }
+static_assert(FX<BN254>::LDS_BYTES_PAIR >= FX<BN254>::LDS_BYTES + FX2W_EXTRA_BYTES, "the pair scratch covers the hand-over words");
 template <class C>
 static void launch_epilogue_ax(hipStream_t st, unsigned blocks, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint32_t* flags,
                                int first_role) {
-  if (latx_two_waves()) k_epilogue_ax<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
+  if (latx_two_waves()) k_epilogue_ax<C, 2><<<blocks, 256, FX<C>::LDS_BYTES_PAIR, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
   else k_epilogue_ax<C, 1><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
 }
 template <class C>
