@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: where does k_miller_latx spend a step?  Runs one multi-signature record and the n = 64 record on the
-LATX_DBG build of the library (tools/exp/libbgls_hip_latxdbg.so, see k_millerlatx.hip) and prints the 100 MHz time stamps of
+LATX_DBG build of the library (tools/exp/latx_dbg_build.sh writes tools/exp/libbgls_hip_latxdbg.so; see k_millerlatx.hip) and prints the 100 MHz time stamps of
 the producer / consumer hand-overs of the last launch."""
 import ctypes, os, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
