@@ -113,6 +113,14 @@ struct TreeX {
   static_assert(REC_DW % 2 == 0 && REC_DW / 2 <= 64, "a record is at most 64 eight-byte words");
 };
 
+#ifdef TREEX_DBG
+// development only: shader-clock stamps of the wave that carries the sum upwards, [level][event] (tools/exp/treex_steps.py)
+__device__ unsigned long long g_treex_t[20][8];
+#define TREEX_T(lv, k) do { if ((threadIdx.x & 63) == 0 && (lv) < 20) g_treex_t[lv][k] = clock64(); } while (0)
+#else
+#define TREEX_T(lv, k) do { } while (0)
+#endif
+
 template <class C>
 __global__ void __launch_bounds__(64) k_sum_tree_x(const Jac<F2<C>>* in, size_t cnt, u32* store, uint32_t* tickets, uint8_t* d_bytes,
                                                    Jac<F2<C>>* d_jac) {
@@ -249,34 +257,77 @@ __global__ void __launch_bounds__(64) k_sum_tree_x(const Jac<F2<C>>* in, size_t 
   };
 
   size_t i = blockIdx.x;                        // node index at the current level
+  int lv = 0;
+  (void)lv;
+  TREEX_T(0, 0);
   load_leaf(in + 2 * i, T::AX);
   if (2 * i + 1 < cnt) {
     load_leaf(in + 2 * i + 1, T::BX);
+    TREEX_T(0, 1);
     add();
   }
+  TREEX_T(0, 2);
   size_t n = (cnt + 1) / 2, off = 0;            // nodes at this level, offset of the level's slots
   while (n > 1) {
     const size_t sib = i ^ 1;
+    ++lv;
     if (sib < n) {
+      TREEX_T(lv, 0);
       park(store + (off + i) * T::REC_DW);
+      TREEX_T(lv, 1);
       unsigned t = 0;
       if (lane == 0) t = atomicAdd(&tickets[off + (i & ~(size_t)1)], 1u);
       t = __shfl(t, 0);
       if (t == 0) return;                       // first of the pair: the sibling's wave carries both sums on
+      TREEX_T(lv, 2);
       fetch(store + (off + sib) * T::REC_DW);
+      TREEX_T(lv, 3);
       add();
+      TREEX_T(lv, 4);
       if (lane == 0) tickets[off + (i & ~(size_t)1)] = 0;        // left clean for the next launch
     }
     off += n;
     i >>= 1;
     n = (n + 1) / 2;
   }
-  to_rec(0, T::AX);
-  if (lane == 0) {
-    const Jac<F> acc = *reinterpret_cast<const Jac<F>*>(lds);
-    if (d_jac) *d_jac = acc;
-    if (d_bytes) aff_to_bytes<F>(d_bytes, jac_to_aff<F>(acc));
+  // the root: the Jacobian record in the library's form if asked for, and the affine wire bytes x = X / Z^2, y = Y / Z^3 -- on
+  // the lane pairs as well (one lane walking jac_to_aff in the 32-bit form took 60 us: an Fp2 inversion and five Fp2 products
+  // of dependent carry chains): |Z|^2 and the products are rounds of the pair arithmetic, ONE value goes through fp_inv
+  TREEX_T(19, 0);
+  const bool zinf = is_zero(LD(T::AZ));
+  if (d_jac || zinf) {
+    to_rec(0, T::AX);
+    if (lane == 0) {
+      const Jac<F> acc = *reinterpret_cast<const Jac<F>*>(lds);
+      if (d_jac) *d_jac = acc;
+      if (d_bytes && zinf) aff_to_bytes<F>(d_bytes, jac_to_aff<F>(acc));
+    }
   }
+  TREEX_T(19, 1);
+  if (d_bytes && !zinf) {
+    const Sx<C, SX_T> own = LD(T::AZ);
+    const Sx<C, SX_T> sq = pair_muls<C>(own, own);                       // z0^2 | z1^2
+    Sx<C, 2 * SX_T> nn;
+#pragma unroll
+    for (int i = 0; i < N; ++i) nn.v[i] = sq.v[i] + pair_swap1(sq.v[i]);
+    const Sx<C, SX_T> ni = sx_from_mont<C>(fp_inv<C>(sx_to_mont<C>(nn)));   // 1 / |Z|^2, the same on every lane
+    ST(T::T1, pair_muls<C>(sx_select<C>(odd, sx_neg<C>(own), own), ni), q == 0);      // 1 / Z = conj(Z) / |Z|^2
+    wave_sync();
+    {
+      const Sx<C, SX_F> zi = sx_as<SX_F, C>(LD(T::T1));
+      ST(T::T2, pair_mul<C>(zi, zi, odd), q == 0);                        // Z^-2
+      wave_sync();
+    }
+    ST(q == 0 ? T::U1 : T::U2, pair_mul<C>(sx_as<SX_F, C>(LD(q == 0 ? T::AX : T::T2)), sx_as<SX_F, C>(LD(q == 0 ? T::T2 : T::T1)), odd), q < 2);   // x | Z^-3
+    wave_sync();
+    ST(T::S1, pair_mul<C>(sx_as<SX_F, C>(LD(T::AY)), sx_as<SX_F, C>(LD(T::U2)), odd), q == 0);     // y
+    wave_sync();
+    if (lane < 4) {                                                       // x.c1 | x.c0 | y.c1 | y.c0, big-endian (g2_to_bytes)
+      const Sx<C, SX_T> v = fx_ld<C>(ebase + (lane < 2 ? T::U1 : T::S1) * ES + ((lane & 1) ? 0 : HS));
+      fp_to_be<C>(d_bytes + lane * C::FP_BYTES, fp_from_mont<C>(sx_to_mont<C>(v)));
+    }
+  }
+  TREEX_T(19, 2);
 }
 
 namespace bgls {
@@ -302,3 +353,6 @@ template void sum_tree<BLS381>(hipStream_t, const void*, size_t, void*, uint32_t
 
 }  // namespace kl
 }  // namespace bgls
+#ifdef TREEX_DBG
+extern "C" int bgls_dbg_treex_dump(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_treex_t), sizeof(g_treex_t)); }
+#endif
