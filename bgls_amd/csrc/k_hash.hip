@@ -131,6 +131,14 @@ __global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<
 // the first round tests counters 0..14 side by side while lane 15 hashes the 0xFF-prefixed sign input (the same instruction
 // stream: only the prefix byte differs), later rounds -- probability 2^-15 per message -- sixteen counters each.  The accepted
 // counter is the LOWEST one with x^3 + 3 a square, as in the sequential loop (curves/hash.go:53-77): same (x, y).
+#ifdef H2C_DBG
+// development only: shader-clock stamps of block 0 of k_h2c_bn_wide (tools/exp/h2c_steps.py)
+__device__ unsigned long long g_h2c_t[16];
+#define H2C_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_h2c_t[k] = clock64(); } while (0)
+extern "C" int bgls_dbg_h2c_dump(unsigned long long* o) { return (int)hipMemcpyFromSymbol(o, HIP_SYMBOL(g_h2c_t), sizeof(g_h2c_t)); }
+#else
+#define H2C_T(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
   typedef BN254 C;
   const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
@@ -149,16 +157,21 @@ __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1
     ByteSrc src;
     src.msg = msg; src.len = len; src.pre[0] = (uint8_t)c; src.npre = 1; src.nsuf = 0;
     u32 d[8];
+    H2C_T(0);
     keccak256_legacy(src, d);
+    H2C_T(1);
     Fp<C> h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) h.v[j] = d[7 - j];
     const Fp<C> xc = fp_to_mont<C>(h);
     const Fp<C> yc = fp_add<C>(fp_mul<C>(fp_sqr<C>(xc), xc), fp_load<C>(C::B));
+    H2C_T(2);
     // every lane takes the square root of its own candidate and squares it back instead of asking for the Legendre symbol
     // first: the sixteen exponentiations are one instruction stream, and the accepted lane has its y already
     const Fp<C> rc = rx_sqrt_pow<C, false>(yc, tab);
+    H2C_T(3);
     bool ok = fp_eq<C>(fp_sqr<C>(rc), yc) && c < 256u && !done;
+    H2C_T(4);
     if (first) {
       sign = __shfl(d[7] & 1u, grp * 16 + 15);          // last digest byte of the 0xFF-prefixed hash, low bit
       if (sub == 15) ok = false;                         // counter 255 is tried in its turn, not in round 0
@@ -181,7 +194,9 @@ __global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1
     }
     return;
   }
+  H2C_T(5);
   if (mine) out[i] = {x, sign ? fp_neg<C>(y2) : y2, false};
+  H2C_T(6);
 }
 
 // BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
