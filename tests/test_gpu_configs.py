@@ -106,6 +106,12 @@ def test_key_sum_tree_shapes_match_the_oracle(gpu_lib, cid, fp):
     got = out(PT)
     assert lib.bgls_aggregate_points(cid, 2, B(bytes(pts)), n, got) == 0
     assert bytes(got) == coracle.aggregate_points(cid, 2, bytes(pts), n)
+    # a sum that IS the point at infinity (P + (-P), alone and spread over two blocks): the root's infinity path
+    for pair in (bytes(pts[20 * PT:21 * PT]) + neg, bytes(pts[20 * PT:21 * PT]) + keys[:127 * PT] + neg + coracle.scale_point(cid, 2, bytes(g2), (ORDER[cid] - sum(sks[:127])) % ORDER[cid])):
+        cnt = len(pair) // PT
+        got = out(PT)
+        assert lib.bgls_aggregate_points(cid, 2, B(pair), cnt, got) == 0
+        assert bytes(got) == coracle.aggregate_points(cid, 2, pair, cnt), cnt
     # two blocks whose sums are equal: the tree's first addition is a doubling
     two = keys[:128 * PT] * 2
     got = out(PT)
