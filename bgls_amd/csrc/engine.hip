@@ -624,21 +624,25 @@ struct Engine {
     if ((rc = c.get(WS_TMP, GTB + 16, &tmp))) return rc;
     if ((rc = c.get(WS_OUT, 16, &fl))) return rc;
     uint8_t* d_gt = (uint8_t*)tmp;
-    uint32_t* d_verdict = (uint32_t*)(d_gt + GTB);
+    uint32_t* d_verdict = (uint32_t*)(d_gt + GTB);        // three words: {verdict, final-stage flags, caller flags} on the finalx path
     uint32_t* d_fl2 = (uint32_t*)fl;
-    HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
+    // finalx.hpp: the same 36-lane split on the carry-free limbs (BGLS_FINALX=0 keeps the 32-bit form of finalexp.hpp: A/B runs)
+    static const bool finalx = [] { const char* e = getenv("BGLS_FINALX"); return !(e && e[0] == '0'); }();
+    if (!finalx) HIPCHK(hipMemsetAsync(d_fl2, 0, 4, st));
     {
       Scope sc(c, st, ST_FINAL);
-      // finalx.hpp: the same 36-lane split on the carry-free limbs (BGLS_FINALX=0 keeps the 32-bit form of finalexp.hpp: A/B runs)
-      static const bool finalx = [] { const char* e = getenv("BGLS_FINALX"); return !(e && e[0] == '0'); }();
-      if (finalx) kl::finalx<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
+      if (finalx) kl::finalx_res<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_flags_in);
       else kl::final36<C>(st, d_partials, count, do_final_exp, d_gt, d_verdict, d_fl2);
     }
     HIPCHK(hipGetLastError());
     c.h_res[0] = c.h_res[1] = c.h_res[2] = 0;
-    HIPCHK(hipMemcpyAsync(&c.h_res[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&c.h_res[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
-    if (d_flags_in) HIPCHK(hipMemcpyAsync(&c.h_res[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
+    if (finalx) {
+      HIPCHK(hipMemcpyAsync(&c.h_res[0], d_verdict, 12, hipMemcpyDeviceToHost, st));      // one copy: the kernel gathered the three words
+    } else {
+      HIPCHK(hipMemcpyAsync(&c.h_res[0], d_verdict, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&c.h_res[1], d_fl2, 4, hipMemcpyDeviceToHost, st));
+      if (d_flags_in) HIPCHK(hipMemcpyAsync(&c.h_res[2], d_flags_in, 4, hipMemcpyDeviceToHost, st));
+    }
     if (h_gt_out) HIPCHK(hipMemcpyAsync(h_gt_out, d_gt, GTB, hipMemcpyDeviceToHost, st));
     c.res_pending = true;
     c.res_stream = st;

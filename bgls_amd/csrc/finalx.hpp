@@ -213,7 +213,7 @@ __device__ __noinline__ void fx_mul1(int dst, int a, int b) {
 }
 
 // hand-over words of fx_mul2w: one lane calls this before the block's first barrier; dynamic LDS = FX::LDS_BYTES + FX2W_EXTRA_BYTES
-constexpr int FX2W_EXTRA_BYTES = 16;
+constexpr int FX2W_EXTRA_BYTES = 32;     // four hand-over words + four words for the kernel that uses them (k_miller_latx: its `valid` word)
 template <class C>
 __device__ __forceinline__ void fx_mul2w_init() {
   extern __shared__ u32 lds[];

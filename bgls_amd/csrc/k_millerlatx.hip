@@ -49,7 +49,11 @@ __device__ __forceinline__ void miller_latx_block(const Aff<F1<C>>* g1s, const u
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool is_sig = sig_at >= 0 && blk == n;
   const int pbase = E::coef(S_PA, 0, 0);
-  __shared__ int s_valid;
+  // (no static LDS in a kernel of this file: it would sit in front of the dynamic array and shift every slot off its 16-byte
+  // alignment -- the 16-byte LDS accesses of fx_ld / fx_st then cost a third more: measured on k_finalx, round 4.  The word lives
+  // behind fx_mul2w's hand-over words.)
+  extern __shared__ u32 lds_words[];
+  volatile int& s_valid = *reinterpret_cast<volatile int*>(lds_words + E::LDS_DW + 4);
   const bool odd = lane & 1;
   const int q = lane >> 1;                                              // the lane pair's product index within a round
   // own half of scratch entry e / store it (values are tight: reductions' outputs or carried sums)
@@ -450,7 +454,7 @@ template <class C>
 static void launch_epilogue_ax(hipStream_t st, unsigned blocks, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint32_t* flags,
                                int first_role) {
   if (latx_two_waves()) k_epilogue_ax<C, 2><<<blocks, 256, FX<C>::LDS_BYTES_PAIR, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
-  else k_epilogue_ax<C, 1><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
+  else k_epilogue_ax<C, 1><<<blocks, 128, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
 }
 template <class C>
 void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
@@ -477,7 +481,7 @@ void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size
                  uint32_t* flags) {
   const unsigned blocks = (unsigned)(n + (sig_at >= 0 ? 1 : 0));
   if (latx_two_waves()) k_miller_latx<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
-  else k_miller_latx<C, 1><<<blocks, 128, FX<C>::LDS_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
+  else k_miller_latx<C, 1><<<blocks, 128, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
 }
 template void miller_latx<BN254>(hipStream_t, const Aff<F1<BN254>>*, const uint8_t*, size_t, long long, const LineCoeffs<BN254>*, Fp2<BN254>*, uint32_t*);
 template void miller_latx<BLS381>(hipStream_t, const Aff<F1<BLS381>>*, const uint8_t*, size_t, long long, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint32_t*);
