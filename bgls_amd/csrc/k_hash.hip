@@ -104,8 +104,7 @@ __device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
   const int lane = threadIdx.x & 63;
   auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
   auto st = [&](int e, int i, i32 v) { tab[(e * N + i) * 64 + lane] = v; };
-  auto word = [&](int k) { return C::EXP_SQRT[k] - ((M1 && k == 0) ? 1u : 0u); };   // the low word of (p + 1) / 4 is odd
-  const Sx<C, SX_T> r = sx_pow_sw<C, RXP_W, 32 * C::L>(ux_to_sx<C>(to_ux<C>(a)), word, ld, st);
+  const Sx<C, SX_T> r = sx_pow_sqrt<C, RXP_W, M1>(ux_to_sx<C>(to_ux<C>(a)), ld, st);   // (the low word of (p + 1) / 4 is odd: M1 borrows nothing)
   Ux<C> u;
 #pragma unroll
   for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];

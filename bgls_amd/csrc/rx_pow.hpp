@@ -128,4 +128,86 @@ BGLS_HD Sx<C, SX_T> sx_pow_sw(const Sx<C, SX_T>& a, Word&& word, Ld&& ld, St&& s
   return r;
 }
 
+// The square-root chains again ((p + 1) / 4, or (p - 3) / 4 with M1), from a window schedule computed at COMPILE time.  sx_pow_sw scans
+// the exponent at run time: every bit it looks at is a scalar load from the constant array and a wait (~570 of them per root); on
+// a lone wave -- the small-batch hash, one chain per lane and nothing else on the SIMD -- that is 15 % of the root.  Here an
+// operation is one 16-bit word: "square nsq times (the zero bits in front of a window and the window's own length), then
+// multiply by table entry idx"; the same squarings and products in the same order as sx_pow_sw<C, W, 32 L>, hence the same limbs.
+template <class C, int W, bool M1>
+struct SqrtSched {
+  static constexpr int NB = 32 * C::L;
+  struct Tab {
+    unsigned short op[NB + 1];                               // nsq | (idx + 1) << 10; op[0]: the leading window (nsq unused)
+    int n;
+  };
+  static constexpr u32 bitc(int i) {
+    const u32 w = C::EXP_SQRT[i >> 5] - ((M1 && (i >> 5) == 0) ? 1u : 0u);
+    return (w >> (i & 31)) & 1u;
+  }
+  static constexpr Tab make() {
+    Tab t{};
+    int n = 0, i = NB - 1, pend = 0;
+    while (i >= 0 && !bitc(i)) --i;
+    while (i >= 0) {
+      if (bitc(i)) {
+        int l = i - W + 1;
+        if (l < 0) l = 0;
+        while (!bitc(l)) ++l;
+        u32 v = 0;
+        for (int k = i; k >= l; --k) v = (v << 1) | bitc(k);
+        t.op[n++] = (unsigned short)((u32)(pend + (i - l + 1)) | (((v >> 1) + 1u) << 10));
+        pend = 0;
+        i = l - 1;
+      } else {
+        ++pend;
+        --i;
+      }
+    }
+    if (pend) t.op[n++] = (unsigned short)pend;
+    t.n = n;
+    return t;
+  }
+};
+template <class C, int W, bool M1>
+struct SqrtSchedTab {
+  static constexpr typename SqrtSched<C, W, M1>::Tab tab = SqrtSched<C, W, M1>::make();
+};
+
+template <class C, int W, bool M1, class Ld, class St>
+BGLS_HD Sx<C, SX_T> sx_pow_sqrt(const Sx<C, SX_T>& a, Ld&& ld, St&& st) {
+  constexpr int N = C::RX_NL;
+  constexpr int TE = 1 << (W - 1);
+  {
+    const Sx<C, SX_T> a2 = sx_sqr<C>(a);
+    Sx<C, SX_T> o = a;
+#pragma unroll
+    for (int i = 0; i < N; ++i) st(0, i, o.v[i]);
+#pragma unroll 1
+    for (int e = 1; e < TE; ++e) {
+      o = sx_mul<C>(o, a2);
+#pragma unroll
+      for (int i = 0; i < N; ++i) st(e, i, o.v[i]);
+    }
+  }
+  const int nops = SqrtSchedTab<C, W, M1>::tab.n;
+  Sx<C, SX_T> r;
+  {
+    const int idx = (int)(SqrtSchedTab<C, W, M1>::tab.op[0] >> 10) - 1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.v[k] = ld(idx, k);
+  }
+#pragma unroll 1
+  for (int o = 1; o < nops; ++o) {
+    const int op = SqrtSchedTab<C, W, M1>::tab.op[o];
+    const int nsq = op & 1023, idx = (op >> 10) - 1;
+#pragma unroll 1
+    for (int s = 0; s < nsq; ++s) r = sx_sqr<C>(r);
+    if (idx >= 0) {
+      const i32* const cols[1] = {r.v};
+      r = sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int k) { return ld(idx, k); });
+    }
+  }
+  return r;
+}
+
 }  // namespace bgls
