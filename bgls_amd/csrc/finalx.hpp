@@ -331,8 +331,12 @@ __device__ __noinline__ void fx_pow(int dst, int a, const u32* e, int nbits, int
   };
   copy(sq, a);
   bool have = false;
+  // the exponent's words in registers: a bit test inside the loop is then scalar arithmetic, not a load from the constant array
+  // and a wait in front of every product (exponents here have at most 128 bits)
+  const u32 w0 = e[0], w1 = nbits > 32 ? e[1] : 0u, w2 = nbits > 64 ? e[2] : 0u, w3 = nbits > 96 ? e[3] : 0u;
   for (int i = 0; i < nbits; ++i) {
-    const bool bit = (e[i >> 5] >> (i & 31)) & 1u;
+    const u32 w = i < 32 ? w0 : i < 64 ? w1 : i < 96 ? w2 : w3;
+    const bool bit = (w >> (i & 31)) & 1u;
     const bool more = i + 1 < nbits;
     if (bit && !have) {
       copy(dst, sq);
