@@ -251,12 +251,12 @@ __device__ __noinline__ void fx_mul2w(int dst, int a, int b, u32 epoch) {
   // "my part of product `epoch` is stored" -> wait for the other's
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) __hip_atomic_store(&s_flag[h], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(&s_flag[1 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+  while (__hip_atomic_load(&s_flag[1 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) { }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   fx_stage2<C>(dst, E::SCR, lane, h);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) __hip_atomic_store(&s_flag[2 + h], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(&s_flag[3 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) __builtin_amdgcn_s_sleep(1);
+  while (__hip_atomic_load(&s_flag[3 - h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch) { }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
