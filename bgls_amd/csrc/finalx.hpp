@@ -21,6 +21,13 @@
 
 namespace bgls {
 
+#ifdef FX_DBG
+// development only: shader-clock stamps of the final exponentiation's phases (tools/exp/fx_steps.py)
+__device__ unsigned long long g_fx_t[16];
+#define FX_T(k) do { if (threadIdx.x == 0) g_fx_t[k] = clock64(); } while (0)
+#else
+#define FX_T(k) do { } while (0)
+#endif
 template <class C>
 struct FX {
   static constexpr int N = C::RX_NL;
@@ -300,6 +307,7 @@ __device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
   fx_frob<C>(sB, sA, 2);                  // N^(p^4)
   fx_mul<C>(sA, sA, sB);                  // M = N^(p^2) N^(p^4)
   fx_mul<C>(sB, sN, sA);                  // Norm(N) in Fp2: only coefficient 0
+  FX_T(9);
   if (lane < 6) {
     // 1 / d = conj(d) / (d0^2 + d1^2): the norm and the two products on these limbs, ONE value through the 32-bit form and back
     const X2<C, SX_T> d = fx_ld2<C>(E::coef(sB, 0, 0));
@@ -311,6 +319,7 @@ __device__ __noinline__ void fx_inv(int dst, int a, int sN, int sA, int sB) {
     fx_put<C>(sA, lane, x2_mul<C>(m, di));                         // N^-1 (every lane touches its own coefficient only)
   }
   __syncthreads();
+  FX_T(10);
   fx_conj<C>(sB, a);
   fx_mul<C>(dst, sB, sA);
 }
@@ -354,16 +363,22 @@ __device__ __noinline__ void fx_pow(int dst, int a, const u32* e, int nbits, int
 template <class C>
 __device__ __noinline__ void fx_final_exp() {
   // easy part: (p^6 - 1)(p^2 + 1)
+  FX_T(1);
   fx_conj<C>(FE_T, FE_F);
   fx_inv<C>(FE_U, FE_F, FE_X, FE_Y5, FE_Y6);
+  FX_T(2);
   fx_mul<C>(FE_T, FE_T, FE_U);
   fx_frob<C>(FE_U, FE_T, 2);
   fx_mul<C>(FE_F, FE_U, FE_T);
+  FX_T(3);
   if constexpr (C::CURVE_ID == 0) {
     // hard part, y0..y6 vectorial chain (pairing.hpp final_exp)
     fx_pow<C>(FE_A, FE_F, C::U_ABS, C::U_BITS, FE_T0);     // ft1
+    FX_T(4);
     fx_pow<C>(FE_B, FE_A, C::U_ABS, C::U_BITS, FE_T0);     // ft2
+    FX_T(5);
     fx_pow<C>(FE_C, FE_B, C::U_ABS, C::U_BITS, FE_T0);     // ft3
+    FX_T(6);
     // (independent products of the chain run two at a time on the two halves of the block)
     fx_frob<C>(FE_Y0, FE_F, 1);
     fx_frob<C>(FE_T, FE_F, 2);
@@ -389,6 +404,7 @@ __device__ __noinline__ void fx_final_exp() {
     fx_mul_pair<C>(FE_T0, FE_T1, FE_Y1, FE_T1, FE_T1, FE_Y0);
     fx_mul<C>(FE_T0, FE_T0, FE_T0);
     fx_mul<C>(FE_F, FE_T1, FE_T0);
+    FX_T(7);
   } else {
     // (p^4 - p^2 + 1)/r = c (x + p)(x^2 + p^2 - 1) + 1,  c = (x-1)^2/3,  x < 0
     fx_pow<C>(FE_A, FE_F, C::COFACTOR, C::COFACTOR_BITS, FE_T0);   // a = f^c

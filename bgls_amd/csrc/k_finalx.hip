@@ -15,6 +15,7 @@ __global__ void __launch_bounds__(256) k_finalx(const uint8_t* partials, size_t 
   typedef FX<C> E;
   const int lane = threadIdx.x;
   const int order_pos[6] = {5, 2, 4, 1, 3, 0};
+  FX_T(0);
   // packed: verdict[0..2] = {verdict, this stage's flags, the caller's flag word} -- ONE copy back to the host instead of three and
   // no flag word to clear beforehand; else the verdict alone and the flags OR-ed into *flags
   bool bad = false;                                         // (no static LDS here: it would shift the 16-byte alignment of the slots)
@@ -29,6 +30,7 @@ __global__ void __launch_bounds__(256) k_finalx(const uint8_t* partials, size_t 
     if (k > 0) fx_mul<C>(FE_F, FE_F, FE_X);
   }
   if (do_final_exp) fx_final_exp<C>();
+  FX_T(8);
   bool is_one = true;
   if (lane < 6) {
     const X2<C, SX_T> x = fx_ld2<C>(E::coef(FE_F, lane, 0));
@@ -41,6 +43,7 @@ __global__ void __launch_bounds__(256) k_finalx(const uint8_t* partials, size_t 
     }
   }
   const unsigned long long ball = __ballot(is_one);       // wave 0 holds the six coefficients (the other lanes vote "one")
+  FX_T(11);
   const unsigned long long bball = __ballot(bad);           // lanes 0..5 of wave 0 parsed the partials
   if (lane == 0) {
     verdict[0] = (ball == ~0ull) ? 1u : 0u;
@@ -69,3 +72,6 @@ template void finalx<BN254>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, 
 template void finalx<BLS381>(hipStream_t, const uint8_t*, size_t, int, uint8_t*, uint32_t*, uint32_t*);
 }  // namespace kl
 }  // namespace bgls
+#ifdef FX_DBG
+extern "C" int bgls_dbg_fx_dump(unsigned long long* o) { return (int)hipMemcpyFromSymbol(o, HIP_SYMBOL(bgls::g_fx_t), sizeof(bgls::g_fx_t)); }
+#endif
