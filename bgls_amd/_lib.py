@@ -80,6 +80,7 @@ SIGNATURES = {
     "bgls_profile_enable": (ci, [ci]),
     "bgls_profile_get": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong)]),
     "bgls_probe_mad_peak": (ci, [ctypes.POINTER(ctypes.c_double)]),
+    "bgls_selftest_exception_barrier": (ci, [ci]),
 }
 
 _lib = None

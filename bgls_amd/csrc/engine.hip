@@ -27,6 +27,9 @@ typedef struct ncclComm* ncclComm_t;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include "dev_common.hpp"
 #include "coop.hpp"
 #include "coop_r28.hpp"
@@ -43,15 +46,36 @@ namespace {
 
 thread_local std::string g_err;
 
-int fail(int code, const char* what, hipError_t e = hipSuccess) {
+int fail(int code, const char* what, hipError_t e = hipSuccess) noexcept {
   char buf[256];
   if (e != hipSuccess)
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
   else
     snprintf(buf, sizeof buf, "%s", what);
-  g_err = buf;
+  try { g_err = buf; } catch (...) {}      // the message is best effort, the code is the contract
   return code;
 }
+
+// The exception barrier of the C ABI ("no exceptions, no abort()": include/bgls_hip.h; the reference never panics and returns
+// (nil, false): curves/curve.go:15-22).  Every extern "C" body below is a function-try-block ending in BGLS_ABI_GUARD: host
+// containers sized by the caller (std::vector), std::string, std::thread and std::shared_ptr can throw, and an exception must
+// not unwind into a cgo / ctypes frame.
+int abi_catch() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    return fail(BGLS_ERR_NOMEM, "out of host memory");
+  } catch (const std::length_error&) {
+    return fail(BGLS_ERR_NOMEM, "host container size limit");
+  } catch (const std::system_error& e) {
+    return fail(BGLS_ERR_HIP, e.what());
+  } catch (const std::exception& e) {
+    return fail(BGLS_ERR_ARG, e.what());
+  } catch (...) {
+    return fail(BGLS_ERR_ARG, "unknown C++ exception");
+  }
+}
+#define BGLS_ABI_GUARD catch (...) { return abi_catch(); }
 
 #define HIPCHK(expr)                                         \
   do {                                                       \
@@ -1953,11 +1977,17 @@ int for_each_shard(KeySet& ks, Fn&& fn) {
   std::vector<std::string> errs(S);
   const int base = g_sel;                 // the context the caller selected (bgls_select_context): shard s takes (base + s) mod NCTX,
   ks.base_ctx = base;                     // so a one-shard key set runs on the caller's context and threads on distinct contexts do not serialise
-  auto body = [&](int s) {
+  auto body = [&](int s) noexcept {        // runs on a thread of its own: nothing may leave it
     g_dev = ks.shards[s].device;
     g_sel = (base + s) % NCTX;
-    rcs[s] = fn(s);
-    if (rcs[s] < 0) errs[s] = g_err;
+    try {
+      rcs[s] = fn(s);
+    } catch (...) {
+      rcs[s] = abi_catch();
+    }
+    try {
+      if (rcs[s] < 0) errs[s] = g_err;
+    } catch (...) {}
   };
   if (S == 1) {
     const int pd = g_dev, ps = g_sel;
@@ -1966,7 +1996,13 @@ int for_each_shard(KeySet& ks, Fn&& fn) {
     g_sel = ps;
   } else {
     std::vector<std::thread> th;
-    for (int s = 0; s < S; ++s) th.emplace_back(body, s);
+    th.reserve(S);
+    int started = 0;
+    try {
+      for (; started < S; ++started) th.emplace_back(body, started);
+    } catch (...) {                        // a thread could not be created: the shards without one fail, the others are joined below
+      for (int s = started; s < S; ++s) rcs[s] = fail(BGLS_ERR_HIP, "could not start a shard's host thread");
+    }
     for (auto& t : th) t.join();
   }
   for (int s = 0; s < S; ++s)
@@ -2134,14 +2170,14 @@ int bgls_abi_version(void) { return 2; }
 
 const char* bgls_last_error(void) { return g_err.c_str(); }
 
-int bgls_init(int device) {
+int bgls_init(int device) try {
   if (device < 0 || device >= MAX_DEVICES) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
   g_default_device.store(device);
   g_dev = -1;
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   return c.enter();
-}
+} BGLS_ABI_GUARD
 
 size_t bgls_fp_size(int curve) { return curve == BGLS_CURVE_ALTBN128 ? 32 : curve == BGLS_CURVE_BLS12_381 ? 48 : 0; }
 size_t bgls_g1_size(int curve) { return 2 * bgls_fp_size(curve); }
@@ -2149,69 +2185,69 @@ size_t bgls_g2_size(int curve) { return 4 * bgls_fp_size(curve); }
 size_t bgls_gt_size(int curve) { return 12 * bgls_fp_size(curve); }
 
 int bgls_verify_aggregate(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
-                          size_t n, int allow_duplicates) {
+                          size_t n, int allow_duplicates) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_aggregate_t<CV>(sig, keys, msg_blob, msg_off, n, allow_duplicates));
-}
+} BGLS_ABI_GUARD
 
-int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+int bgls_verify_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_batch(int curve, const uint8_t* sigs, const uint8_t* keys, const uint64_t* key_off, size_t n_sets, const uint8_t* msg_blob,
-                            const uint64_t* msg_off, int allow_duplicates) {
+                            const uint64_t* msg_off, int allow_duplicates) try {
   if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!key_off || !msg_off || (n_sets && (!sigs || !msg_blob)) || (n_sets && key_off[n_sets] > key_off[0] && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_batch_t<CV>(sigs, keys, key_off, n_sets, msg_blob, msg_off, allow_duplicates));
-}
+} BGLS_ABI_GUARD
 
-int bgls_aggregate_sets(int curve, int group, const uint8_t* pts, const uint64_t* set_off, size_t n_sets, uint8_t* out) {
+int bgls_aggregate_sets(int curve, int group, const uint8_t* pts, const uint64_t* set_off, size_t n_sets, uint8_t* out) try {
   if (!group_ok(group) || !set_off || (n_sets && !out) || (n_sets && set_off[n_sets] > set_off[0] && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, aggregate_sets_t<CV>(group, pts, set_off, n_sets, out));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_batch_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
-                                const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) {
+                                const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) try {
   if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n_sets && (!d_sigs || !d_keys || !d_key_off || !d_msgs)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_batch_sub_t<CV>(d_sigs, d_keys, d_key_off, n_sets, max_set, d_msgs, msg_len, msg_stride, allow_duplicates, stream, false));
-}
+} BGLS_ABI_GUARD
 int bgls_verify_multi_batch_submit_dev(int curve, const void* d_sigs, const void* d_keys, const void* d_key_off, size_t n_sets, size_t max_set,
-                                       const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) {
+                                       const void* d_msgs, size_t msg_len, size_t msg_stride, int allow_duplicates, void* stream) try {
   if (n_sets >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n_sets && (!d_sigs || !d_keys || !d_key_off || !d_msgs)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_batch_sub_t<CV>(d_sigs, d_keys, d_key_off, n_sets, max_set, d_msgs, msg_len, msg_stride, allow_duplicates, stream, true));
-}
+} BGLS_ABI_GUARD
 
-int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) {
+int bgls_pairing_product(int curve, const uint8_t* g1s, const uint8_t* g2s, size_t n, uint8_t* gt_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!gt_out || (n && (!g1s || !g2s))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, pairing_product_t<CV>(g1s, g2s, n, gt_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out) {
+int bgls_hash_to_g1(int curve, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* g1_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n && (!msg_off || !g1_out)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, hash_to_g1_t<CV>(msg_blob, msg_off, n, g1_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+int bgls_aggregate_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || !out || (n && !pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, aggregate_points_t<CV>(group, pts, n, out));
-}
+} BGLS_ABI_GUARD
 
 int bgls_scale_points(int curve, int group, const uint8_t* pts, const uint8_t* scalars, const uint8_t* signs, size_t n,
-                      uint8_t* out) {
+                      uint8_t* out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, scale_points_t<CV>(group, pts, scalars, signs, n, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) try {
   if (!group_ok(group) || !a || !b || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   size_t pb = group == BGLS_G1 ? bgls_g1_size(curve) : bgls_g2_size(curve);
   if (!pb) return fail(BGLS_ERR_ARG, "unknown curve id");
@@ -2219,35 +2255,35 @@ int bgls_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uin
   memcpy(two.data(), a, pb);
   memcpy(two.data() + pb, b, pb);
   return bgls_aggregate_points(curve, group, two.data(), 2, out);
-}
+} BGLS_ABI_GUARD
 
-int bgls_point_check(int curve, int group, const uint8_t* a) {
+int bgls_point_check(int curve, int group, const uint8_t* a) try {
   if (!group_ok(group) || !a) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, point_check_t<CV>(group, a));
-}
+} BGLS_ABI_GUARD
 
-int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out) {
+int bgls_check_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* ok_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !ok_out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, check_points_t<CV>(group, pts, n, ok_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_select_device(int device) {
+int bgls_select_device(int device) try {
   if (device < -1 || device >= MAX_DEVICES) return fail(BGLS_ERR_NO_DEVICE, "device index out of range");
   g_dev = device;
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out) {
+int bgls_keys_upload(int curve, const uint8_t* keys, size_t n, const int* devices, int n_devices, unsigned flags, bgls_keys_t* handle_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!handle_out || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n_devices < 1 || n_devices > NCTX) return fail(BGLS_ERR_ARG, "n_devices out of range (1..16)");
   int dflt = cur_device();
   if (!devices && n_devices == 1) devices = &dflt;
   DISPATCH(curve, keys_upload_t<CV>(keys, n, devices, n_devices, flags, handle_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_keys_free(bgls_keys_t handle) {
+int bgls_keys_free(bgls_keys_t handle) try {
   std::shared_ptr<KeySet> ks;
   {
     std::lock_guard<std::mutex> lk(g_keys_mu);
@@ -2258,41 +2294,41 @@ int bgls_keys_free(bgls_keys_t handle) {
   }
   std::lock_guard<std::mutex> lk(ks->mu);      // wait for a verification in progress
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices) {
+int bgls_keys_info(bgls_keys_t handle, int* curve, size_t* n, int* n_devices) try {
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (curve) *curve = ks->curve;
   if (n) *n = ks->n;
   if (n_devices) *n_devices = (int)ks->shards.size();
   return 0;
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_aggregate_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
-                            int allow_duplicates) {
+                            int allow_duplicates) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (!sig || !msg_off) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(ks->curve, verify_aggregate_h_t<CV>(*ks, sig, msg_blob, msg_off, n, allow_duplicates, nullptr));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_aggregate_h_gt(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n,
-                               int allow_duplicates, uint8_t* gt_out) {
+                               int allow_duplicates, uint8_t* gt_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (!sig || !msg_off || !gt_out) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(ks->curve, verify_aggregate_h_t<CV>(*ks, sig, msg_blob, msg_off, n, allow_duplicates, gt_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_rccl_available(void) { return rccl().ok ? 1 : 0; }
+int bgls_rccl_available(void) try { return rccl().ok ? 1 : 0; } BGLS_ABI_GUARD
 
 // device-resident messages against a one-device key set, on the calling thread's context (several verifications in flight
 // on several contexts: the handle's resident arrays are read-only)
 int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n,
-                                 int check_duplicates, void* d_partial_out, void* d_flags, void* stream) {
+                                 int check_duplicates, void* d_partial_out, void* d_flags, void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
@@ -2325,7 +2361,7 @@ int bgls_miller_product_keys_dev(bgls_keys_t handle, const void* d_sig, const vo
   }
   g_dev = pd;
   return rc;
-}
+} BGLS_ABI_GUARD
 
 // verifyMultiSignature against a one-device key set with signature and message already on the device, on the calling thread's
 // context (several checks in flight on several contexts: the handle's resident arrays are read-only)
@@ -2356,22 +2392,22 @@ static int verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const vo
   g_dev = pd;
   return rc;
 }
-int bgls_verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) {
+int bgls_verify_multi_keys_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) try {
   return verify_multi_keys_dev(handle, d_sig, d_msg, msg_len, stream, false);
-}
-int bgls_verify_multi_keys_submit_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) {
+} BGLS_ABI_GUARD
+int bgls_verify_multi_keys_submit_dev(bgls_keys_t handle, const void* d_sig, const void* d_msg, size_t msg_len, void* stream) try {
   return verify_multi_keys_dev(handle, d_sig, d_msg, msg_len, stream, true);
-}
+} BGLS_ABI_GUARD
 
-int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len) {
+int bgls_verify_multi_h(bgls_keys_t handle, const uint8_t* sig, const uint8_t* msg, size_t msg_len) try {
   auto ks = keyset(handle);
   if (!ks) return fail(BGLS_ERR_ARG, "unknown key-set handle");
   if (!sig || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(ks->curve, verify_multi_h_t<CV>(*ks, sig, msg, msg_len));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
-                                size_t n, int allow_duplicates, const int* devices, int n_devices) {
+                                size_t n, int allow_duplicates, const int* devices, int n_devices) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
   // host keys arrive unvalidated here (no Point construction in between): the upload checks the order-r subgroup as the
@@ -2383,10 +2419,10 @@ int bgls_verify_aggregate_multi(int curve, const uint8_t* sig, const uint8_t* ke
   (void)bgls_keys_free(h);
   g_last_exchange = ex;
   return rc;
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len,
-                            const int* devices, int n_devices) {
+                            const int* devices, int n_devices) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   bgls_keys_t h;
   int rc = bgls_keys_upload(curve, keys, n, devices, n_devices, BGLS_KEYS_CHECK, &h);
@@ -2396,38 +2432,38 @@ int bgls_verify_multi_multi(int curve, const uint8_t* sig, const uint8_t* keys, 
   (void)bgls_keys_free(h);
   g_last_exchange = ex;
   return rc;
-}
+} BGLS_ABI_GUARD
 
 int bgls_last_exchange(void) { return g_last_exchange; }
 
-int bgls_generator(int curve, int group, uint8_t* out) {
+int bgls_generator(int curve, int group, uint8_t* out) try {
   if (!group_ok(group) || !out) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, generator_t<CV>(group, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out) {
+int bgls_pair(int curve, const uint8_t* g1, const uint8_t* g2, uint8_t* gt_out) try {
   return bgls_pairing_product(curve, g1, g2, 1, gt_out);
-}
+} BGLS_ABI_GUARD
 
-int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+int bgls_gt_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) try {
   if (!a || !b || !out) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, gt_mul_t<CV>(a, b, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_gt_pow(int curve, const uint8_t* gt, const uint8_t* k_be32, int negative, uint8_t* out) {
+int bgls_gt_pow(int curve, const uint8_t* gt, const uint8_t* k_be32, int negative, uint8_t* out) try {
   if (!gt || !k_be32 || !out) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, gt_pow_t<CV>(gt, k_be32, negative ? 1 : 0, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_gt_identity(int curve, uint8_t* out) {
+int bgls_gt_identity(int curve, uint8_t* out) try {
   size_t n = bgls_gt_size(curve);
   if (!n || !out) return fail(BGLS_ERR_ARG, "unknown curve id or NULL argument");
   memset(out, 0, n);
   out[n - 1] = 1;
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_profile_enable(int on) {
+int bgls_profile_enable(int on) try {
   Ctx* all = ctx_pool();
   for (int k = 0; k < MAX_DEVICES * NCTX; ++k) {
     Ctx& c = all[k];
@@ -2436,9 +2472,9 @@ int bgls_profile_enable(int on) {
     for (int i = 0; i < 8; ++i) { c.stage_ms[i] = 0; c.stage_cnt[i] = 0; }
   }
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches) {
+int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* launches) try {
   if (!stage || !total_ms || !launches) return fail(BGLS_ERR_ARG, "NULL argument");
   for (int i = 0; i < ST_NUM; ++i)
     if (!strcmp(stage, STAGE_NAMES[i])) {
@@ -2453,9 +2489,36 @@ int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* la
       return 0;
     }
   return fail(BGLS_ERR_ARG, "unknown stage name");
-}
+} BGLS_ABI_GUARD
 
-int bgls_probe_mad_peak(double* mac_per_s) {
+// Self-test of the exception barrier (no device needed): raises the named C++ exception inside a guarded body -- kind 0
+// std::bad_alloc, 1 std::length_error, 2 std::system_error, 3 std::runtime_error, 4 a non-standard object, 5 a vector whose
+// size no allocator can serve, 6 an exception on a shard's host thread -- and returns what the guard made of it.
+int bgls_selftest_exception_barrier(int kind) try {
+  switch (kind) {
+    case 0: throw std::bad_alloc();
+    case 1: throw std::length_error("selftest");
+    case 2: throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "selftest");
+    case 3: throw std::runtime_error("selftest");
+    case 4: throw 42;
+    case 5: {
+      std::vector<uint64_t> v((size_t)-1 / 16);
+      return (int)v.size();
+    }
+    case 6: {
+      KeySet ks;
+      ks.shards.resize(2);
+      ks.shards[0].device = ks.shards[1].device = 0;
+      return for_each_shard(ks, [&](int s) -> int {
+        if (s == 1) throw std::bad_alloc();
+        return 0;
+      });
+    }
+    default: return 0;
+  }
+} BGLS_ABI_GUARD
+
+int bgls_probe_mad_peak(double* mac_per_s) try {
   if (!mac_per_s) return fail(BGLS_ERR_ARG, "NULL argument");
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
@@ -2484,23 +2547,23 @@ int bgls_probe_mad_peak(double* mac_per_s) {
   (void)hipEventDestroy(b);
   *mac_per_s = best;
   return 0;
-}
+} BGLS_ABI_GUARD
 
 int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, const void* d_msgs, size_t msg_len,
                             size_t msg_stride, size_t n, int check_duplicates, void* d_partial_out, void* d_flags,
-                            void* stream) {
+                            void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_partial_out || !d_flags || (n && (!d_keys || (!d_msgs && msg_len)))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, miller_product_dev_t<CV>(d_sig, d_keys, d_msgs, msg_len, msg_stride, n, check_duplicates, d_partial_out,
                                            d_flags, stream));
-}
+} BGLS_ABI_GUARD
 
-int bgls_set_throughput_mode(int on) {
+int bgls_set_throughput_mode(int on) try {
   g_throughput.store(on ? 1 : 0);
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_set_miller_shape(int shape, int pairings_per_group) {
+int bgls_set_miller_shape(int shape, int pairings_per_group) try {
   if (shape < 0 || shape > 5 || pairings_per_group < 0 || pairings_per_group > 4096) return fail(BGLS_ERR_ARG, "bad Miller shape");
   if (shape >= 4) {                       // 4: k_miller_x60 always (second argument: mode word, see bgls_hip.h); 5: the 32-bit fused kernels always
     if (shape == 4 && (pairings_per_group > 31 || (pairings_per_group & 3) == 3)) return fail(BGLS_ERR_ARG, "bad k_miller_x60 mode word");
@@ -2513,45 +2576,45 @@ int bgls_set_miller_shape(int shape, int pairings_per_group) {
   g_shape.store(shape);
   g_ng.store(pairings_per_group);
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_set_msm_min(size_t n) {
+int bgls_set_msm_min(size_t n) try {
   g_msm_min.store(n);
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_weighted_sum_dev(int curve, int group, const void* d_pts, const void* d_w16, size_t n, void* d_out, void* stream) {
+int bgls_weighted_sum_dev(int curve, int group, const void* d_pts, const void* d_w16, size_t n, void* d_out, void* stream) try {
   if (group != BGLS_G1 && group != BGLS_G2) return fail(BGLS_ERR_ARG, "bad group");
   if (!d_out || (n && (!d_pts || !d_w16))) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   DISPATCH(curve, weighted_sum_dev_t<CV>(group, d_pts, d_w16, n, d_out, stream));
-}
+} BGLS_ABI_GUARD
 
-int bgls_select_context(int index) {
+int bgls_select_context(int index) try {
   if (index < 0 || index >= NCTX) return fail(BGLS_ERR_ARG, "context index out of range");
   g_sel = index;
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) try {
   if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, final_verify_submit_dev_t<CV>(d_partials, count, d_flags, stream));
-}
+} BGLS_ABI_GUARD
 
-int bgls_final_verify_collect(int curve) {
+int bgls_final_verify_collect(int curve) try {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   DISPATCH(curve, Engine<CV>::finalize_collect(c));
-}
+} BGLS_ABI_GUARD
 
-int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) {
+int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags, void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_flags || (n && !d_msgs && msg_len)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (n >= (1ull << 30)) return fail(BGLS_ERR_ARG, "too many messages for one scan");
   return duplicate_scan_dev(d_msgs, msg_len, msg_stride, n, d_flags, stream);
-}
+} BGLS_ABI_GUARD
 
-int bgls_message_digests_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_out16, void* stream) {
+int bgls_message_digests_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_out16, void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n && (!d_out16 || (!d_msgs && msg_len))) return fail(BGLS_ERR_ARG, "NULL argument");
   if (((uintptr_t)d_out16 & 15) != 0) return fail(BGLS_ERR_ARG, "digest buffer must be 16-byte aligned");
@@ -2565,92 +2628,92 @@ int bgls_message_digests_dev(const void* d_msgs, size_t msg_len, size_t msg_stri
   kl::msg_digest(st, mv, n, (uint8_t*)d_out16);
   HIPCHK(hipGetLastError());
   return 0;
-}
+} BGLS_ABI_GUARD
 
-int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) {
+int bgls_final_verify_dev(int curve, const void* d_partials, size_t count, const void* d_flags, void* stream) try {
   if (!d_partials || !count) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, final_verify_dev_t<CV>(d_partials, count, d_flags, stream));
-}
+} BGLS_ABI_GUARD
 
-int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream) {
+int bgls_aggregate_points_dev(int curve, int group, const void* d_pts, size_t n, void* d_out, void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || !d_out || (n && !d_pts)) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, aggregate_points_dev_t<CV>(group, d_pts, n, d_out, stream));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
-                          void* stream) {
+                          void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_submit_dev(int curve, const void* d_sig, const void* d_keys, size_t n, const void* d_msg, size_t msg_len,
-                                 void* stream) {
+                                 void* stream) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!d_sig || (n && !d_keys) || (msg_len && !d_msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_dev_entry_t<CV>(d_sig, d_keys, n, d_msg, msg_len, stream, true));
-}
+} BGLS_ABI_GUARD
 
 /* ---- hashed aggregation exponents (bgls/blsHAE.go) and multiplicities (bgls/blsKosk.go:137-150) ---- */
-int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out) {
+int bgls_hae_exponents(int curve, const uint8_t* keys, size_t n, uint8_t* t_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (n && (!keys || !t_out)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, hae_exponents_t<CV>(keys, n, t_out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) {
+int bgls_aggregate_signatures_hae(int curve, const uint8_t* sigs, const uint8_t* keys, size_t n, uint8_t* out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!out || (n && (!sigs || !keys))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, aggregate_signatures_hae_t<CV>(sigs, keys, n, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) {
+int bgls_verify_multi_hae(int curve, const uint8_t* sig, const uint8_t* keys, size_t n, const uint8_t* msg, size_t msg_len) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, nullptr, n, msg, msg_len));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_aggregate_hae(int curve, const uint8_t* sig, const uint8_t* keys, const uint8_t* msg_blob, const uint64_t* msg_off,
-                              size_t n) {
+                              size_t n) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || !msg_off || (n && !keys)) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, verify_aggregate_hae_t<CV>(sig, keys, msg_blob, msg_off, n));
-}
+} BGLS_ABI_GUARD
 
 int bgls_verify_multi_multiplicity(int curve, const uint8_t* sig, const uint8_t* keys, const int64_t* multiplicity, size_t n,
-                                   const uint8_t* msg, size_t msg_len) {
+                                   const uint8_t* msg, size_t msg_len) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!sig || (n && !keys) || (msg_len && !msg)) return fail(BGLS_ERR_ARG, "NULL argument");
   if (!multiplicity) DISPATCH(curve, verify_multi_t<CV>(sig, keys, n, msg, msg_len));
   DISPATCH(curve, verify_multi_weighted_t<CV>(sig, keys, multiplicity, n, msg, msg_len));
-}
+} BGLS_ABI_GUARD
 
 /* ---- compressed wire formats (alt-bn128; curves/altbn128.go:81-89,203-221,296-376) ---- */
-int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) {
+int bgls_compress_points(int curve, int group, const uint8_t* pts, size_t n, uint8_t* out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!pts || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   return wire_points(curve, group, true, pts, n, out, nullptr);
-}
+} BGLS_ABI_GUARD
 
-int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+int bgls_decompress_points(int curve, int group, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!in || !out || !ok))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   return wire_points(curve, group, false, in, n, out, ok);
-}
+} BGLS_ABI_GUARD
 
 /* ---- batch key generation / signing (bgls/bgls.go:40-56) ---- */
-int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out) {
+int bgls_scale_generator(int curve, int group, const uint8_t* scalars, size_t n, uint8_t* out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!group_ok(group) || (n && (!scalars || !out))) return fail(BGLS_ERR_ARG, "bad group or NULL argument");
   DISPATCH(curve, scale_generator_t<CV>(group, scalars, n, out));
-}
+} BGLS_ABI_GUARD
 
-int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* sigs_out) {
+int bgls_sign_batch(int curve, const uint8_t* sks, const uint8_t* msg_blob, const uint64_t* msg_off, size_t n, uint8_t* sigs_out) try {
   if (n >= MAX_BATCH) return fail(BGLS_ERR_ARG, "batch too large (n must be below 2^30)");
   if (!msg_off || (n && (!sks || !sigs_out))) return fail(BGLS_ERR_ARG, "NULL argument");
   DISPATCH(curve, sign_batch_t<CV>(sks, msg_blob, msg_off, n, sigs_out));
-}
+} BGLS_ABI_GUARD
 
 }  // extern "C"
 

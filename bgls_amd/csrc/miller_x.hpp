@@ -21,6 +21,7 @@
 // Replaces the n calls of CurveSystem.Pair behind PairingProduct: curves/curve.go:125-170, curves/altbn128.go:130-145,
 // curves/bls12_381.go:228-240.
 #pragma once
+#include <type_traits>
 #include "dev_common.hpp"
 #include "coop.hpp"
 #include "rx_pair.hpp"
@@ -45,6 +46,16 @@ namespace bgls {
 // NP = pairings per block: 60 (six lines per group and step) or 64 (all 32 lane pairs of both producer waves: groups 0..3 take
 // a seventh line, the other groups' seventh line is the constant 1) -- 1024 resident blocks of the 64-form are exactly 2^16
 // pairings, the batch a lone VerifyAggregateSignature of BASELINE configs 2 / 3 submits.
+// The number form a curve's kernel runs on: alt-bn128 on nine limbs of 29 bits (BN254W, round 5: 81 instead of 100 multiplier
+// instructions per limb product), BLS12-381 on fourteen of 28 (thirteen of 30 leave no head-room in a 64-bit column at all).
+// -DMX_BN_W28 keeps alt-bn128 on ten limbs of 28 bits (A/B measurements).
+template <class C>
+struct MxForm { typedef C type; };
+#ifndef MX_BN_W28
+template <>
+struct MxForm<BN254> { typedef BN254W type; };
+#endif
+
 template <class C, int NP = 60>
 struct MX {
   static_assert(NP == 60 || NP == 64, "pairings per block");
@@ -101,8 +112,10 @@ __device__ __forceinline__ Ux<C> mx_ld_half(int off, bool second) {
 #pragma unroll
     for (int k = 0; k < (N + 3) / 4; ++k) {
       const uint4 v = mx_ld16(off + 4 * k);
-      r.v[4 * k] = v.x; r.v[4 * k + 1] = v.y;
-      if (4 * k + 2 < N) { r.v[4 * k + 2] = v.z; r.v[4 * k + 3] = v.w; }
+      r.v[4 * k] = v.x;
+      if (4 * k + 1 < N) r.v[4 * k + 1] = v.y;
+      if (4 * k + 2 < N) r.v[4 * k + 2] = v.z;
+      if (4 * k + 3 < N) r.v[4 * k + 3] = v.w;
     }
   } else {
     static_assert(!PACKED || N % 4 == 2, "packed halves: NL = 2 mod 4");
@@ -134,6 +147,8 @@ __device__ __forceinline__ void mx_st_half(int off, bool second, const Ux<C>& a)
 #pragma unroll
     for (int k = 0; k < N / 4; ++k) p[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
     if constexpr (N % 4 == 2) *reinterpret_cast<uint2*>(lds + off + (N & ~3)) = make_uint2(a.v[N - 2], a.v[N - 1]);
+    if constexpr (N % 4 == 1) lds[off + N - 1] = a.v[N - 1];
+    static_assert(N % 4 != 3, "tail store");
   } else {
     *reinterpret_cast<uint2*>(lds + off) = make_uint2(a.v[0], a.v[1]);
     uint4* p = reinterpret_cast<uint4*>(lds + off + 2);
@@ -194,6 +209,38 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) {
       });
 }
 
+// The 29-bit form's squaring (rx.hpp ux_sqr_dot3): the row's doubled slots and its plain slots as two piles.  The split of the
+// row is a per-lane constant, made once before the step loop: dsl = up to three table bytes (0xff = unused), psl = up to two.
+__device__ __forceinline__ void mx_sq_split(unsigned row, unsigned& dsl, unsigned& psl) {
+  dsl = 0xffffffu;
+  psl = 0xffffu;
+  int nd = 0, np = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned e = (row >> (8 * t)) & 0xFFu;
+    if ((e & 7u) == 7u) continue;
+    if (e & 0x80u) { dsl = (dsl & ~(0xFFu << (8 * nd))) | (e << (8 * nd)); ++nd; }
+    else { psl = (psl & ~(0xFFu << (8 * np))) | (e << (8 * np)); ++np; }
+  }
+}
+template <class C, int NP>
+__device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned dsl, unsigned psl) {
+  typedef MX<C, NP> K;
+  auto fetch = [&](unsigned sl, int t, int side, int h) __attribute__((always_inline)) {
+    const unsigned e = (sl >> (8 * t)) & 0xFFu;
+    const bool unused = (e & 7u) == 7u;
+    const int i = unused ? 0 : (int)(e & 7u), k = unused ? 0 : (int)((e >> 3) & 7u), wrap = unused ? 0 : (int)((e >> 6) & 1u);
+    Ux<C> a = mx_ld_half<C, K::PACKED>(gb + (side == 0 ? K::acc_off(i, 0) : K::acc_off(k, wrap)) + h * K::HS, h != 0);
+    if (side == 0) {                                      // an unused slot's product vanishes with its left operand
+      const u32 keep = unused ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < C::RX_NL; ++q) a.v[q] &= keep;
+    }
+    return a;
+  };
+  return ux_sqr_dot3<C>([&](int t, int side, int h) { return fetch(dsl, t, side, h); }, [&](int t, int side, int h) { return fetch(psl, t, side, h); });
+}
+
 // A producer lane's parked values: its own region of the workspace, NPARK slots of HS dwords (16-byte aligned), moved with
 // 16-byte accesses off ONE address register.  (A lane-interleaved layout coalesces better but needs a separate 64-bit
 // address per limb -- the element stride exceeds the instructions' immediate offsets -- and those addresses cost more
@@ -207,6 +254,7 @@ struct MxPark {
 #pragma unroll
     for (int k = 0; k < NL / 4; ++k) p[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
     if constexpr (NL % 4 == 2) *reinterpret_cast<uint2*>(lane_base + slot * HS + (NL & ~3)) = make_uint2(v[NL - 2], v[NL - 1]);
+    if constexpr (NL % 4 == 1) lane_base[slot * HS + NL - 1] = v[NL - 1];
   }
   static __device__ __forceinline__ void ld_raw(const u32* lane_base, int slot, u32 (&v)[NL]) {
     const uint4* p = reinterpret_cast<const uint4*>(lane_base + slot * HS);
@@ -219,6 +267,7 @@ struct MxPark {
       const uint2 q = *reinterpret_cast<const uint2*>(lane_base + slot * HS + (NL & ~3));
       v[NL - 2] = q.x; v[NL - 1] = q.y;
     }
+    if constexpr (NL % 4 == 1) v[NL - 1] = lane_base[slot * HS + NL - 1];
   }
   static __device__ __forceinline__ void st(u32* base, int slot, const Sx<C, SX_T>& a) {
     u32 w[NL];
@@ -368,7 +417,9 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
     Ux<C> e[3];
     auto emit = [&](int which, const auto& v) __attribute__((always_inline)) {
       const int entry = which == 1 ? 1 : ((which == 0) == C::TWIST_D ? 0 : 2);     // D-type: c0 yP, c1 xP, c2;  M-type: c2, c1 xP, c0 yP
-      e[entry] = sx_to_ux<C>(v);
+      if constexpr (rx_lazy<C>) e[entry] = sx_to_ux<C>(v);
+      else if constexpr (std::is_same<std::decay_t<decltype(v)>, Sx<C, SX_T>>::value) e[entry] = sx_to_ux_p<C>(v);    // a reduction's output: + p, below 2.1 p
+      else e[entry] = sx_to_ux_k<1, C>(v);              // the P-free coefficient, a difference of two reductions' outputs: + 2 p, below 3.1 p
     };
     auto hand_over = [&]() __attribute__((always_inline)) {
       if (DBG == 2 || !valid) {           // the constant line 1
@@ -452,6 +503,8 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
       }
     }
     mx_publish<C, NP>(gb, j, fj, live);
+    unsigned sq_d = 0, sq_p = 0;
+    if constexpr (!rx_lazy<C>) mx_sq_split(COOP_SQ_TAB[j], sq_d, sq_p);
     auto fold_all = [&]() __attribute__((always_inline)) {
       if constexpr (DBG == 1) return;
 #pragma unroll 1
@@ -464,7 +517,8 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       __syncthreads();                    // A
       if (DBG != 1 && i > 1) {            // f = 1 before the first step
-        fj = mx_sqr<C, NP>(gb, j);
+        if constexpr (rx_lazy<C>) fj = mx_sqr<C, NP>(gb, j);
+        else fj = mx_sqr3<C, NP>(gb, sq_d, sq_p);
         mx_publish<C, NP>(gb, j, fj, live);
       }
       __syncthreads();                    // B
@@ -484,6 +538,7 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
       }
     }
     if (live) {
+      if constexpr (!rx_lazy<C>) fj = ux_quasi<C, 2, 1>(fj);        // the folds' fixed point is 3.7 p; from_ux_inl takes values below 4 p
       Fp2<C> r = {from_ux_inl<C>(fj.c0), from_ux_inl<C>(fj.c1)};
       if constexpr (C::CURVE_ID != 0) {
         if (j & 1) r = f2_neg<C>(r);                      // x < 0: f^(p^6), w -> -w

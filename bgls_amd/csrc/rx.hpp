@@ -25,7 +25,17 @@ namespace bgls {
 
 typedef int32_t i32;
 typedef int64_t i64;
-constexpr u32 RX_MASK = (1u << 28) - 1;
+// limb width: C::RX_W bits (28 everywhere but the alt-bn128 Miller kernel's form BN254W: nine limbs of 29 bits, round 5), mask C::RX_MASK
+constexpr u32 RX_MASK = (1u << 28) - 1;      // the 28-bit forms' mask, for the headers that only exist on them (rx_pow.hpp, finalx.hpp)
+// "lazy" forms leave 2^8 of head-room in a 64-bit column (W = 28): six term-equivalents per pile, products of sums, four
+// products per interleaved reduction.  The 29-bit form has 2^6: three-term piles of TIGHT operands only (63 of the 64 units of
+// 2^58 a column holds: tools/gen_constants.py), and its Montgomery radix is only 169 p, so values are kept small explicitly
+// (ux_quasi) where the 28-bit forms simply never get near R'.
+template <class C>
+constexpr bool rx_lazy = 2 * C::RX_W + 8 <= 64;
+// does an interleaved product with this bound sum (units 2^(2 W - 8)) fit the signed 64-bit columns?  (MontAcc below)
+template <class C>
+constexpr bool rx_fits(long long budget) { return (long long)C::RX_NL * (budget + 256) + 64 < (1ll << (71 - 2 * C::RX_W)); }
 
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(BGLS_RX_CHECK)
 extern int g_rx_overflow;
@@ -191,11 +201,13 @@ BGLS_HD void ux_acc_new(u64 (&c)[2 * C::RX_NL], const Ux<C>& a, const Ux<C>& b) 
 template <class C>
 BGLS_HD Ux<C> ux_redc(u64 (&c)[2 * C::RX_NL]) {
   constexpr int N = C::RX_NL;
+  constexpr int W = C::RX_W;
+  constexpr u32 RX_MASK = C::RX_MASK;
   u32 m = ((u32)c[0] * C::RX_NP) & RX_MASK;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     rx_rowu_blk<2, true>(c + i, m, C::RX_P);
-    c[i + 1] += c[i] >> 28;
+    c[i + 1] += c[i] >> W;
     const u32 m_next = ((u32)c[i + 1] * C::RX_NP) & RX_MASK;
     rx_rowu<N - 2, true>(c + i + 2, m, C::RX_P + 2);
     m = m_next;
@@ -204,7 +216,7 @@ BGLS_HD Ux<C> ux_redc(u64 (&c)[2 * C::RX_NL]) {
 #pragma unroll
   for (int k = N; k < 2 * N - 1; ++k) {
     r.v[k - N] = (u32)c[k] & RX_MASK;
-    c[k + 1] += c[k] >> 28;
+    c[k + 1] += c[k] >> W;
   }
   r.v[N - 1] = (u32)c[2 * N - 1];
   return r;
@@ -218,25 +230,77 @@ BGLS_HD Ux<C> ux_norm(const Ux<C>& a) {
 #pragma unroll
   for (int i = 0; i < C::RX_NL - 1; ++i) {
     const u32 t = a.v[i] + c;
-    r.v[i] = t & RX_MASK;
-    c = t >> 28;
+    r.v[i] = t & C::RX_MASK;
+    c = t >> C::RX_W;
   }
   r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + c;
   return r;
 }
 
 // xi * a, normalised; a tight with value < 2 p (a reduction's output); the result is tight, non-negative and below 32 p.  alt-bn128: xi = 9 + i; BLS12-381: 1 + i.
+// 29-bit form: 9 a_i leaves 32 bits, so the carry runs through 64-bit sums limb by limb; a below 3.7 p gives a result below 39 p
+// (the consumer's fixed point, miller_x.hpp) -- values only have to stay below RX_VBND p = 128 p.
 template <class C>
 BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
   Ux2<C> r;
+  if constexpr ((long long)(C::XI_RE + 3) << C::RX_W <= (1ll << 32)) {
 #pragma unroll
-  for (int i = 0; i < C::RX_NL; ++i) {
-    r.c0.v[i] = (u32)C::XI_RE * a.c0.v[i] + (C::RX_FAT[i] - a.c1.v[i]);
-    r.c1.v[i] = (u32)C::XI_RE * a.c1.v[i] + a.c0.v[i];
+    for (int i = 0; i < C::RX_NL; ++i) {
+      r.c0.v[i] = (u32)C::XI_RE * a.c0.v[i] + (C::RX_FAT[i] - a.c1.v[i]);
+      r.c1.v[i] = (u32)C::XI_RE * a.c1.v[i] + a.c0.v[i];
+    }
+    r.c0 = ux_norm<C>(r.c0);
+    r.c1 = ux_norm<C>(r.c1);
+  } else {
+    u64 c0 = 0, c1 = 0;
+#pragma unroll
+    for (int i = 0; i < C::RX_NL - 1; ++i) {
+      const u64 t0 = (u64)(u32)C::XI_RE * a.c0.v[i] + (u64)(C::RX_FAT[i] - a.c1.v[i]) + c0;
+      const u64 t1 = (u64)(u32)C::XI_RE * a.c1.v[i] + (u64)a.c0.v[i] + c1;
+      r.c0.v[i] = (u32)t0 & C::RX_MASK;
+      r.c1.v[i] = (u32)t1 & C::RX_MASK;
+      c0 = t0 >> C::RX_W;
+      c1 = t1 >> C::RX_W;
+    }
+    constexpr int T = C::RX_NL - 1;                       // top limbs are small (value < 128 p): 32-bit arithmetic
+    r.c0.v[T] = (u32)C::XI_RE * a.c0.v[T] + (C::RX_FAT[T] - a.c1.v[T]) + (u32)c0;
+    r.c1.v[T] = (u32)C::XI_RE * a.c1.v[T] + a.c0.v[T] + (u32)c1;
   }
-  r.c0 = ux_norm<C>(r.c0);
-  r.c1 = ux_norm<C>(r.c1);
   return r;
+}
+
+// Quasi-reduction (29-bit form): subtract 2^k p, k = KHI .. KLO, wherever the top limb shows that the value is above it, then one
+// carry pass.  a: non-negative limbs below 2^31 - 2^(W+2) (a few tight values added up), any value below 2^(KHI+1) p; the result
+// is tight and below 2^KLO p + 8 * 2^(W (NL-1))  (= 2^KLO p (1 + 2^-19)).  The margin of 5 on the top limb covers the lower limbs
+// going negative by the constants of the levels already subtracted (at most four levels).
+template <class C, int KHI, int KLO>
+BGLS_HD Ux<C> ux_quasi(const Ux<C>& a) {
+  constexpr int N = C::RX_NL;
+  static_assert(KLO >= 1 && KHI <= 6 && KHI - KLO <= 3, "ladder levels");
+  i32 t[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = (i32)a.v[i];
+#pragma unroll
+  for (int k = KHI; k >= KLO; --k) {
+    const u32* L = C::RX_LAD + (k - 1) * N;
+    const i32 hit = t[N - 1] >= (i32)L[N - 1] + 5 ? -1 : 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] -= (i32)L[i] & hit;
+  }
+  Ux<C> r;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    const i32 s = t[i] + c;
+    r.v[i] = (u32)(s & (i32)C::RX_MASK);
+    c = s >> C::RX_W;
+  }
+  r.v[N - 1] = (u32)(t[N - 1] + c);
+  return r;
+}
+template <class C, int KHI, int KLO>
+BGLS_HD Ux2<C> ux_quasi(const Ux2<C>& a) {
+  return {ux_quasi<C, KHI, KLO>(a.c0), ux_quasi<C, KHI, KLO>(a.c1)};
 }
 
 // ---- the consumer's dot products.  Operands are fetched through functors (LDS on the device, arrays in the unit tests):
@@ -344,6 +408,7 @@ BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
 template <class C, class KD, class LA, class LB>
 BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
   constexpr int N = C::RX_NL;
+  static_assert(rx_lazy<C>, "six term-equivalents per pile: 28-bit forms only (the 29-bit form squares with ux_sqr_dot3)");
   u64 d[2 * N], e[2 * N];
   auto scaled = [&](int t, int h) __attribute__((always_inline)) {       // left operand: doubled or masked out
     const int kd = kind(t);
@@ -418,6 +483,25 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
   return r;
 }
 
+// The symmetric squaring on the 29-bit form: a pile holds three term-equivalents, so the row's doubled products (at most three,
+// accumulated UNdoubled) and its plain products (at most two) are two three-term dot products and
+//   c = 2 * reduce(doubled) + reduce(plain),    then a quasi-reduction back below 4 p
+// (operands below 3.7 p / 39 p: the doubled pile reduces below 6 p, the plain one below 4.4 p, c below 17 p).  Five slot products
+// and four reductions per lane against the 28-bit form's four and two, on 81 instead of 100 multiplier instructions each.
+//   ldd(t, side, h): slot t < 3 of the doubled pile, side 0 / 1 = left / right operand, half h; zeros for an unused slot.  ldp: the plain pile (t < 2).
+template <class C, class LD, class LP>
+BGLS_HD Ux2<C> ux_sqr_dot3(LD&& ldd, LP&& ldp) {
+  const Ux2<C> d = ux_dot_k2p<C, 3>([&](int t, int h) { return ldd(t, 0, h); }, [&](int t, int h) { return ldd(t, 1, h); });
+  const Ux2<C> p = ux_dot_k2p<C, 2>([&](int t, int h) { return ldp(t, 0, h); }, [&](int t, int h) { return ldp(t, 1, h); });
+  Ux2<C> s;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) {
+    s.c0.v[i] = 2 * d.c0.v[i] + p.c0.v[i];
+    s.c1.v[i] = 2 * d.c1.v[i] + p.c1.v[i];
+  }
+  return ux_quasi<C, 4, 2>(s);
+}
+
 // ---- conversions between the library's form (32-bit limbs, Montgomery radix R = 2^(32 L)) and this one
 // x R (reduced, 32-bit limbs) -> x R' (tight, value < 2 p): split into 28-bit limbs, one product by R'^2 / R
 template <class C>
@@ -426,10 +510,10 @@ BGLS_HD Ux<C> to_ux(const Fp<C>& y) {
   Ux<C> s;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int lo = 28 * i, q = lo >> 5, r = lo & 31;
+    const int lo = C::RX_W * i, q = lo >> 5, r = lo & 31;
     u64 two = q < C::L ? (u64)y.v[q] : 0;
     if (q + 1 < C::L) two |= (u64)y.v[q + 1] << 32;
-    s.v[i] = (u32)(two >> r) & RX_MASK;
+    s.v[i] = (u32)(two >> r) & C::RX_MASK;
   }
   u64 c[2 * N];
   ux_acc_new<C>(c, s, ux_load<C>(C::RX_TO));
@@ -448,11 +532,11 @@ BGLS_HD Fp<C> from_ux(const Ux<C>& a) {
 #pragma unroll
   for (int k = 0; k <= L; ++k) {
     const int lo = 32 * k;
-    const int i = lo / 28, r = lo % 28;
+    const int i = lo / C::RX_W, r = lo % C::RX_W;
     u64 acc = 0;
     if (i < N) acc = (u64)a.v[i] >> r;
-    int have = 28 - r;
-    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += 28; }
+    int have = C::RX_W - r;
+    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += C::RX_W; }
     if (have < 32 && i + 2 < N) acc |= (u64)a.v[i + 2] << have;
     w[k] = (u32)acc;
   }
@@ -545,8 +629,8 @@ BGLS_HD Sx<C, SX_T> sx_norm(const Sx<C, LA>& a) {
 #pragma unroll
   for (int i = 0; i < C::RX_NL - 1; ++i) {
     const i32 t = a.v[i] + c;
-    r.v[i] = t & (i32)RX_MASK;
-    c = t >> 28;
+    r.v[i] = t & (i32)C::RX_MASK;
+    c = t >> C::RX_W;
   }
   r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + c;
   return r;
@@ -556,10 +640,12 @@ template <class C, int LA>
 BGLS_HD Sx<C, SX_F> sx_normf(const Sx<C, LA>& a) {
   static_assert(LA < 128, "limb leaves 31 bits");
   Sx<C, SX_F> r;
-  r.v[0] = a.v[0] & (i32)RX_MASK;
+  constexpr int W = C::RX_W;
+  constexpr i32 RX_MASK = (i32)C::RX_MASK;
+  r.v[0] = a.v[0] & RX_MASK;
 #pragma unroll
-  for (int i = 1; i < C::RX_NL - 1; ++i) r.v[i] = (a.v[i] & (i32)RX_MASK) + (a.v[i - 1] >> 28);
-  r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + (a.v[C::RX_NL - 2] >> 28);
+  for (int i = 1; i < C::RX_NL - 1; ++i) r.v[i] = (a.v[i] & RX_MASK) + (a.v[i - 1] >> W);
+  r.v[C::RX_NL - 1] = a.v[C::RX_NL - 1] + (a.v[C::RX_NL - 2] >> W);
   return r;
 }
 // a / 2 mod p: add p when odd (the parity of the value is the parity of limb 0), then shift every limb, the dropped bit of
@@ -573,7 +659,7 @@ BGLS_HD Sx<C, (LA + 16 + 1) / 2 + 8> sx_half(const Sx<C, LA>& a) {
   for (int i = 0; i < N; ++i) t[i] = a.v[i] + ((i32)C::RX_P[i] & odd);
   Sx<C, (LA + 16 + 1) / 2 + 8> r;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> 1) + (i + 1 < N ? (t[i + 1] & 1) << 27 : 0);
+  for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> 1) + (i + 1 < N ? (t[i + 1] & 1) << (C::RX_W - 1) : 0);
   return r;
 }
 
@@ -586,7 +672,8 @@ BGLS_HD Sx<C, (LA + 16 + 1) / 2 + 8> sx_half(const Sx<C, LA>& a) {
 // and the carries; the total must stay below 2^63.
 template <class C, int B>
 struct MontAcc {
-  static_assert((long long)C::RX_NL * (B + 256) + 64 < 32768, "column budget (signed 64-bit)");
+  // units 2^(2 W - 8) (bounds count 2^(W - 4)): NL rows of the products' bounds plus the reduction's own 2^(2 W) and the carries, below 2^63
+  static_assert((long long)C::RX_NL * (B + 256) + 64 < (1ll << (71 - 2 * C::RX_W)), "column budget (signed 64-bit)");
 };
 // NP products (1..4).  cols[k] = the limbs of product k's COLUMN factor (register-resident); row(k, i) = limb i of its ROW
 // factor, produced where it is used -- the point steps derive it from a neighbour lane's register, so a row factor never
@@ -610,21 +697,21 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
     else rx_macs(t[i], r[0], cols[0][0]);
 #pragma unroll
     for (int k = 1; k < NP; ++k) rx_macs(t[i], r[k], cols[k][0]);
-    const i32 m = (i32)(((u32)t[i] * C::RX_NP) & RX_MASK);
+    const i32 m = (i32)(((u32)t[i] * C::RX_NP) & C::RX_MASK);
     if (i == 0) rx_rows_new<N - 1, 1>(t + 1, r[0], cols[0] + 1);
     else rx_rows_new<N - 1, 2>(t + i + 1, r[0], cols[0] + 1);
 #pragma unroll
     for (int k = 1; k < NP; ++k) rx_rows<N - 1, false>(t + i + 1, r[k], cols[k] + 1);
     rx_rows<N, true>(t + i, m, (const i32*)C::RX_P);
-    t[i + 1] += t[i] >> 28;
+    t[i + 1] += t[i] >> C::RX_W;
   }
   Sx<C, SX_T> r;
 #pragma unroll
   for (int k = N; k < 2 * N - 1; ++k) {
-    r.v[k - N] = (i32)((u32)t[k] & RX_MASK);
-    if (k + 1 < 2 * N - 1) t[k + 1] += t[k] >> 28;
+    r.v[k - N] = (i32)((u32)t[k] & C::RX_MASK);
+    if (k + 1 < 2 * N - 1) t[k + 1] += t[k] >> C::RX_W;
   }
-  r.v[N - 1] = (i32)(t[2 * N - 2] >> 28);     // column 2 NL - 1 receives this carry and nothing else
+  r.v[N - 1] = (i32)(t[2 * N - 2] >> C::RX_W);     // column 2 NL - 1 receives this carry and nothing else
   return r;
 }
 
@@ -657,10 +744,28 @@ BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y);
 template <class C, int LA>
 BGLS_HD Ux<C> sx_to_ux(const Sx<C, LA>& a) {
   constexpr int K = (LA + 15) / 16;
-  static_assert(K >= 1 && K <= 8, "fat constants cover limbs below 8 * 2^28");
+  static_assert(K >= 1 && K <= C::RX_FAT_KMAX, "fat constants cover limbs below RX_FAT_KMAX * 2^W");
   Ux<C> t;
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) t.v[i] = (u32)((i32)C::RX_FAT[(K - 1) * C::RX_NL + i] + a.v[i]);
+  return ux_norm<C>(t);
+}
+// the same with the fat multiple chosen by the caller: K 2^W must dominate the limbs' magnitudes (a difference of two tight
+// non-negative values has limbs inside (-2^W, 2^W) whatever its static bound says) and K RX_FAT_VB p the value's negative side
+template <int K, class C, int LA>
+BGLS_HD Ux<C> sx_to_ux_k(const Sx<C, LA>& a) {
+  static_assert(K >= 1 && K <= C::RX_FAT_KMAX, "fat constants");
+  Ux<C> t;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) t.v[i] = (u32)((i32)C::RX_FAT[(K - 1) * C::RX_NL + i] + a.v[i]);
+  return ux_norm<C>(t);
+}
+// a reduction's output (limbs 0..NL-2 non-negative, value above -p): adding p itself makes it non-negative; result below value + p
+template <class C>
+BGLS_HD Ux<C> sx_to_ux_p(const Sx<C, SX_T>& a) {
+  Ux<C> t;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) t.v[i] = (u32)((i32)C::RX_P[i] + a.v[i]);
   return ux_norm<C>(t);
 }
 template <class C>
@@ -684,10 +789,10 @@ BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y) {
   i32 s[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int lo = 28 * i, q = lo >> 5, r = lo & 31;
+    const int lo = C::RX_W * i, q = lo >> 5, r = lo & 31;
     u64 two = q < C::L ? (u64)y.v[q] : 0;
     if (q + 1 < C::L) two |= (u64)y.v[q + 1] << 32;
-    s[i] = (i32)((u32)(two >> r) & RX_MASK);
+    s[i] = (i32)((u32)(two >> r) & C::RX_MASK);
   }
   const Sx<C, SX_T> k = sx_const<C>(C::RX_R2);
   const i32* const cols[1] = {k.v};
@@ -704,11 +809,11 @@ BGLS_HD Fp<C> from_ux_inl(const Ux<C>& a) {
 #pragma unroll
   for (int k = 0; k <= L; ++k) {
     const int lo = 32 * k;
-    const int i = lo / 28, r = lo % 28;
+    const int i = lo / C::RX_W, r = lo % C::RX_W;
     u64 acc = 0;
     if (i < N) acc = (u64)a.v[i] >> r;
-    int have = 28 - r;
-    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += 28; }
+    int have = C::RX_W - r;
+    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += C::RX_W; }
     if (have < 32 && i + 2 < N) acc |= (u64)a.v[i + 2] << have;
     w[k] = (u32)acc;
   }

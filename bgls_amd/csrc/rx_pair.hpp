@@ -76,14 +76,19 @@ RX_DEV Sx<C, SX_T> pair_mul_const(const Sx<C, LA>& a, const u32* k_re, const u32
   return sx_montr<C, 2, 2 * LA * SX_T>(cols, [&](int k, int i) { return (i32)(k == 0 ? k_re[i] : k_im[i]); });
 }
 // own half of a^2:  (a0 + a1)(a0 - a1)  |  2 a1 a0
+// Column budget: 2 LA x 2 LA in general.  The 29-bit form has no room for that and does not need it: every value squared in the
+// point steps is a reduction's output or one parallel carry step behind a sum (limbs 0..NL-2 non-negative up to 2^4: LA <= SX_F),
+// so the DIFFERENCE a0 - a1 stays inside LA + 1 and only the sum doubles.
 template <class C, int LA>
 RX_DEV Sx<C, SX_T> pair_sqr(const Sx<C, LA>& a, bool odd) {
+  static_assert(rx_lazy<C> || LA <= SX_F, "29-bit form: squares of (nearly) non-negative limbs only");
+  constexpr int BUDGET = rx_lazy<C> ? 4 * LA * LA : 2 * LA * (LA + 1);
   Sx<C, 2 * LA> u;                                            // a0 + a1 | 2 a1
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) u.v[i] = a.v[i] + pair_odd1(a.v[i], odd);
   const i32 even = odd ? 0 : -1;
   const i32* const cols[1] = {u.v};
-  return sx_montr<C, 1, 4 * LA * LA>(cols, [&](int, int i) { return pair_even1(a.v[i], odd) - (pair_odd1(a.v[i], odd) & even); });   // a0 - a1 | a0
+  return sx_montr<C, 1, BUDGET>(cols, [&](int, int i) { return pair_even1(a.v[i], odd) - (pair_odd1(a.v[i], odd) & even); });   // a0 - a1 | a0
 }
 // own half of a * s, s in Fp (the same value on both lanes)
 template <class C, int LA, int LS>
@@ -95,6 +100,7 @@ RX_DEV Sx<C, SX_T> pair_muls(const Sx<C, LA>& a, const Sx<C, LS>& s) {
 // instead of NL registers of negated columns)
 template <class C, int LA, int LB, int LC, int LD>
 RX_DEV Sx<C, SX_T> pair_mulsub(const Sx<C, LA>& a, const Sx<C, LB>& b, const Sx<C, LC>& c, const Sx<C, LD>& d, bool odd) {
+  static_assert(rx_fits<C>(2 * LA * LB + 2 * LC * LD), "four products per reduction: 28-bit forms (the 29-bit form reduces the two products apart)");
   const Sx<C, LA> pa = pair_swap_neg_even<C>(a, odd);
   const Sx<C, LC> pc = pair_swap_neg_even<C>(c, odd);
   const i32* const cols[4] = {a.v, pa.v, c.v, pc.v};
@@ -105,6 +111,7 @@ RX_DEV Sx<C, SX_T> pair_mulsub(const Sx<C, LA>& a, const Sx<C, LB>& b, const Sx<
 // own half of g^2 - e f, one reduction
 template <class C, int LG, int LE, int LF>
 RX_DEV Sx<C, SX_T> pair_sqrsub(const Sx<C, LG>& g, const Sx<C, LE>& e, const Sx<C, LF>& f, bool odd) {
+  static_assert(rx_fits<C>(4 * LG * LG + 2 * LE * LF), "three products per reduction: 28-bit forms");
   Sx<C, 2 * LG> u;
 #pragma unroll
   for (int i = 0; i < C::RX_NL; ++i) u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
@@ -131,18 +138,30 @@ struct PointX {
 // Doubling step.  emit(slot, value): slot 2 = the P-free coefficient (any bound), slots 0 / 1 = the coefficients already
 // scaled by yP / xP (tight).  env.nyP() = -yP and env.xP() are the hash point's coordinates in this form (same on both
 // lanes); they are fetched where they are used so that they do not occupy registers through the step.
+//
+// 29-bit form (BN254W): the column budget holds TWO products of near-tight factors per reduction, so every factor that is a sum or
+// a multiple goes through one parallel carry step first (sx_normf: three instructions per limb) and the two results that the 28-bit
+// forms reduce lazily as differences of products (Y3 here, Y3 and the P-free line coefficient of the addition) are reduced apart
+// and subtracted: one reduction more per doubling step (29 units of NL^2 = 81 multiplier instructions against 28 of 100), two more
+// per addition step (41 against 39).  Same values mod p at every step, hence the same lines.
+template <class C, class T>
+RX_DEV auto rx_nf(const T& a) {              // one carry step where the form has no head-room for the raw sum
+  if constexpr (rx_lazy<C>) return a;
+  else return sx_normf<C>(a);
+}
 template <class C, class Env, class Emit>
 RX_DEV void dbl_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_T> B = pair_sqr<C>(R.Y, odd);
   const Sx<C, SX_T> Cc = pair_sqr<C>(R.Z, odd);
-  const auto H = sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(R.Y, R.Z)), odd), sx_add<C>(B, Cc));      // 2 Y Z
+  const auto H = rx_nf<C>(sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(R.Y, R.Z)), odd), sx_add<C>(B, Cc)));      // 2 Y Z
   const Sx<C, SX_T> E = pair_mul_3b<C>(Cc, odd);
-  const auto J3 = sx_mulc<3, C>(pair_sqr<C>(R.X, odd));      // 3 X^2
-  const auto A = sx_half<C>(pair_mul<C>(R.X, R.Y, odd));
+  const auto J3 = rx_nf<C>(sx_mulc<3, C>(pair_sqr<C>(R.X, odd)));      // 3 X^2
+  const auto A = rx_nf<C>(sx_half<C>(pair_mul<C>(R.X, R.Y, odd)));
   const Sx<C, SX_F> Fv = sx_normf<C>(sx_mulc<3, C>(E));
-  R.X = pair_mul<C>(A, sx_sub<C>(B, Fv), odd);
+  R.X = pair_mul<C>(A, rx_nf<C>(sx_sub<C>(B, Fv)), odd);
   const Sx<C, SX_F> G = sx_normf<C>(sx_half<C>(sx_add<C>(B, Fv)));
-  R.Y = pair_sqrsub<C>(G, E, Fv, odd);                       // G^2 - 3 E^2   (the step's register peak: Z3 and I come after it)
+  if constexpr (rx_lazy<C>) R.Y = pair_sqrsub<C>(G, E, Fv, odd);                       // G^2 - 3 E^2   (the step's register peak: Z3 and I come after it)
+  else R.Y = sx_norm<C>(sx_sub<C>(pair_sqr<C>(G, odd), pair_mul<C>(E, Fv, odd)));
   const auto I = sx_sub<C>(E, B);
   R.Z = pair_mul<C>(B, H, odd);
   // the line, last: its coefficients go straight from registers to the hand-over
@@ -163,9 +182,14 @@ RX_DEV void add_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_F> Hh = sx_normf<C>(sx_sub<C>(sx_add<C>(E, Fv), sx_mulc<2, C>(G)));
   R.X = pair_mul<C>(la, Hh, odd);
   R.Z = pair_mul<C>(R.Z, E, odd);
-  R.Y = pair_mulsub<C>(th, sx_sub<C>(G, Hh), E, R.Y, odd);
-  // the line, last (la and th are live to the end anyway)
-  emit(2, pair_mulsub<C>(th, env.xq(), la, env.yq(), odd));  // th xq - la yq
+  if constexpr (rx_lazy<C>) {
+    R.Y = pair_mulsub<C>(th, sx_sub<C>(G, Hh), E, R.Y, odd);
+    // the line, last (la and th are live to the end anyway)
+    emit(2, pair_mulsub<C>(th, env.xq(), la, env.yq(), odd));  // th xq - la yq
+  } else {
+    R.Y = sx_norm<C>(sx_sub<C>(pair_mul<C>(th, sx_normf<C>(sx_sub<C>(G, Hh)), odd), pair_mul<C>(E, R.Y, odd)));
+    emit(2, sx_sub<C>(pair_mul<C>(th, env.xq(), odd), pair_mul<C>(la, env.yq(), odd)));
+  }
   emit(0, pair_muls<C>(sx_neg<C>(la), env.nyP()));           // la yP
   emit(1, pair_muls<C>(sx_neg<C>(th), env.xP()));            // (-th) xP
 }

@@ -49,6 +49,7 @@ extern "C" {
 #define BGLS_ERR_HASH (-3)      /* try-and-increment exhausted 256 counters (probability 2^-256) */
 #define BGLS_ERR_NO_DEVICE (-4) /* no usable HIP device */
 #define BGLS_ERR_HIP (-5)       /* a HIP runtime call failed; see bgls_last_error() */
+#define BGLS_ERR_NOMEM (-6)     /* a host allocation failed inside the library (std::bad_alloc); nothing was verified */
 
 /* ---- runtime ---------------------------------------------------------------------------- */
 /* Select the default HIP device of the calling process (default 0) and bring it up.  May be called again with another
@@ -369,6 +370,11 @@ int bgls_profile_get(const char* stage, double* total_ms, unsigned long long* la
 /* Measured peak of dependent-free v_mad_u64_u32 chains on this GPU, in 32x32->64 MAC/s:
  * the roofline denominator for the integer-multiply-bound kernels. */
 int bgls_probe_mad_peak(double* mac_per_s);
+/* Self-test of the ABI's exception barrier, usable without a device: raises a C++ exception of the given kind inside the
+ * library (0 bad_alloc, 1 length_error, 2 system_error, 3 runtime_error, 4 a non-standard object, 5 an unservable std::vector,
+ * 6 bad_alloc on a shard's host thread) and returns the error code the barrier maps it to (BGLS_ERR_NOMEM / _HIP / _ARG).
+ * No entry point lets an exception unwind into the caller (the reference never panics: curves/curve.go:15-22). */
+int bgls_selftest_exception_barrier(int kind);
 
 #ifdef __cplusplus
 }

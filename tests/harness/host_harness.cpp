@@ -1,5 +1,6 @@
 // TEST-ONLY: compiles the device arithmetic headers for the host so that every routine can be
 // diffed against the oracle in the CPU test tier (no GPU here).  Never linked into the product.
+#include <type_traits>
 #include <string.h>
 #include <atomic>
 #include <thread>
@@ -332,14 +333,29 @@ static int rx_raw(int op, int arg, const u32* A, const u32* Bv, u32* out) {
   auto ld = [&](const u32* base, int t, int h) { Ux<C> r; for (int i = 0; i < N; ++i) r.v[i] = base[(t * 2 + h) * N + i]; return r; };
   Ux2<C> r;
   if (op == 0) r = ux_dot_k2p<C, 3>([&](int t, int h) { return ld(A, t, h); }, [&](int t, int h) { return ld(Bv, t, h); });
-  else if (op == 1) r = ux_sqr_dot<C>([&](int t) { return (arg >> (2 * t)) & 3; }, [&](int t, int h) { return ld(A, t, h); }, [&](int t, int h) { return ld(Bv, t, h); });
+  else if (op == 1) {
+    if constexpr (rx_lazy<C>) r = ux_sqr_dot<C>([&](int t) { return (arg >> (2 * t)) & 3; }, [&](int t, int h) { return ld(A, t, h); }, [&](int t, int h) { return ld(Bv, t, h); });
+    else return -1;
+  }
   else if (op == 2) { Ux2<C> a = {ld(A, 0, 0), ld(A, 0, 1)}; r = ux_mulxi<C>(a); }
+  else if (op == 3) {   // the 29-bit form's squaring: doubled pile = operands 0..2, plain pile = operands 3..4 (A, B hold FIVE operands); arg bit t = slot t used
+    auto lm = [&](const u32* base, int t, int h) { Ux<C> v = ld(base, t, h); if (!((arg >> t) & 1)) for (int i = 0; i < N; ++i) v.v[i] = 0; return v; };
+    r = ux_sqr_dot3<C>([&](int t, int side, int h) { return side ? ld(Bv, t, h) : lm(A, t, h); }, [&](int t, int side, int h) { return side ? ld(Bv, 3 + t, h) : lm(A, 3 + t, h); });
+  }
+  else if (op == 4) {   // quasi-reduction, levels arg >> 4 .. arg & 15, of A[0] (raw limbs, not necessarily tight)
+    Ux2<C> a = {ld(A, 0, 0), ld(A, 0, 1)};
+    if constexpr (!rx_lazy<C>) {
+      if (arg == 0x42) r = ux_quasi<C, 4, 2>(a);
+      else if (arg == 0x21) r = ux_quasi<C, 2, 1>(a);
+      else return -1;
+    } else return -1;
+  }
   else return -1;
   for (int i = 0; i < N; ++i) { out[i] = r.c0.v[i]; out[N + i] = r.c1.v[i]; }
   return g_rx_overflow;
 }
 extern "C" int ht_rx_raw(int curve, int op, int arg, const u32* A, const u32* Bv, u32* out) {
-  return curve == 0 ? rx_raw<BN254>(op, arg, A, Bv, out) : rx_raw<BLS381>(op, arg, A, Bv, out);
+  return curve == 0 ? rx_raw<BN254>(op, arg, A, Bv, out) : (curve == 2 ? rx_raw<BN254W>(op, arg, A, Bv, out) : rx_raw<BLS381>(op, arg, A, Bv, out));
 }
 // a (FP_BYTES big-endian, canonical) -> limbs of to_ux(a R);  and back: from_ux(limbs) -> canonical bytes
 template <class C>
@@ -357,7 +373,7 @@ static int rx_conv(int dir, uint8_t* bytes, u32* limbs) {
   return g_rx_overflow;
 }
 extern "C" int ht_rx_conv(int curve, int dir, uint8_t* bytes, u32* limbs) {
-  return curve == 0 ? rx_conv<BN254>(dir, bytes, limbs) : rx_conv<BLS381>(dir, bytes, limbs);
+  return curve == 0 ? rx_conv<BN254>(dir, bytes, limbs) : (curve == 2 ? rx_conv<BN254W>(dir, bytes, limbs) : rx_conv<BLS381>(dir, bytes, limbs));
 }
 
 // ---- rx_pow.hpp: sqrt exponent powers on the carry-free limbs.  op 0: sx_sqr of raw limbs (in/out: NL limbs, signed
@@ -436,7 +452,9 @@ struct RxMillerRun {
     int s = 0;
     auto emit = [&](int which, const auto& v) {
       const int entry = which == 1 ? 1 : ((which == 0) == C::TWIST_D ? 0 : 2);
-      got[s][entry][l] = sx_to_ux<C>(v);
+      if constexpr (rx_lazy<C>) got[s][entry][l] = sx_to_ux<C>(v);            // as miller_x.hpp's emit
+      else if constexpr (std::is_same<std::decay_t<decltype(v)>, Sx<C, SX_T>>::value) got[s][entry][l] = sx_to_ux_p<C>(v);
+      else got[s][entry][l] = sx_to_ux_k<1, C>(v);
     };
     for (int i = 1; i < C::LOOP_LEN; ++i) {
       dbl_step_x<C>(T, env, odd, emit);
@@ -489,7 +507,7 @@ static int rx_miller_check(const uint8_t* g1, const uint8_t* g2) {
     const bool ok = same(e0, run.got[s][0][0], run.got[s][0][1]) && same(b, run.got[s][1][0], run.got[s][1][1]) && same(e2, run.got[s][2][0], run.got[s][2][1]);
     // handed-over entries must be tight and non-negative
     bool tight = true;
-    for (int e = 0; e < 3; ++e) for (int h = 0; h < 2; ++h) for (int i = 0; i + 1 < C::RX_NL; ++i) tight = tight && run.got[s][e][h].v[i] < (1u << 28);
+    for (int e = 0; e < 3; ++e) for (int h = 0; h < 2; ++h) for (int i = 0; i + 1 < C::RX_NL; ++i) tight = tight && run.got[s][e][h].v[i] < (1u << C::RX_W);
     ++s;
     return ok && tight;
   };
@@ -512,7 +530,7 @@ static int rx_miller_check(const uint8_t* g1, const uint8_t* g2) {
   return 0;
 }
 extern "C" int ht_rx_miller(int curve, const uint8_t* g1, const uint8_t* g2) {
-  return curve == 0 ? rx_miller_check<BN254>(g1, g2) : rx_miller_check<BLS381>(g1, g2);
+  return curve == 0 ? rx_miller_check<BN254>(g1, g2) : (curve == 2 ? rx_miller_check<BN254W>(g1, g2) : rx_miller_check<BLS381>(g1, g2));
 }
 
 // ---- rx_jac.hpp: a G2 key sum on the carry-free arithmetic (jacx_madd over the wire-format points, in order) against the

@@ -58,3 +58,42 @@ def test_product_never_imports_oracle():
                     not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_exception_barrier_at_the_c_abi():
+    """include/bgls_hip.h promises "no exceptions, no abort()" (the reference never panics: curves/curve.go:15-22).  Every
+    extern "C" body is a function-try-block; a C++ exception raised inside the library -- on the calling thread or on a shard's
+    host thread -- comes back as a negative code."""
+    from bgls_amd import _lib
+    lib = _lib.load()
+    assert lib.bgls_selftest_exception_barrier(0) == -6 and "memory" in _lib.last_error()
+    assert lib.bgls_selftest_exception_barrier(1) == -6
+    assert lib.bgls_selftest_exception_barrier(2) == -5
+    assert lib.bgls_selftest_exception_barrier(3) == -1 and "selftest" in _lib.last_error()
+    assert lib.bgls_selftest_exception_barrier(4) == -1
+    assert lib.bgls_selftest_exception_barrier(5) == -6          # a real allocation failure, not a thrown stand-in
+    assert lib.bgls_selftest_exception_barrier(6) == -6          # raised on a second host thread, joined, reported
+    assert lib.bgls_selftest_exception_barrier(99) == 0
+    # an absurd batch size is refused before anything is sized by it
+    o = (ctypes.c_uint8 * 64)()
+    off = (ctypes.c_uint64 * 2)(0, 0)
+    assert lib.bgls_verify_aggregate(0, o, o, o, off, (1 << 30) - 1 + 1, 0) == -1
+    assert lib.bgls_hash_to_g1(0, o, off, 1 << 40, o) == -1
+
+
+def test_every_abi_body_is_guarded():
+    """Source rule: each `int bgls_*(...)` defined in engine's extern "C" block is a function-try-block closed by BGLS_ABI_GUARD
+    (one-line accessors that cannot throw are exempt)."""
+    src = ""
+    csrc = os.path.join(ROOT, "bgls_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            src += open(os.path.join(csrc, f)).read()
+    block = src[src.index('extern "C" {'):]
+    names = [m.group(1) for m in re.finditer(r"^int (bgls_[a-z0-9_]+)\(", block, flags=re.M)]
+    assert len(names) >= 55
+    for m in re.finditer(r"^int (bgls_[a-z0-9_]+)\(([^{;]*)\)\s*(try\s*)?\{([^\n]*)$", block, flags=re.M):
+        name, guarded, rest = m.group(1), m.group(3), m.group(4)
+        one_liner = rest.strip().endswith("}")
+        assert guarded or one_liner, name + " is not a function-try-block"
+    assert block.count("} BGLS_ABI_GUARD") + block.count("BGLS_ABI_GUARD\n") >= 55

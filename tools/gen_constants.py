@@ -151,16 +151,18 @@ def main():
         o += arr("R28_BACK", limbs((R * R // Rp) % p * 1 % p if (R * R) % Rp == 0 else (R * R * pow(Rp, -1, p)) % p, L))   # 32-bit Montgomery multiplier: x R' -> x R
         return o
 
-    def rx_consts(p, L, N, xi, b2x3=None):
-        """Constants of the generic carry-free 28-bit-limb representation (rx.hpp): N limbs, Montgomery radix R' = 2^(28 N).
-        alt-bn128: N = 10 (26 spare bits), BLS12-381: N = 14 (11 spare bits)."""
-        W = 28
+    def rx_consts(p, L, N, xi, b2x3=None, W=28, VB=4, VBND=32):
+        """Constants of the generic carry-free W-bit-limb representation (rx.hpp): N limbs, Montgomery radix R' = 2^(W N).
+        alt-bn128: N = 10, W = 28 (26 spare bits), BLS12-381: N = 14, W = 28 (11 spare bits); round 5: alt-bn128's Miller kernel
+        on N = 9, W = 29 (7.4 spare bits: struct BN254W) -- 81 instead of 100 multiplier instructions per limb product.
+        VB: a signed value handed to sx_to_ux must lie above -K VB p; VBND: value bound (multiples of p) of the consumer's operands."""
         Mk = (1 << W) - 1
         lim = lambda x: [(x >> (W * i)) & Mk for i in range(N)]
         R = 1 << (32 * L)
         Rp = 1 << (W * N)
         assert Rp > 4 * p
-        o = "  static constexpr int RX_NL = %d;\n" % N
+        o = "  static constexpr int RX_NL = %d;\n  static constexpr int RX_W = %d;\n  static constexpr uint32_t RX_MASK = 0x%xu;\n" % (N, W, Mk)
+        o += "  static constexpr int RX_VBND = %d;\n" % VBND
         o += arr("RX_P", lim(p))
         o += "  static constexpr uint32_t RX_NP = 0x%xu;\n" % ((-pow(p, -1, 1 << W)) % (1 << W))
         o += arr("RX_ONE", lim(Rp % p))
@@ -172,9 +174,9 @@ def main():
         # Fat multiples of p for limb-wise negation: FAT[k-1] has limbs 0..N-2 in [k 2^28, (k+1) 2^28) and a top limb >= TOPK * k,
         # so FAT_k - b has non-negative limbs for every b with limbs below k 2^28 and value below k * RX_FAT_VB * p
         top_p = p >> (W * (N - 1))
-        VB = 4
         fats = []
-        for k in range(1, 9):
+        KMAX = 8 if W <= 28 else 6                 # (k + 1) 2^W must stay below 2^32
+        for k in range(1, KMAX + 1):
             base = sum((k << W) << (W * i) for i in range(N - 1)) + ((k * VB * (top_p + 1) + 1) << (W * (N - 1)))
             mult = -(-base // p)
             d = mult * p - base
@@ -184,12 +186,13 @@ def main():
             assert sum(v << (W * i) for i, v in enumerate(f)) == mult * p and all((k << W) <= v < ((k + 1) << W) for v in f[:-1])
             assert f[-1] < (1 << 31)
             fats += f
-        o += "  static constexpr int RX_FAT_VB = %d;\n" % VB
+        o += "  static constexpr int RX_FAT_VB = %d;\n  static constexpr int RX_FAT_KMAX = %d;\n" % (VB, KMAX)
         o += arr("RX_FAT", fats)                   # [8][N]
         # Column biases (multiples of p) for the consumer's dot products of TIGHT non-negative operands (limbs < 2^28, value < 32 p):
         #   RX_BIAS_D3: >= column k of sum_{t<3} a1 b1           (re = D + BIAS - E of the three-term Karatsuba fold)
         #   RX_BIAS_S6: >= column k of six term-equivalents      (symmetric squaring: up to 3 doubled + 0 plain or 2 doubled + 2 plain)
-        la = [1 << 28] * (N - 1) + [32 * (top_p + 1)]
+        la = [1 << W] * (N - 1) + [VBND * (top_p + 1)]
+        assert la[-1] <= (1 << W)
         col = [0] * (2 * N)
         for i in range(N):
             for j in range(N):
@@ -207,7 +210,8 @@ def main():
             assert all(bias[k] >= mult * col[k] for k in range(2 * N))
             return bias
         b3 = bias_for(3)
-        b6 = bias_for(6)
+        lazy = 2 * W + 8 <= 64                     # 2^8 of head-room per column (W = 28); W = 29 has 2^6: three-term piles only
+        b6 = bias_for(6) if lazy else [0] * (2 * N)
         # 64-bit column budget: worst case of every pile the consumer forms, plus the reduction's own products and carries
         red = [0] * (2 * N)
         for i in range(N):
@@ -219,12 +223,15 @@ def main():
                 scol[i + j] += (2 * la[i] - 2) * (2 * la[j] - 2)
         for k in range(2 * N):
             carry = 1 << 37
-            assert 3 * scol[k] + red[k] + carry < (1 << 64), ("S pile", k)                 # sum (a0+a1)(b0+b1), three terms
             assert 3 * col[k] + b3[k] + red[k] + carry < (1 << 64), ("D + BIAS", k)
-            assert 6 * col[k] + b6[k] + red[k] + carry < (1 << 64), ("sqr D + BIAS", k)
-            # six term-equivalents x (a0 b1 + a1 b0): the FINAL totals of the squaring's cross pile, which rx.hpp's ux_sqr_dot forms as
-            # -(D + E) + sum (a0 + a1)(b0 + b1) mod 2^64 (Karatsuba; the sum alone would not fit on 14 limbs, it is never formed alone)
-            assert 12 * col[k] + red[k] + carry < (1 << 64), ("sqr cross pile", k)
+            # the cross pile is formed as -(D + E) + sum (a0 + a1)(b0 + b1) mod 2^64: its FINAL totals sum (a0 b1 + a1 b0) are what must fit
+            assert 6 * col[k] + red[k] + carry < (1 << 64), ("cross pile", k)
+            if lazy:
+                assert 3 * scol[k] + red[k] + carry < (1 << 64), ("S pile", k)             # sum (a0+a1)(b0+b1), three terms, formed alone by r28-style callers
+                assert 6 * col[k] + b6[k] + red[k] + carry < (1 << 64), ("sqr D + BIAS", k)
+                # six term-equivalents x (a0 b1 + a1 b0): the FINAL totals of the squaring's cross pile, which rx.hpp's ux_sqr_dot forms as
+                # -(D + E) + sum (a0 + a1)(b0 + b1) mod 2^64 (Karatsuba; the sum alone would not fit on 14 limbs, it is never formed alone)
+                assert 12 * col[k] + red[k] + carry < (1 << 64), ("sqr cross pile", k)
         o += "  static constexpr uint64_t RX_BIAS_D3[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b3))
         o += "  static constexpr uint64_t RX_BIAS_S6[%d] = {%s};\n" % (2 * N, ", ".join("0x%xull" % b for b in b6))
         if b2x3 is not None:
@@ -238,6 +245,7 @@ def main():
             gam += lim(gv[0] * Rp % p) + lim(gv[1] * Rp % p)
         o += arr("RX_GAMMA", gam)                                 # [(1,2), (1,3), (2,2), (2,3)][re, im][N]
         o += arr("RX_PK", sum((lim(k * p) for k in range(9)), []))    # tight limbs of 0, p, 2p .. 8p (exact zero test of a lazy value)
+        o += arr("RX_LAD", sum((lim((1 << k) * p) for k in range(1, 7)), []))   # tight limbs of 2p, 4p .. 64p (ux_quasi: conditional subtractions)
         return o
 
     def bn_extra(M, limbs, L):
@@ -307,6 +315,8 @@ def main():
     txt = "// GENERATED by tools/gen_constants.py -- do not edit.\n#pragma once\n#include <stdint.h>\n\nnamespace bgls {\n\n"
     txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, lambda M, limbs, L: bn_extra(M, limbs, L) + r28_consts(p_bn, L) + rx_consts(p_bn, L, 10, (9, 1), bn_b2x3))
     txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, lambda M, limbs, L: bls_extra(M, limbs, L) + rx_consts(p_bls, L, 14, (1, 1), (12, 12)))
+    # alt-bn128 on nine 29-bit limbs: the form of the Miller kernel k_miller_x60 alone (round 5).  Everything else of the curve is inherited.
+    txt += "struct BN254W : BN254 {\n" + rx_consts(p_bn, 8, 9, (9, 1), bn_b2x3, W=29, VB=1, VBND=128) + "};\n\n"
     txt += "}  // namespace bgls\n"
     with open(OUT, "w") as f:
         f.write(txt)
