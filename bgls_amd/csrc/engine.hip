@@ -77,6 +77,17 @@ int abi_catch() noexcept {
 }
 #define BGLS_ABI_GUARD catch (...) { return abi_catch(); }
 
+// Error-path guard of a fork onto a context's side stream: kernels launched there read and write the context's workspaces, so
+// an early return between the fork and the join must not leave them running into the next call on the same context.  Armed at
+// the fork, disarmed once the main stream waits on the join event; an error return in between drains the side stream.
+struct SideJoin {
+  hipStream_t side;
+  bool armed = false;
+  ~SideJoin() {
+    if (armed) (void)hipStreamSynchronize(side);
+  }
+};
+
 #define HIPCHK(expr)                                         \
   do {                                                       \
     hipError_t e_ = (expr);                                  \
@@ -100,8 +111,6 @@ struct Ctx {
   hipStream_t side = nullptr;                // a lone verification's independent stages run beside each other (fork / join with the two events)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<std::pair<void*, size_t>> ws;  // cached device workspaces by slot
-  void* tick_ptr = nullptr;                  // the key-sum tree's ticket words (zeroed when allocated, left zero by every launch)
-  size_t tick_cap = 0;
   uint32_t* h_res = nullptr;                 // pinned host words {verdict, final-stage flags, caller flags} of the verification in flight
   bool res_pending = false;
   hipStream_t res_stream = nullptr;
@@ -319,6 +328,7 @@ struct Engine {
     static const bool sig_early_on = [] { const char* e = getenv("BGLS_EPIX"); const char* f = getenv("BGLS_SIG_EARLY"); return !(e && e[0] == '0') && !(f && f[0] == '0'); }();
     const bool sig_early = d_sig != nullptr && sig_early_on && !throughput_mode() && n > LAT_MAX && (miller_shape() == 0 || miller_shape() == 4);
     Fp2<C>* sig_half = nullptr;
+    SideJoin sj{c.side};
     if (d_sig && sig_early) {
       const LineCoeffs<C>* gl = nullptr;
       void* tmp;
@@ -327,6 +337,7 @@ struct Engine {
       kl::g1_parse<C>(st, d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
       HIPCHK(hipEventRecord(c.ev_fork, st));
       HIPCHK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+      sj.armed = true;
       kl::cofactor_epiloguex_part<C>(c.side, 1, nullptr, (const Aff<G1F>*)g1s + n, gl, (Fp2<C>*)tmp, nullptr);
       HIPCHK(hipEventRecord(c.ev_join, c.side));
       sig_half = (Fp2<C>*)tmp;
@@ -339,6 +350,7 @@ struct Engine {
     }
     if (d_sig && !sig_early) kl::g1_parse<C>(st, d_sig, 1, 1, (Aff<G1F>*)g1s + n, d_flags);
     if (sig_half) HIPCHK(hipStreamWaitEvent(st, c.ev_join, 0));
+    sj.armed = false;
     return miller(c, st, (const Aff<G1F>*)g1s, d_keys, n, d_sig ? (const Aff<G1F>*)g1s + n : nullptr, d_partial, d_flags, raw, sig_half);
   }
 
@@ -805,11 +817,11 @@ struct Engine {
         void *store, *tick;
         if ((rc = c.get(WS_TREE_S, std::max((cnt + 64) * JB, kl::sum_tree_store_bytes<C>(cnt)), &store))) return rc;
         if ((rc = c.get(WS_TREE_T, (size_t)(8192 + 64) * 4, &tick))) return rc;
-        if (tick != c.tick_ptr || c.ws[WS_TREE_T].second != c.tick_cap) {
-          HIPCHK(hipMemsetAsync(tick, 0, c.ws[WS_TREE_T].second, st));
-          c.tick_ptr = tick;
-          c.tick_cap = c.ws[WS_TREE_T].second;
-        }
+        // The tickets of THIS tree are zeroed in front of every launch (cnt + 64 words: the levels' offsets sum below cnt + 64).  The
+        // kernel also leaves them at zero, but a launch that was aborted -- or a second sum submitted on the same context through a
+        // user stream while the first was in flight -- would leave ones behind, every later tree would then take its waves for
+        // "first arrivals", the root would never be written and a STALE key sum would be verified against.
+        HIPCHK(hipMemsetAsync(tick, 0, (cnt + 64) * 4, st));
         kl::sum_tree<C>(st, a, cnt, store, (uint32_t*)tick, d_bytes, d_jac);
         HIPCHK(hipGetLastError());
         if (bytes_done) *bytes_done = d_bytes != nullptr;
@@ -909,9 +921,11 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
   constexpr bool raw = C::CURVE_ID == 1;        // BLS12-381: H(m) before cofactor clearing, the cofactor applied in GT
   const bool fork = !throughput_mode() && n >= 4096;
   hipStream_t hs = fork ? c.side : st;
+  SideJoin sj{c.side};
   if (fork) {
     HIPCHK(hipEventRecord(c.ev_fork, st));
     HIPCHK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+    sj.armed = true;
   } else {
     // apk = sum(keys)  (AggregatePoints)
     if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags, key_src))) return rc;
@@ -922,6 +936,7 @@ int verify_multi_dev_t(Ctx& c, hipStream_t st, const uint8_t* d_sig, const uint8
     HIPCHK(hipEventRecord(c.ev_join, c.side));
     if ((rc = E::sum_points(c, st, BGLS_G2, d_keys, n, (uint8_t*)d_g2s, (uint32_t*)d_flags, key_src))) return rc;
     HIPCHK(hipStreamWaitEvent(st, c.ev_join, 0));
+    sj.armed = false;
   }
   if ((rc = E::miller(c, st, g1s, (const uint8_t*)d_g2s, 1, g1s + 1, (uint8_t*)d_part, (uint32_t*)d_flags, raw))) return rc;
   if (submit_only) return E::finalize_submit(c, st, (const uint8_t*)d_part, 1, 1, (const uint32_t*)d_flags, nullptr);

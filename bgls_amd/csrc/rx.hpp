@@ -238,12 +238,17 @@ BGLS_HD Ux<C> ux_norm(const Ux<C>& a) {
 }
 
 // xi * a, normalised; a tight with value < 2 p (a reduction's output); the result is tight, non-negative and below 32 p.  alt-bn128: xi = 9 + i; BLS12-381: 1 + i.
-// 29-bit form: 9 a_i leaves 32 bits, so the carry runs through 64-bit sums limb by limb; a below 3.7 p gives a result below 39 p
-// (the consumer's fixed point, miller_x.hpp) -- values only have to stay below RX_VBND p = 128 p.
+//
+// 29-bit form: the radix is only 169 p, so the ten-fold growth cannot be left to the next reduction (the real part's column bias is
+// worth 3 A B / 169 p for operand bounds A p, B p: with xi copies of 40 p the folds' fixed point runs away).  An estimate q of the
+// quotient is read off the top limbs before the pass -- q <= value / p, at most 3 short -- and subtracted IN the pass:
+//      xi a - q p  =  xi a + (32 - q) p + G,    G0 = 4 p - 32 p (low limbs dominating the a1 that the real part subtracts, a1 below 4 p), G1 = -32 p
+// one more multiplier instruction per limb; 9 a_i leaves 32 bits anyway, so the carry runs through 64-bit sums limb by limb.
+// a tight, value below 3 p: the result is tight, non-negative and below 3.001 p.
 template <class C>
 BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
   Ux2<C> r;
-  if constexpr ((long long)(C::XI_RE + 3) << C::RX_W <= (1ll << 32)) {
+  if constexpr (rx_lazy<C>) {
 #pragma unroll
     for (int i = 0; i < C::RX_NL; ++i) {
       r.c0.v[i] = (u32)C::XI_RE * a.c0.v[i] + (C::RX_FAT[i] - a.c1.v[i]);
@@ -252,19 +257,29 @@ BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
     r.c0 = ux_norm<C>(r.c0);
     r.c1 = ux_norm<C>(r.c1);
   } else {
+    constexpr int T = C::RX_NL - 1;
+    constexpr float QI = 1.0f / (float)(C::RX_P[T] + 1u);
+    // un-normalised top limbs of xi a (+ 4 p, not counting the low limbs' 2^W each: an under-estimate): the lower limbs add less than 12 units to them
+    const i32 s0 = (i32)((u32)C::XI_RE * a.c0.v[T]) - (i32)a.c1.v[T] + 4 * (i32)C::RX_P[T];
+    const i32 s1 = (i32)((u32)C::XI_RE * a.c1.v[T] + a.c0.v[T]);
+    auto quot = [&](i32 s) {              // floor(s / (top limb of p + 1)) - 2 (one for the float's rounding), clamped to 0 .. 31
+      i32 q = (i32)((float)s * QI) - 2;
+      q = q < 0 ? 0 : q;
+      return (u32)(32 - (q > 31 ? 31 : q));
+    };
+    const u32 k0 = quot(s0), k1 = quot(s1);
     u64 c0 = 0, c1 = 0;
 #pragma unroll
-    for (int i = 0; i < C::RX_NL - 1; ++i) {
-      const u64 t0 = (u64)(u32)C::XI_RE * a.c0.v[i] + (u64)(C::RX_FAT[i] - a.c1.v[i]) + c0;
-      const u64 t1 = (u64)(u32)C::XI_RE * a.c1.v[i] + (u64)a.c0.v[i] + c1;
+    for (int i = 0; i < T; ++i) {
+      const u64 t0 = (u64)(u32)C::XI_RE * a.c0.v[i] + (u64)k0 * C::RX_P[i] + (u64)((u32)C::RX_XIG0[i] - a.c1.v[i]) + c0;
+      const u64 t1 = (u64)(u32)C::XI_RE * a.c1.v[i] + (u64)k1 * C::RX_P[i] + (u64)((u32)C::RX_XIG1[i] + a.c0.v[i]) + c1;
       r.c0.v[i] = (u32)t0 & C::RX_MASK;
       r.c1.v[i] = (u32)t1 & C::RX_MASK;
       c0 = t0 >> C::RX_W;
       c1 = t1 >> C::RX_W;
     }
-    constexpr int T = C::RX_NL - 1;                       // top limbs are small (value < 128 p): 32-bit arithmetic
-    r.c0.v[T] = (u32)C::XI_RE * a.c0.v[T] + (C::RX_FAT[T] - a.c1.v[T]) + (u32)c0;
-    r.c1.v[T] = (u32)C::XI_RE * a.c1.v[T] + a.c0.v[T] + (u32)c1;
+    r.c0.v[T] = (u32)((i32)((u32)C::XI_RE * a.c0.v[T] + k0 * C::RX_P[T]) + (i32)C::RX_XIG0[T] - (i32)a.c1.v[T] + (i32)c0);
+    r.c1.v[T] = (u32)((i32)((u32)C::XI_RE * a.c1.v[T] + k1 * C::RX_P[T] + a.c0.v[T]) + (i32)C::RX_XIG1[T] + (i32)c1);
   }
   return r;
 }
@@ -381,13 +396,20 @@ BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
       for (int q = 0; q < N; ++q) sb.v[q] = b0.v[q] + b1.v[q];
     }
 #if RX_HOST_CHECK
-    ux_acc<C>(chk, sa, sb);             // the true (non-negative) pile is checked; the wrap-around sum below cannot be
+    // the TRUE cross pile sum (a0 b1 + a1 b0) is accumulated with every addition checked; the pile of the sums' products is taken
+    // mod 2^64 on purpose (on the 29-bit form it wraps: 3 x 9 x 2^60) and must land on the true one column by column
+    ux_acc<C>(chk, lda(t, 0), ldb(t, 1));
+    ux_acc<C>(chk, lda(t, 1), ldb(t, 0));
     for (int i = 0; i < N; ++i)
       for (int j = 0; j < N; ++j) d[i + j] += (u64)sa.v[i] * sb.v[j];
 #else
     ux_acc<C>(d, sa, sb);
 #endif
   }
+#if RX_HOST_CHECK
+  for (int k = 0; k < 2 * N; ++k)
+    if (chk[k] != d[k]) g_rx_overflow = 1;
+#endif
   r.c1 = ux_redc<C>(d);
   return r;
 }
@@ -485,9 +507,9 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
 
 // The symmetric squaring on the 29-bit form: a pile holds three term-equivalents, so the row's doubled products (at most three,
 // accumulated UNdoubled) and its plain products (at most two) are two three-term dot products and
-//   c = 2 * reduce(doubled) + reduce(plain),    then a quasi-reduction back below 4 p
-// (operands below 3.7 p / 39 p: the doubled pile reduces below 6 p, the plain one below 4.4 p, c below 17 p).  Five slot products
-// and four reductions per lane against the 28-bit form's four and two, on 81 instead of 100 multiplier instructions each.
+//   c = 2 * reduce(doubled) + reduce(plain),    then a quasi-reduction back below 2 p
+// (operands below 2 p / 3 p: each pile reduces below 1.5 p, c below 4.5 p).  Five slot products and four reductions per lane
+// against the 28-bit form's four and two, on 81 instead of 100 multiplier instructions each.
 //   ldd(t, side, h): slot t < 3 of the doubled pile, side 0 / 1 = left / right operand, half h; zeros for an unused slot.  ldp: the plain pile (t < 2).
 template <class C, class LD, class LP>
 BGLS_HD Ux2<C> ux_sqr_dot3(LD&& ldd, LP&& ldp) {
@@ -499,7 +521,7 @@ BGLS_HD Ux2<C> ux_sqr_dot3(LD&& ldd, LP&& ldp) {
     s.c0.v[i] = 2 * d.c0.v[i] + p.c0.v[i];
     s.c1.v[i] = 2 * d.c1.v[i] + p.c1.v[i];
   }
-  return ux_quasi<C, 4, 2>(s);
+  return ux_quasi<C, 2, 1>(s);
 }
 
 // ---- conversions between the library's form (32-bit limbs, Montgomery radix R = 2^(32 L)) and this one

@@ -42,7 +42,7 @@ def host_harness():
     csrc = os.path.join(ROOT, "bgls_amd", "csrc")
     deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O2", "-shared", "-fPIC", "-pthread", "-o", so, src],
+        subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-o", so, src],
                        check=True, timeout=900)
     return ctypes.CDLL(so)
 

@@ -204,3 +204,118 @@ def test_sqrt_powers_on_carry_free_limbs(host_harness, cid):
             rc = host_harness.ht_rx_pow(cid, op, buf, None)
             assert rc == 0, (op, x, rc)
             assert int.from_bytes(bytes(buf), "big") == pow(x, e, p)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 5
+# alt-bn128's Miller kernel runs on NINE limbs of 29 bits (struct BN254W: 81 instead of 100 multiplier instructions per limb
+# product).  A 64-bit column then has 2^6 of head-room instead of 2^8 and the Montgomery radix is only 169 p, so the form's
+# rules are tighter -- three-term piles of tight operands fill 63 of the 64 units of 2^58 a column holds, values are kept below
+# 4 p explicitly -- and every one of them is checked here on worst-case limb patterns (harness curve id 2).
+W29, N29 = 29, 9
+MASK29 = (1 << W29) - 1
+
+
+def limbs29(x):
+    out = [(x >> (W29 * i)) & MASK29 for i in range(N29 - 1)]
+    out.append(x >> (W29 * (N29 - 1)))
+    assert out[-1] < (1 << 32)
+    return out
+
+
+def val29(l):
+    return sum(int(v) << (W29 * i) for i, v in enumerate(l))
+
+
+def run29(lib, op, arg, A, Bv):
+    o = (ctypes.c_uint32 * (2 * N29))()
+    ovf = lib.ht_rx_raw(2, op, arg, pack(A, N29), pack(Bv, N29), o)
+    return ovf, list(o[:N29]), list(o[N29:])
+
+
+def tight29(l):
+    return all(v < (1 << W29) for v in l[:-1]) and l[-1] < (1 << 31)
+
+
+def operand29(rnd, p, kind, vb):
+    top_p = p >> (W29 * (N29 - 1))
+    if kind == "max":
+        l = [MASK29] * (N29 - 1) + [vb * (top_p + 1) - 1]
+        return (l, list(l))
+    return (limbs29(rnd.randrange(vb * p)), limbs29(rnd.randrange(vb * p)))
+
+
+def test_29bit_form_conversions_and_consumer_arithmetic(host_harness):
+    lib = host_harness
+    p = CURVES["altbn128"].p
+    Rp = 1 << (W29 * N29)
+    Rinv = pow(Rp, -1, p)
+    rnd = random.Random(2905)
+    for x in [0, 1, p - 1, p // 2] + [rnd.randrange(p) for _ in range(20)]:
+        buf = (ctypes.c_uint8 * 32).from_buffer_copy(x.to_bytes(32, "big"))
+        lim = (ctypes.c_uint32 * N29)()
+        assert lib.ht_rx_conv(2, 0, buf, lim) == 0
+        assert tight29(list(lim)) and val29(lim) % p == x * Rp % p and val29(lim) < 2 * p
+        back = (ctypes.c_uint8 * 32)()
+        assert lib.ht_rx_conv(2, 1, back, lim) == 0 and int.from_bytes(bytes(back), "big") == x
+    for v in [p, 2 * p - 1, 3 * p + 12345, 4 * p - 1]:
+        back = (ctypes.c_uint8 * 32)()
+        assert lib.ht_rx_conv(2, 1, back, (ctypes.c_uint32 * N29)(*limbs29(v))) == 0
+        assert int.from_bytes(bytes(back), "big") == v * Rinv % p
+    # the three-term fold: worst-case limbs (every limb at 2^29 - 1, values at the form's bound of 4 p) stay inside the columns
+    worst = 0
+    for kind in ["rand"] * 12 + ["max"]:
+        A = [operand29(rnd, p, kind, 4) for _ in range(3)]
+        Bv = [operand29(rnd, p, kind, 4) for _ in range(3)]
+        ovf, r0, r1 = run29(lib, 0, 0, A, Bv)
+        assert ovf == 0, "64-bit column overflow in the three-term fold (%s operands)" % kind
+        re = sum(val29(a[0]) * val29(b[0]) - val29(a[1]) * val29(b[1]) for a, b in zip(A, Bv))
+        im = sum(val29(a[0]) * val29(b[1]) + val29(a[1]) * val29(b[0]) for a, b in zip(A, Bv))
+        assert tight29(r0) and tight29(r1) and val29(r0) % p == re * Rinv % p and val29(r1) % p == im * Rinv % p
+        worst = max(worst, val29(r0), val29(r1))
+    assert worst < 3 * p            # what ux_mulxi accepts (the kernel's operands are smaller: lines below 3.1 p, accumulators below 3 p)
+    # xi multiple with the quotient subtracted in the same pass: any input below 3 p -> tight, non-negative, below 3.001 p
+    edge = [(3 * p - 1, 0), (0, 3 * p - 1), (3 * p - 1, 3 * p - 1), (0, 0), (1, 1), (p, p)]
+    for it in range(200):
+        v0, v1 = edge[it] if it < len(edge) else (rnd.randrange(3 * p), rnd.randrange(3 * p))
+        a = (limbs29(v0), limbs29(v1))
+        ovf, r0, r1 = run29(lib, 2, 0, [a] * 3, [a] * 3)
+        assert tight29(r0) and tight29(r1), (it, r0, r1)
+        assert val29(r0) % p == (9 * v0 - v1) % p and val29(r1) % p == (9 * v1 + v0) % p
+        assert val29(r0) < 3.001 * p and val29(r1) < 3.001 * p
+    # the squaring as two piles + quasi-reduction: slot masks as the table's rows have them, worst-case limbs included
+    for used in (0b00111, 0b11011, 0b11111, 0b11110):
+        for kind in ["rand"] * 6 + ["max"]:
+            A = [operand29(rnd, p, kind, 2 if kind == "rand" else 4) for _ in range(5)]
+            Bv = [operand29(rnd, p, kind, 3 if kind == "rand" else 4) for _ in range(5)]
+            ovf, r0, r1 = run29(lib, 3, used, A, Bv)
+            assert ovf == 0, (kind, used)
+            ks = [2, 2, 2, 1, 1]
+            re = sum(k * (val29(a[0]) * val29(b[0]) - val29(a[1]) * val29(b[1])) for t, (k, a, b) in enumerate(zip(ks, A, Bv)) if (used >> t) & 1)
+            im = sum(k * (val29(a[0]) * val29(b[1]) + val29(a[1]) * val29(b[0])) for t, (k, a, b) in enumerate(zip(ks, A, Bv)) if (used >> t) & 1)
+            assert tight29(r0) and tight29(r1)
+            assert val29(r0) % p == re * Rinv % p and val29(r1) % p == im * Rinv % p
+            assert val29(r0) < 2.001 * p and val29(r1) < 2.001 * p
+    # quasi-reduction ladders
+    for _ in range(60):
+        v0, v1 = rnd.randrange(31 * p), rnd.randrange(31 * p)
+        a = (limbs29(v0), limbs29(v1))
+        ovf, r0, r1 = run29(lib, 4, 0x42, [a] * 3, [a] * 3)
+        assert tight29(r0) and val29(r0) % p == v0 % p and val29(r0) < 4.001 * p and val29(r1) % p == v1 % p and val29(r1) < 4.001 * p
+        v0 = rnd.randrange(8 * p)
+        a = (limbs29(v0), limbs29(v0))
+        ovf, r0, r1 = run29(lib, 4, 0x21, [a] * 3, [a] * 3)
+        assert tight29(r0) and val29(r0) % p == v0 % p and val29(r0) < 2.001 * p
+
+
+def test_29bit_form_point_steps_match_the_library_steps(host_harness):
+    """The lane-pair point steps on nine 29-bit limbs (one more reduction per doubling, two per addition, carry steps in front of
+    every product of a sum) hand over the same line coefficients as pairing.hpp's steps over a whole Miller loop, with every
+    column accumulation checked for overflow."""
+    c = CURVES["altbn128"]
+    G = Groups(c)
+    rnd = random.Random(2931)
+    for _ in range(3):
+        g1 = G.g1_bytes(G.g1_mul(c.g1, rnd.randrange(1, c.r)))
+        g2 = G.g2_bytes(G.g2_mul(c.g2, rnd.randrange(1, c.r)))
+        rc = host_harness.ht_rx_miller(2, (ctypes.c_uint8 * len(g1)).from_buffer_copy(g1), (ctypes.c_uint8 * len(g2)).from_buffer_copy(g2))
+        assert rc == 0, "29-bit lane-pair point steps differ from pairing.hpp (code %d: 1 + first differing step, -3 = column overflow)" % rc

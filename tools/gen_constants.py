@@ -246,6 +246,22 @@ def main():
         o += arr("RX_GAMMA", gam)                                 # [(1,2), (1,3), (2,2), (2,3)][re, im][N]
         o += arr("RX_PK", sum((lim(k * p) for k in range(9)), []))    # tight limbs of 0, p, 2p .. 8p (exact zero test of a lazy value)
         o += arr("RX_LAD", sum((lim((1 << k) * p) for k in range(1, 7)), []))   # tight limbs of 2p, 4p .. 64p (ux_quasi: conditional subtractions)
+        if not lazy:
+            # ux_mulxi on the narrow form subtracts an estimated quotient q < 32 in the same pass: xi a - q p = xi a + (32 - q) p + G with
+            # G0 = (fat 4p) - 32 p for the real part (low limbs in [2^W, 2^(W+1)): they dominate the subtracted a1; signed top limb) and G1 = -32 p
+            def signed_rep(v, lowbase):
+                base = sum(lowbase << (W * i) for i in range(N - 1))
+                d = (v - base) % (1 << (W * (N - 1)))
+                low = [lowbase + ((d >> (W * i)) & Mk) for i in range(N - 1)]
+                rest = v - sum(x << (W * i) for i, x in enumerate(low))
+                assert rest % (1 << (W * (N - 1))) == 0
+                top = rest >> (W * (N - 1))
+                assert -(1 << 31) < top < (1 << 31) and sum(x << (W * i) for i, x in enumerate(low)) + (top << (W * (N - 1))) == v
+                return low + [top]
+            g0 = signed_rep(4 * p - 32 * p, 1 << W)          # 4 p: the subtracted a1 may be anything below 4 p
+            g1 = signed_rep(-32 * p, 0)
+            for nm, g in (("RX_XIG0", g0), ("RX_XIG1", g1)):
+                o += "  static constexpr int64_t %s[%d] = {%s};\n" % (nm, N, ", ".join("%dll" % v for v in g))
         return o
 
     def bn_extra(M, limbs, L):
@@ -316,7 +332,7 @@ def main():
     txt += emit("BN254", 0, 8, p_bn, r_bn, 3, (9, 1), "D", 6 * u + 2, lambda M, limbs, L: bn_extra(M, limbs, L) + r28_consts(p_bn, L) + rx_consts(p_bn, L, 10, (9, 1), bn_b2x3))
     txt += emit("BLS381", 1, 12, p_bls, r_bls, 4, (1, 1), "M", -x, lambda M, limbs, L: bls_extra(M, limbs, L) + rx_consts(p_bls, L, 14, (1, 1), (12, 12)))
     # alt-bn128 on nine 29-bit limbs: the form of the Miller kernel k_miller_x60 alone (round 5).  Everything else of the curve is inherited.
-    txt += "struct BN254W : BN254 {\n" + rx_consts(p_bn, 8, 9, (9, 1), bn_b2x3, W=29, VB=1, VBND=128) + "};\n\n"
+    txt += "struct BN254W : BN254 {\n" + rx_consts(p_bn, 8, 9, (9, 1), bn_b2x3, W=29, VB=1, VBND=4) + "};\n\n"
     txt += "}  // namespace bgls\n"
     with open(OUT, "w") as f:
         f.write(txt)

@@ -118,6 +118,22 @@ __global__ void __launch_bounds__(256) k_issue(int iters, uint64_t* sink) {
 #define X(j) asm volatile("v_mov_b32 %0, %1" : "+v"(w[j]) : "v"(w[(j + 1) & 7]));
       REP64(X)
 #undef X
+    } else if constexpr (KIND == 24) {      // v_fma_f64 (round 5, variant D of the number-form question: is the FP64 pipe any faster than the integer multiplier?)
+#define X(j) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(c[j]) : "v"(c[(j + 1) & 7]), "v"(c[(j + 2) & 7]));
+      REP64(X)
+#undef X
+    } else if constexpr (KIND == 25) {      // 64-bit add as v_add_co_u32 + v_addc_co_u32 (counted as ONE operation of two instructions)
+#define X(j) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(w[j]), "+v"(w[(j + 4) & 7]) : "v"(a), "v"(b) : "vcc");
+      REP64(X)
+#undef X
+    } else if constexpr (KIND == 26) {      // one 52 x 52-bit limb product of the FP64 form: hi = fma(a, b, C1), lo = fma(a, b, C2 - hi), both bit patterns added into 64-bit integer columns
+#define X(j) asm volatile("v_fma_f64 %0, %2, %3, %0\n v_fma_f64 %1, %2, %3, %1\n v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %0" : "+v"(c[j]), "+v"(c[(j + 4) & 7]) : "v"(c[(j + 1) & 7]), "v"(c[(j + 2) & 7]));
+      REP64(X)
+#undef X
+    } else if constexpr (KIND == 27) {      // v_add_f64
+#define X(j) asm volatile("v_add_f64 %0, %0, %1" : "+v"(c[j]) : "v"(c[(j + 1) & 7]));
+      REP64(X)
+#undef X
     } else if constexpr (KIND == 13) {      // v_alignbit_b32
 #define X(j) asm volatile("v_alignbit_b32 %0, %0, %1, 28" : "+v"(w[j]) : "v"(a));
       REP64(X)
@@ -232,9 +248,11 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "all") || !strcmp(what, "issue")) {
     const char* names[] = {"v_mad_u64_u32 (vcc sink)", "v_mad_i64_i32", "v_mad_u64_u32 x8 per asm", "v_add_u32", "v_and_b32", "v_lshl_add_u64", "v_ashrrev_i64",
                            "v_mov_b32_dpp", "v_mul_lo_u32", "v_cndmask_b32", "v_mad_u64_u32 sgpr factor", "v_mad_u64_u32 + s_nop 0", "v_mad_u64_u32 + v_add_u32 (pair)", "v_alignbit_b32",
-                           "v_cndmask_b32_e64 sgpr mask", "v_bfi_b32", "v_xor_b32", "v_mov_b32_dpp [0,0,2,2]", "v_add_u32_dpp", "v_sub_u32", "v_lshrrev_b32", "v_add3_u32", "v_and_or_b32", "v_mov_b32"};
+                           "v_cndmask_b32_e64 sgpr mask", "v_bfi_b32", "v_xor_b32", "v_mov_b32_dpp [0,0,2,2]", "v_add_u32_dpp", "v_sub_u32", "v_lshrrev_b32", "v_add3_u32", "v_and_or_b32", "v_mov_b32",
+                           "v_fma_f64", "v_add_co_u32 + v_addc_co_u32 (64-bit add, 2 instr)", "FP64 limb product: 2 fma_f64 + 2 lshl_add_u64 (4 instr)", "v_add_f64"};
     for (int wps = 2; wps <= 3; ++wps) {
-      double t[24];
+      double t[28];
+      t[24] = time_issue<24>(wps, sink); t[25] = time_issue<25>(wps, sink); t[26] = time_issue<26>(wps, sink); t[27] = time_issue<27>(wps, sink);
       t[14] = time_issue<14>(wps, sink); t[15] = time_issue<15>(wps, sink); t[16] = time_issue<16>(wps, sink); t[17] = time_issue<17>(wps, sink);
       t[18] = time_issue<18>(wps, sink); t[19] = time_issue<19>(wps, sink); t[20] = time_issue<20>(wps, sink); t[21] = time_issue<21>(wps, sink);
       t[22] = time_issue<22>(wps, sink); t[23] = time_issue<23>(wps, sink);
@@ -242,7 +260,7 @@ int main(int argc, char** argv) {
       t[4] = time_issue<4>(wps, sink); t[5] = time_issue<5>(wps, sink); t[6] = time_issue<6>(wps, sink); t[7] = time_issue<7>(wps, sink);
       t[8] = time_issue<8>(wps, sink); t[9] = time_issue<9>(wps, sink); t[10] = time_issue<10>(wps, sink); t[11] = time_issue<11>(wps, sink);
       t[12] = time_issue<12>(wps, sink); t[13] = time_issue<13>(wps, sink);
-      for (int k = 0; k < 24; ++k) printf("waves/SIMD %d  %-34s %.3f ns per wave-instruction per SIMD   (x%.2f of mad)\n", wps, names[k], t[k], t[k] / t[0]);
+      for (int k = 0; k < 28; ++k) printf("waves/SIMD %d  %-34s %.3f ns per wave-instruction per SIMD   (x%.2f of mad)\n", wps, names[k], t[k], t[k] / t[0]);
     }
   }
   if (!strcmp(what, "where")) where_test();
@@ -254,6 +272,8 @@ int main(int argc, char** argv) {
              time_x60<BLS381, 2>(n, rot, 3));
       printf("BN254  n=%zu mode=%d  whole %.3f ms   producer only %.3f ms   consumer only %.3f ms\n", n, rot, time_x60<BN254, 0>(n, rot, 5), time_x60<BN254, 1>(n, rot, 3),
              time_x60<BN254, 2>(n, rot, 3));
+      printf("BN254W n=%zu mode=%d  whole %.3f ms   producer only %.3f ms   consumer only %.3f ms   (nine limbs of 29 bits)\n", n, rot, time_x60<BN254W, 0>(n, rot, 5),
+             time_x60<BN254W, 1>(n, rot, 3), time_x60<BN254W, 2>(n, rot, 3));
     }
   }
   return 0;
