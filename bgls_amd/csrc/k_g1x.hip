@@ -4,7 +4,7 @@
 //   k_scale_g1x       ScalePoints / Point.Mul on G1 (curves/curve.go:190-214; wire bytes in, sign bytes: 1 = negate first,
 //                     2 = nil factor -> Copy())
 // Same windows, same group law and therefore the same points as k_scale_aff / k_scale of k_points.hip (which keep serving
-// G2, alt-bn128's G1 -- no gain there: ten 28-bit limbs against eight 32-bit ones -- and, with BGLS_G1X=0, BLS12-381's):
+// G2, alt-bn128's G1 -- no gain there: ten 28-bit limbs against eight 32-bit ones -- and, with BGLS_LEGACY bit 32, BLS12-381's):
 // only the field arithmetic under the chain changed.  BLS12-381 at 2^18 points: Sign 55 -> 43 ms, ScalePoints 36 -> 29 ms.
 #include "dev_common.hpp"
 #include "rx_jac1.hpp"

@@ -491,15 +491,14 @@ void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* cn,
 // BLS12-381: pts / kinds hold 2n work items (message, tag); raw = uncleared sum (verification path, cofactor in GT)
 void h2c_bls(hipStream_t st, MsgView mv, size_t n, Jac<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw) {
   const size_t items = 2 * n;
+  // BGLS_LEGACY bit 32 (engine.hip): the combine step's G1 arithmetic on the 32-bit chain instead of the carry-free limbs (A/B runs)
+  static const bool g1x = [] { const char* e = getenv("BGLS_LEGACY"); return !(e && (atoi(e) & 32)); }();
   k_bls_sw_jacobi<<<nblk(items, 64), 64, 0, st>>>(mv, items, pts, kinds);
   if (raw && n >= ((size_t)1 << 18)) k_bls_combine_raw_batched<4><<<nblk((n + 3) / 4, 64), 64, 0, st>>>(n, pts, kinds, out);
   else if (raw) {
-    static const bool g1x = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();
     if (g1x) k_bls_combine_raw_x<<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
     else k_bls_combine<true><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
-  }
-  else {
-    static const bool g1x = [] { const char* e = getenv("BGLS_G1X"); return !(e && e[0] == '0'); }();      // BGLS_G1X=0: the 32-bit chain (A/B runs)
+  } else {
     if (g1x) k_bls_combine_x<<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
     else k_bls_combine<false><<<nblk(n, 64), 64, 0, st>>>(n, pts, kinds, out);
   }

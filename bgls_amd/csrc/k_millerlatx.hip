@@ -444,17 +444,11 @@ void reduce_fx(hipStream_t st, const Fp2<C>* in, size_t count, int R, Fp2<C>* ou
 }
 template void reduce_fx<BN254>(hipStream_t, const Fp2<BN254>*, size_t, int, Fp2<BN254>*);
 template void reduce_fx<BLS381>(hipStream_t, const Fp2<BLS381>*, size_t, int, Fp2<BLS381>*);
-// BGLS_LATX2=0 keeps the one-wave accumulator (round 3's block of two waves): A/B runs and the legacy-path tests
-static bool latx_two_waves() {
-  static const bool on = [] { const char* e = getenv("BGLS_LATX2"); return !(e && e[0] == '0'); }();
-  return on;
-}
 static_assert(FX<BN254>::LDS_BYTES_PAIR >= FX<BN254>::LDS_BYTES + FX2W_EXTRA_BYTES, "the pair scratch covers the hand-over words");
 template <class C>
 static void launch_epilogue_ax(hipStream_t st, unsigned blocks, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint32_t* flags,
                                int first_role) {
-  if (latx_two_waves()) k_epilogue_ax<C, 2><<<blocks, 256, FX<C>::LDS_BYTES_PAIR, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
-  else k_epilogue_ax<C, 1><<<blocks, 128, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
+  k_epilogue_ax<C, 2><<<blocks, 256, FX<C>::LDS_BYTES_PAIR, st>>>(rest, sig, gen_lines, tmp, flags, first_role);
 }
 template <class C>
 void cofactor_epiloguex(hipStream_t st, const Fp2<C>* rest, const Aff<F1<C>>* sig, const LineCoeffs<C>* gen_lines, Fp2<C>* tmp, uint8_t* out,
@@ -480,8 +474,7 @@ template <class C>
 void miller_latx(hipStream_t st, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at, const LineCoeffs<C>* gen_lines, Fp2<C>* out,
                  uint32_t* flags) {
   const unsigned blocks = (unsigned)(n + (sig_at >= 0 ? 1 : 0));
-  if (latx_two_waves()) k_miller_latx<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
-  else k_miller_latx<C, 1><<<blocks, 128, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
+  k_miller_latx<C, 2><<<blocks, 192, FX<C>::LDS_BYTES + FX2W_EXTRA_BYTES, st>>>(g1s, g2s, n, sig_at, gen_lines, out, flags);
 }
 template void miller_latx<BN254>(hipStream_t, const Aff<F1<BN254>>*, const uint8_t*, size_t, long long, const LineCoeffs<BN254>*, Fp2<BN254>*, uint32_t*);
 template void miller_latx<BLS381>(hipStream_t, const Aff<F1<BLS381>>*, const uint8_t*, size_t, long long, const LineCoeffs<BLS381>*, Fp2<BLS381>*, uint32_t*);

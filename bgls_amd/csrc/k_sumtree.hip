@@ -26,70 +26,7 @@ using namespace bgls;
 // fenced twice per level and was SLOWER than twelve launches).  So the record travels as 8-byte relaxed agent-scope atomics:
 // write-through (sc1) stores by 6 L / 2 lanes, drained (s_waitcnt vmcnt(0)) before the ticket is taken, sc1 loads behind
 // the returned ticket on the other side.  No fence anywhere.
-template <class C>
-__device__ __forceinline__ void tree_park(Jac<F2<C>>* slot, const Jac<F2<C>>& v, int lds_base) {
-  extern __shared__ u32 lds[];
-  constexpr int NW = 6 * C::L / 2;              // 8-byte words of a record
-  static_assert(sizeof(Jac<F2<C>>) == NW * 8 && 2 * NW <= CoopF2<C>::WAVE_DW, "record fits the wave's LDS scratch");
-  const int lane = threadIdx.x & 63;
-  if (lane == 0) *reinterpret_cast<Jac<F2<C>>*>(lds + lds_base) = v;     // every lane holds the same record
-  wave_sync();
-  if (lane < NW) {
-    const unsigned long long w = *reinterpret_cast<const unsigned long long*>(lds + lds_base + 2 * lane);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  wave_sync();
-}
-template <class C>
-__device__ __forceinline__ Jac<F2<C>> tree_fetch(const Jac<F2<C>>* slot, int lds_base) {
-  extern __shared__ u32 lds[];
-  constexpr int NW = 6 * C::L / 2;
-  const int lane = threadIdx.x & 63;
-  if (lane < NW) {
-    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slot) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *reinterpret_cast<unsigned long long*>(lds + lds_base + 2 * lane) = w;
-  }
-  wave_sync();
-  const Jac<F2<C>> r = *reinterpret_cast<const Jac<F2<C>>*>(lds + lds_base);
-  wave_sync();
-  return r;
-}
-
-template <class C>
-__global__ void __launch_bounds__(64) k_sum_tree(const Jac<F2<C>>* in, size_t cnt, Jac<F2<C>>* store, uint32_t* tickets, uint8_t* d_bytes,
-                                                 Jac<F2<C>>* d_jac) {
-  typedef F2<C> F;
-  const int lane = threadIdx.x;
-  const CoopF2<C> k(0);
-  size_t i = blockIdx.x;                        // node index at the current level
-  Jac<F> acc = in[2 * i];
-  if (2 * i + 1 < cnt) acc = coop_jac_add<C>(k, acc, in[2 * i + 1]);
-  size_t n = (cnt + 1) / 2, off = 0;            // nodes at this level, offset of the level's slots
-  while (n > 1) {
-    const size_t sib = i ^ 1;
-    if (sib < n) {
-      tree_park<C>(store + off + i, acc, 0);    // visible (written through, drained) before the ticket is taken
-      unsigned t = 0;
-      if (lane == 0) t = atomicAdd(&tickets[off + (i & ~(size_t)1)], 1u);
-      t = __shfl(t, 0);
-      if (t == 0) return;                       // first of the pair: the sibling's wave carries both sums on
-      const Jac<F> other = tree_fetch<C>(store + off + sib, 0);
-      acc = coop_jac_add<C>(k, acc, other);
-      if (lane == 0) tickets[off + (i & ~(size_t)1)] = 0;        // left clean for the next launch
-    }
-    off += n;
-    i >>= 1;
-    n = (n + 1) / 2;
-  }
-  if (lane == 0) {
-    if (d_jac) *d_jac = acc;
-    if (d_bytes) aff_to_bytes<F>(d_bytes, jac_to_aff<F>(acc));
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------ the same tree, round 4b
+// ------------------------------------------------------------------------------------------------ the tree on the carry-free limbs (round 4b; the 32-bit form k_sum_tree it replaced was removed in round 5)
 // The additions on the carry-free limbs, one Fp2 product per LANE PAIR (rx_pair.hpp), in FOUR rounds of independent products
 // instead of jac_coop.hpp's five levels of 32-bit products (~20 us an addition on a lone wave: most of the ~25 us a level costs).
 // The formulas are add-2007-bl written out so that nothing is more than four products deep:
@@ -340,13 +277,7 @@ template size_t sum_tree_store_bytes<BLS381>(size_t);
 
 template <class C>
 void sum_tree(hipStream_t st, const void* in, size_t cnt, void* store, uint32_t* tickets, uint8_t* d_bytes, void* d_jac) {
-  static const bool treex = [] { const char* e = getenv("BGLS_SUMTREEX"); return !(e && e[0] == '0'); }();      // BGLS_SUMTREEX=0: the 32-bit additions (A/B runs)
-  if (treex) {
-    k_sum_tree_x<C><<<(unsigned)((cnt + 1) / 2), 64, TreeX<C>::LDS_DW * 4, st>>>((const Jac<F2<C>>*)in, cnt, (u32*)store, tickets, d_bytes, (Jac<F2<C>>*)d_jac);
-    return;
-  }
-  k_sum_tree<C><<<(unsigned)((cnt + 1) / 2), 64, CoopF2<C>::WAVE_DW * 4, st>>>((const Jac<F2<C>>*)in, cnt, (Jac<F2<C>>*)store, tickets, d_bytes,
-                                                                                (Jac<F2<C>>*)d_jac);
+  k_sum_tree_x<C><<<(unsigned)((cnt + 1) / 2), 64, TreeX<C>::LDS_DW * 4, st>>>((const Jac<F2<C>>*)in, cnt, (u32*)store, tickets, d_bytes, (Jac<F2<C>>*)d_jac);
 }
 template void sum_tree<BN254>(hipStream_t, const void*, size_t, void*, uint32_t*, uint8_t*, void*);
 template void sum_tree<BLS381>(hipStream_t, const void*, size_t, void*, uint32_t*, uint8_t*, void*);

@@ -19,9 +19,7 @@ template <class C> void g1_to_bytes(hipStream_t st, const Aff<F1<C>>* in, size_t
 template <class C> void g1_parse(hipStream_t st, const uint8_t* in, size_t n, int negate, Aff<F1<C>>* out, uint32_t* flags);
 template <class C> void sum_main(hipStream_t st, int group, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
 template <class C> void sumseg_main(hipStream_t st, int group, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
-// ---- k_sumx.hip   (G2 key sums on carry-free limbs, rx_jac.hpp)
-template <class C> void sumx_main(hipStream_t st, bool parsed, const uint8_t* pts, size_t n, unsigned waves, void* out, uint32_t* flags);
-template <class C> void sumxseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
+// ---- k_sumpair.hip   (G2 key sums on lane pairs, carry-free limbs: rx_jacpair.hpp)
 template <class C> void sumpair_main(hipStream_t st, int src, const uint8_t* pts, size_t n, unsigned partials, void* out, uint32_t* flags);
 template <class C> void sumpairseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags);
 template <class C> void sum_wave(hipStream_t st, int group, const void* in, size_t n, void* out);
@@ -71,19 +69,12 @@ template <class C>
 void miller_ab64(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, long long sig_at,
                  const LineCoeffs<C>* gen_lines, Fp2<C>* out, uint32_t* flags, int dbg, uint32_t* qp);
 template <class C> constexpr size_t miller_qp_bytes(size_t nblocks) { return nblocks * 64 * 6 * C::L * 4; }    // parked Q, P of every producer lane
-template <class C>
-void miller_s60(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags,
-                int dbg, uint32_t* qp);
 
 // ---- k_millerx_{bn,bls}.hip (NP = 60), k_millerx64_{bn,bls}.hip (NP = 64)
 template <class C, int NP>
 void miller_x(hipStream_t st, unsigned nblocks, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, uint32_t* park, int rot_mode);
 template <class C, int NP> size_t miller_x_park_bytes(size_t nblocks);
 
-template <class C> size_t lines_bytes(int variant, size_t n_pad);
-template <class C>
-void miller_lines(hipStream_t st, int variant, const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, size_t n_pad, uint32_t* table, uint32_t* flags);
-template <class C> void miller_fold(hipStream_t st, int variant, const uint32_t* table, size_t n_pad, int ng, Fp2<C>* out);
 
 // prepared key sets (prepared.hpp): bytes per key of the line table, per pairing of the point table, per key of k_prepare's scratch
 struct PrepSizes { size_t line_bytes_per_key, point_bytes, tmp_bytes_per_key; };

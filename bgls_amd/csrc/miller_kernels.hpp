@@ -294,152 +294,9 @@ __global__ void __launch_bounds__(128, 2) k_miller_ab64(const Aff<F1<C>>* g1s, c
   }
 }
 
-// ---- throughput shape of the alt-bn128 Miller kernel: 60 pairings per block, single lines, 28-bit-limb consumer ------
-// With the consumer on 28-bit limbs (coop_r28.hpp) the producer wave is the slower half of k_miller_ab64, and a fifth of
-// its step is the product of neighbouring lines.  Here the producer only steps its points and stores its own line
-// (converted to 28-bit limbs); the consumer, which has the slack, folds the six three-term lines of its group itself --
-// the same number of products as three five-term elements plus a single line, two more reductions.  Six lines per group
-// and buffer is exactly the LDS footprint of k_miller_ab64 (38.4 KB), so four blocks still share a CU; lanes 60..63 of the
-// producer idle and the signature pair moves to the epilogue kernel (as on BLS12-381).  A 2^16 batch is 1093 blocks: one
-// more than fit at once, which is irrelevant while launches overlap and a second, nearly empty round when they do not --
-// hence only in throughput mode (bgls_set_throughput_mode).
-template <class C, int DBG = 0>    // DBG 1 / 2: producer / consumer work only (timing, wrong results)
-__global__ void __launch_bounds__(128, 2) k_miller_s60(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, Fp2<C>* out, uint32_t* flags, u32* qp) {
-  static_assert(C::CURVE_ID == 0 && C::TWIST_D, "alt-bn128 only");
-  typedef Coop64<C, true> K;
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  if (wave == 0) {
-    // ---------------- producer: 60 pairings, one per lane; lane 6g + j feeds line j of group g
-    const bool owner = lane < 60;
-    const size_t idx = (size_t)blockIdx.x * 60 + lane;
-    const int tg = owner ? lane / 6 : 0;
-    const int j = owner ? lane % 6 : 0;
-    const int tgb = tg * K::GROUP_DW;
-    Aff<F2<C>> Q;
-    Aff<F1<C>> P;
-    bool valid = owner && idx < n;
-    if (valid) {
-      bool ok = g2_from_bytes<C>(Q, g2s + idx * 4 * C::FP_BYTES);
-      ok = ok && aff_on_curve<F2<C>>(Q);
-      if (!ok) atomicOr(flags, FLAG_ENC);
-      P = g1s[idx];
-      valid = !P.inf && !Q.inf;
-    }
-    if (!valid) {
-      Q.x = f2_load<C>(C::G2);
-      Q.y = f2_load<C>(C::G2 + 2 * C::L);
-      P.x = fp_load<C>(C::G1X);
-      P.y = fp_load<C>(C::G1Y);
-    }
-    G2Proj<C> T = {Q.x, Q.y, f2_one<C>()};
-    u32* const myqp = qp + (size_t)blockIdx.x * QP<C>::DW * 64 + lane;
-    QP<C>::park(myqp, Q, P);
-    int buf = 0;
-    auto done = [&]() {
-      wave_sync();
-      __syncthreads();
-      buf ^= 1;
-    };
-#pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      {
-        const u32* q = QP<C>::launder(myqp);
-        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
-        if constexpr (DBG != 2) dbl_step_emit<C>(T, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
-        done();
-      }
-      const int d = C::LOOP_NAF[i];
-      if (d != 0) {
-        const u32* q = QP<C>::launder(myqp);
-        const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
-        const Fp2<C> qx = QP<C>::ld_f2(q, QP<C>::QX), qy = QP<C>::ld_f2(q, QP<C>::QY);
-        if constexpr (DBG != 2) add_step_emit<C>(T, qx, d > 0 ? qy : f2_neg<C>(qy), LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
-        done();
-      }
-    }
-    {
-      const u32* q = QP<C>::launder(myqp);
-      const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
-      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QX)), gamma_const<C>(1, 2));
-      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(QP<C>::ld_f2(q, QP<C>::QY)), gamma_const<C>(1, 3));
-      if constexpr (DBG != 2) add_step_emit<C>(T, x1, y1, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
-      done();
-    }
-    {
-      const u32* q = QP<C>::launder(myqp);
-      const Fp<C> px = QP<C>::ld_fp(q, QP<C>::PX), py = QP<C>::ld_fp(q, QP<C>::PY);
-      Fp2<C> x2 = f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QX), gamma_const<C>(2, 2));
-      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(QP<C>::ld_f2(q, QP<C>::QY), gamma_const<C>(2, 3)));
-      if constexpr (DBG != 2) add_step_emit<C>(T, x2, y2, LineEmitter<C, true>{LReg{tgb + (buf ? K::RL2 : K::RL), K::NENT}, j, px, py, valid, owner});
-      done();
-    }
-    if (DBG == 0 && valid && f2_is_zero<C>(T.Z)) atomicOr(flags, FLAG_DEGENERATE);     // a degenerate point step leaves Z = 0 (miller_x.hpp)
-  } else {
-    // ---------------- consumer: 10 groups x 6 lanes, six three-term lines per step
-    const bool live = lane < 60;
-    const int g = live ? lane / 6 : 9;
-    const int j = live ? lane % 6 : lane - 60;
-    const int gb = g * K::GROUP_DW;
-    const int rbo = gb + K::RB;
-    F28x2 fj;
-    {
-      const F28 one = r28_load<C>(C::R28_ONE);
-#pragma unroll
-      for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
-    }
-    coop_publish28<C>(rbo, j, fj, live);
-    int buf = 0;
-    auto fold = [&]() {
-      if constexpr (DBG == 1) { buf ^= 1; return; }
-      const int rlo = gb + (buf ? K::RL2 : K::RL);
-#pragma unroll 1
-      for (int m = 0; m < 6; ++m) {
-        fj = coop_dot28_k3<C>(rlo, 3 * m, rbo, j, COOP_SH_D);
-        coop_publish28<C>(rbo, j, fj, live);
-      }
-      buf ^= 1;
-    };
-#pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      __syncthreads();
-      if constexpr (DBG != 1) {
-        fj = coop_sqr_sym28<C>(rbo, j);
-        coop_publish28<C>(rbo, j, fj, live);
-      }
-      fold();
-      if (C::LOOP_NAF[i] != 0) {
-        __syncthreads();
-        fold();
-      }
-    }
-    __syncthreads();
-    fold();
-    __syncthreads();
-    fold();
-    if (live) out[((size_t)blockIdx.x * 10 + g) * 6 + j] = from_r28<C>(fj);
-  }
-}
-
-
-// =====================================================================================================================
-// Decoupled Miller loop: the point steps and the accumulator folds run as two kernels joined through HBM.
-//
-//   k_lines   thread per pairing: parses the key, walks the G2 point steps and writes the scaled line of every step
-//             (three Fp2 coefficients) to a line table in HBM -- no LDS, no barrier, its own register budget
-//   k_fold    wave = 10 groups x 6 lanes, no block-level synchronisation at all: a group folds the lines of NG
-//             pairings per step into its shared Fp12 accumulator, f <- f^2 * l_1 * ... * l_NG (one squaring per NG
-//             pairings instead of per 6), reading the lines back through a small per-wave LDS ring
-//
-// The fused kernels above tie both roles to one block (one barrier per step, one register allocation sized by the
-// hungrier role, LDS footprint fixing two waves per SIMD).  Here the 288 GB of HBM, otherwise idle on this path, is
-// the hand-over buffer: 88 (alt-bn128) / 69 (BLS12-381) lines of 240 / 288 B per pairing, about 1.4 GB per 2^16
-// pairings, written and read once (a few hundred GB/s of the 8 TB/s).  A line table depends on the key and the hash
-// point only through the final scaling by (xP, yP); tables of UNSCALED lines are what a key-set handle caches
-// (bgls_keys_upload), so that verifications against a resident key set skip the point steps altogether.
-//
-// Table layout: entry-major per (step, pairing):  table[(s * n_pad + i) * LINE_DW + e * S2 + d],  e = 0..2, so the NG
-// lines a group needs for one step are contiguous.
+// Step count and line layout of a Miller loop's line table (the prepared key sets of prepared.hpp keep one per key; the decoupled
+// k_lines / k_fold kernels that first used it -- the Miller loop as two kernels joined through HBM, rounds 2-4: never faster than
+// the fused kernels -- were removed in round 5).
 template <class C, bool R28>
 struct LineTab {
   static constexpr int S2 = R28 ? R28_S2 : 2 * C::L;
@@ -452,218 +309,5 @@ struct LineTab {
   }
   static constexpr int NSTEPS = nsteps();
 };
-
-// emitter for dbl_step_emit / add_step_emit: scales coefficient `which` by yP / xP and stores it as entry 0..2 of the
-// pairing's line in the table (entry order as LineEmitter: D-type c0 yP, c1 xP, c2; M-type c2, c1 xP, c0 yP)
-template <class C, bool R28>
-struct GlobalLineEmitter {
-  u32* line;             // this pairing's line of the current step
-  const Fp<C>& xP;
-  const Fp<C>& yP;
-  bool valid;
-  __device__ __forceinline__ void store(int entry, const Fp2<C>& e) const {
-    uint4* p = reinterpret_cast<uint4*>(line + entry * LineTab<C, R28>::S2);
-    if constexpr (R28) {
-      const F28x2 r = to_r28<C>(e);
-      u32 w[20];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) { w[k] = r.c0.v[k]; w[10 + k] = r.c1.v[k]; }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) p[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < C::L / 4; ++k) p[k] = make_uint4(e.c0.v[4 * k], e.c0.v[4 * k + 1], e.c0.v[4 * k + 2], e.c0.v[4 * k + 3]);
-#pragma unroll
-      for (int k = 0; k < C::L / 4; ++k) p[C::L / 4 + k] = make_uint4(e.c1.v[4 * k], e.c1.v[4 * k + 1], e.c1.v[4 * k + 2], e.c1.v[4 * k + 3]);
-    }
-  }
-  __device__ __forceinline__ void operator()(int which, const Fp2<C>& v) const {
-    Fp2<C> e;
-    int entry;
-    if (which == 0) {
-      e = f2ms<C, true>(v, yP);
-      entry = C::TWIST_D ? 0 : 2;
-    } else if (which == 1) {
-      e = f2ms<C, true>(v, xP);
-      entry = 1;
-    } else {
-      e = v;
-      entry = C::TWIST_D ? 2 : 0;
-    }
-    if (!valid) e = (entry == 0) ? f2_one<C>() : f2_zero<C>();
-    store(entry, e);
-  }
-};
-
-// one thread per pairing i < n_pad; pairings i >= n (padding up to whole fold groups), infinite points and bad keys
-// contribute the constant line 1
-template <class C, bool R28>
-__global__ void __launch_bounds__(64, 2) k_lines(const Aff<F1<C>>* g1s, const uint8_t* g2s, size_t n, size_t n_pad, u32* table, uint32_t* flags) {
-  typedef LineTab<C, R28> T;
-  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n_pad) return;
-  Aff<F2<C>> Q;
-  Aff<F1<C>> P;
-  bool valid = i < n;
-  if (valid) {
-    bool ok = g2_from_bytes<C>(Q, g2s + i * 4 * C::FP_BYTES);
-    ok = ok && aff_on_curve<F2<C>>(Q);
-    if (!ok) atomicOr(flags, FLAG_ENC);
-    P = g1s[i];
-    valid = !P.inf && !Q.inf;
-  }
-  if (!valid) {
-    Q.x = f2_load<C>(C::G2);
-    Q.y = f2_load<C>(C::G2 + 2 * C::L);
-    P.x = fp_load<C>(C::G1X);
-    P.y = fp_load<C>(C::G1Y);
-  }
-  G2Proj<C> R = {Q.x, Q.y, f2_one<C>()};
-  u32* line = table + i * T::LINE_DW;
-  const size_t step_dw = n_pad * T::LINE_DW;
-#pragma unroll 1
-  for (int k = 1; k < C::LOOP_LEN; ++k) {
-    dbl_step_emit<C>(R, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
-    line += step_dw;
-    const int d = C::LOOP_NAF[k];
-    if (d != 0) {
-      add_step_emit<C>(R, Q.x, d > 0 ? Q.y : f2_neg<C>(Q.y), GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
-      line += step_dw;
-    }
-  }
-  if constexpr (C::CURVE_ID == 0) {
-    {
-      Fp2<C> x1 = f2_mul<C>(f2_conj<C>(Q.x), gamma_const<C>(1, 2));
-      Fp2<C> y1 = f2_mul<C>(f2_conj<C>(Q.y), gamma_const<C>(1, 3));
-      add_step_emit<C>(R, x1, y1, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
-      line += step_dw;
-    }
-    {
-      Fp2<C> x2 = f2_mul<C>(Q.x, gamma_const<C>(2, 2));
-      Fp2<C> y2 = f2_neg<C>(f2_mul<C>(Q.y, gamma_const<C>(2, 3)));
-      add_step_emit<C>(R, x2, y2, GlobalLineEmitter<C, R28>{line, P.x, P.y, valid});
-    }
-  }
-  if (valid && f2_is_zero<C>(R.Z)) atomicOr(flags, FLAG_DEGENERATE);                 // a degenerate point step leaves Z = 0 (miller_x.hpp)
-}
-
-// LDS of one fold wave: 10 groups x (accumulator region + two line slots)
-template <class C, bool R28>
-struct FoldLds {
-  static constexpr int S2 = LineTab<C, R28>::S2;
-  static constexpr bool XF = !R28 && C::XI_RE == 1;       // 32-bit BLS12-381: plain coefficients only, xi applied after the load
-  static constexpr int RBN = XF ? 6 : 12;
-  static constexpr int RB = 0, RL = RBN * S2;             // line slots: RL + slot * 3 * S2
-  static constexpr int GROUP_DW = (RBN + 2 * 3) * S2;
-  static constexpr int WAVE_BYTES = 10 * GROUP_DW * 4;
-};
-
-// KARA (R28 only): three-pile Karatsuba dot products (fewer multiplications, ~190 registers) or the four-pile
-// schoolbook form (fits the 168 registers of three waves per SIMD)
-template <class C, bool R28, bool KARA>
-__global__ void __launch_bounds__(64, KARA ? 2 : 3) k_fold(const u32* table, size_t n_pad, int ng, Fp2<C>* out) {
-  typedef LineTab<C, R28> T;
-  typedef FoldLds<C, R28> K;
-  extern __shared__ u32 lds[];
-  const int lane = threadIdx.x;
-  const bool live = lane < 60;
-  const int g = live ? lane / 6 : 9;
-  const int j = live ? lane % 6 : lane - 60;
-  const int gb = g * K::GROUP_DW;
-  const size_t G = (size_t)blockIdx.x * 10 + g;                 // global group: pairings [G * ng, (G + 1) * ng)
-  // each of the 6 lanes of a group fetches chunks j, j + 6, j + 12 (16 B each) of a line
-  constexpr int NCH = T::LINE_DW / 4;                            // 15 (r28) / 12 (alt-bn128, 32-bit) / 18 (BLS12-381)
-  const u32* src = table + (G * (size_t)ng) * T::LINE_DW + 4 * j;
-  const size_t step_dw = n_pad * T::LINE_DW;
-  uint4 pf[3];
-  auto prefetch = [&](const u32* ln) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (j + 6 * q < NCH) pf[q] = *reinterpret_cast<const uint4*>(ln + 24 * q);
-  };
-  auto stash = [&](int slot) {
-    if (live) {
-      uint4* dst = reinterpret_cast<uint4*>(lds + gb + K::RL + slot * T::LINE_DW + 4 * j);
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (j + 6 * q < NCH) dst[6 * q] = pf[q];
-    }
-    wave_sync();
-  };
-  const int nsteps = T::NSTEPS;
-  // line sequence: step-major, the ng lines of a step one after the other
-  int s = 0, m = 0, slot = 0;
-  auto next_line = [&]() {                                       // address of the line after (s, m), or nullptr at the end
-    int s2 = s, m2 = m + 1;
-    if (m2 == ng) { m2 = 0; ++s2; }
-    return s2 < nsteps ? src + (size_t)s2 * step_dw + (size_t)m2 * T::LINE_DW : (const u32*)nullptr;
-  };
-  prefetch(src);
-  if constexpr (R28) {
-    const int rbo = gb + K::RB;
-    F28x2 fj;
-    {
-      const F28 one = r28_load<C>(C::R28_ONE);
-#pragma unroll
-      for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
-    }
-    coop_publish28<C>(rbo, j, fj, live);
-    auto fold_step = [&]() {
-#pragma unroll 1
-      for (m = 0; m < ng; ++m) {
-        stash(slot);
-        const u32* nx = next_line();
-        if (nx) prefetch(nx);
-        const int rlo = gb + K::RL + slot * T::LINE_DW;
-        if constexpr (KARA) fj = coop_dot28_k3<C>(rlo, 0, rbo, j, COOP_SH_D);
-        else fj = coop_dot28<C, 3>(rlo, 0, rbo, j, COOP_SH_D);
-        coop_publish28<C>(rbo, j, fj, live);
-        slot ^= 1;
-      }
-      ++s;
-    };
-#pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      fj = coop_sqr_sym28<C>(rbo, j);
-      coop_publish28<C>(rbo, j, fj, live);
-      fold_step();
-      if (C::LOOP_NAF[i] != 0) fold_step();
-    }
-    fold_step();
-    fold_step();
-    if (live) out[G * 6 + j] = from_r28<C>(fj);
-  } else {
-    const LReg rb = {gb + K::RB, 12};
-    Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
-    coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-    auto fold_step = [&]() {
-#pragma unroll 1
-      for (m = 0; m < ng; ++m) {
-        stash(slot);
-        const u32* nx = next_line();
-        if (nx) prefetch(nx);
-        const LReg rl = {gb + K::RL + slot * T::LINE_DW, 3};
-        fj = coop_dot_inl<C, 3, K::XF>(rl, 0, 1, rb, j, C::TWIST_D ? COOP_SH_D : COOP_SH_M);
-        coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-        slot ^= 1;
-      }
-      ++s;
-    };
-#pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
-      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-      fold_step();
-      if (C::LOOP_NAF[i] != 0) fold_step();
-    }
-    if constexpr (C::CURVE_ID == 0) {
-      fold_step();
-      fold_step();
-    } else {
-      if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
-    }
-    if (live) out[G * 6 + j] = fj;
-  }
-}
 
 }  // namespace bgls

@@ -122,6 +122,26 @@ RX_DEV Sx<C, SX_T> pair_sqrsub(const Sx<C, LG>& g, const Sx<C, LE>& e, const Sx<
     return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -pair_even1(f.v[i], odd) : -pair_odd1(f.v[i], odd));
   });
 }
+// own half of g^2 - 3 e^2, one reduction: pair_sqrsub(g, e, 3 e) with the multiple formed in the ROW factors, so that 3 e never
+// occupies NL registers next to e (round 5: the doubling step's register peak sits on this product; BLS12-381 spilled there)
+template <class C, int LG, int LE>
+RX_DEV Sx<C, SX_T> pair_sqrsub3(const Sx<C, LG>& g, const Sx<C, LE>& e, bool odd) {
+  // Budget (units 2^(2W-8)): g is one parallel carry step behind a sum (limbs in (-2^4, 2^W + 2^4)), so the sum g0 + g1 stays below
+  // 2 (2^W + 2^4) and the difference g0 - g1 inside +-(2^W + 2^5): 512.0002 units, counted as 513, where the bounds' product
+  // (2 * 17) * (2 * 17) would say 1156 -- with that BLS12-381's fourteen rows of 3 e^2 (1536 units) would not fit.
+  static_assert(LG <= SX_F, "g: a reduction's output or one carry step behind a sum");
+  constexpr int BUDGET = 513 + 6 * LE * LE;
+  static_assert(rx_fits<C>(BUDGET), "three products per reduction: 28-bit forms");
+  Sx<C, 2 * LG> u;
+#pragma unroll
+  for (int i = 0; i < C::RX_NL; ++i) u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
+  const i32 even = odd ? 0 : -1;
+  const Sx<C, LE> pe = pair_swap_neg_even<C>(e, odd);
+  const i32* const cols[3] = {u.v, e.v, pe.v};
+  return sx_montr<C, 3, BUDGET>(cols, [&](int k, int i) {
+    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -3 * pair_even1(e.v[i], odd) : -3 * pair_odd1(e.v[i], odd));
+  });
+}
 // 3 b' z of the doubling step: a product by the constant on both curves.  (BLS12-381's 3 b' = 12 (1 + i) could be formed with
 // additions, as pairing.hpp does, but the VALUE would grow to 25 p and the P-free line coefficient E - B must reach the
 // consumer below 32 p after the fat multiple of p that makes it non-negative; a reduction is what brings it back.)
@@ -160,7 +180,8 @@ RX_DEV void dbl_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_F> Fv = sx_normf<C>(sx_mulc<3, C>(E));
   R.X = pair_mul<C>(A, rx_nf<C>(sx_sub<C>(B, Fv)), odd);
   const Sx<C, SX_F> G = sx_normf<C>(sx_half<C>(sx_add<C>(B, Fv)));
-  if constexpr (rx_lazy<C>) R.Y = pair_sqrsub<C>(G, E, Fv, odd);                       // G^2 - 3 E^2   (the step's register peak: Z3 and I come after it)
+  // G^2 - 3 E^2: the step's register peak (Z3 and I come after it).  The 28-bit forms take 3 E in the row factors, so that Fv is dead here.
+  if constexpr (rx_lazy<C>) R.Y = pair_sqrsub3<C>(G, E, odd);
   else R.Y = sx_norm<C>(sx_sub<C>(pair_sqr<C>(G, odd), pair_mul<C>(E, Fv, odd)));
   const auto I = sx_sub<C>(E, B);
   R.Z = pair_mul<C>(B, H, odd);

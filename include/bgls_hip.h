@@ -255,32 +255,25 @@ int bgls_final_verify_collect(int curve);
  * the neighbours fill it.  Results are identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the
  * environment. */
 int bgls_set_throughput_mode(int on);
-/* Environment switches, each read ONCE per process.  None changes a result: they select between kernels that compute the same
- * bytes and exist for A/B measurements and for the legacy-path tests (tests/test_gpu_legacy_paths.py, tests/test_gpu_x60.py).
+/* Environment switches, each read ONCE per process (four in all).  None changes a result: they select between kernels that
+ * compute the same bytes and exist for A/B measurements and for the legacy-path tests (tests/test_gpu_legacy_paths.py,
+ * tests/test_gpu_x60.py).
  *   BGLS_THROUGHPUT=1     = bgls_set_throughput_mode(1)
- *   BGLS_MILLER_SHAPE, BGLS_X60_ROT, BGLS_X_NP=60|64          see bgls_set_miller_shape below
- *   BGLS_FINALX=0         final exponentiation on 32-bit limbs (k_final36)      BGLS_LATX=0   latency Miller kernel on 32-bit limbs
- *   BGLS_EPIX=0           verification epilogue on 32-bit limbs (k_cofactor_epilogue)
- *   BGLS_SUMX=0|1|2       G2 key sums: 32-bit limbs / one lane / lane pairs (default 2);  BGLS_SUM_WAVES = waves of their main pass
- *   BGLS_SUMTREE=0        the tree above a key sum's partials as one launch per level instead of one launch
- *   BGLS_SUMTREEX=0       that one-launch tree with its additions on 32-bit limbs (round 4's first form) instead of carry-free lane pairs
- *   BGLS_G1X=0            BLS12-381 G1 scalar multiplications (Sign, ScalePoints, HashToG1's cofactor clearing) on 32-bit limbs
- *   BGLS_LATX2=0          the latency Miller kernel / epilogue with a one-wave accumulator (round 3's two-wave block)
- *   BGLS_SIG_EARLY=0      the signature pair of a lone large verification behind its reduce stage instead of beside its hashing
- *   BGLS_REDUCEX=0        every pass of the reduce stage on the six-lane 32-bit kernel (k_reduce_coop)
+ *   BGLS_MILLER_SHAPE=4|5 = bgls_set_miller_shape(shape, 0) below
+ *   BGLS_LEGACY=<mask>    the one 32-bit-limb fallback kept per stage: 1 final exponentiation (k_final36), 2 latency Miller loop
+ *                         (k_miller_lat), 4 epilogue (k_cofactor_epilogue), 8 G2 key sums (k_sum_main), 16 key-sum tree as one launch
+ *                         per level, 32 BLS12-381 G1 scalar multiplications on 32-bit limbs, 64 every reduce pass on k_reduce_coop
  *   BGLS_NO_RCCL=1        host exchange between the devices of a key set instead of RCCL */
 /* Shape of the Miller stage.  0 (default): automatic -- up to 128 pairings the latency kernel; above, k_miller_x60 (carry-free
- * 28-bit limbs, lane-pair point steps) with 60 pairings per block, or with 64 per block where that saves a nearly empty last
- * round of the 1024 resident blocks outside throughput mode (61 441..65 536 pairings: exactly 2^16 is one round).  1..3:
- * decoupled -- k_lines writes every pairing's scaled line coefficients to a table in HBM, k_fold folds them into shared
- * accumulators, pairings_per_group pairings per squaring (1: 32-bit limbs, 2: 28-bit limbs, 3: 28-bit limbs + Karatsuba; 2
- * and 3 alt-bn128 only, others fall back to 1).  4: k_miller_x60 for every batch; pairings_per_group is then a development
- * mode word, validated: bits 0-1 role placement (0 by SIMD id, 1 wave 2 consumes, 2 rotate by block), bit 2 consumer
- * priority, bit 3 producer priority, bit 4 the 64-pairing block form (clear: the 60-pairing form); values above 31 are
- * rejected.  5: the 32-bit fused kernels (k_miller_ab64) for every batch.
- * Environment presets, read once at the first use: BGLS_MILLER_SHAPE, BGLS_X60_ROT (the mode word), BGLS_X_NP=60|64.
+ * limbs: nine of 29 bits on alt-bn128, fourteen of 28 on BLS12-381; lane-pair point steps) with 60 pairings per block, or with 64
+ * per block where that saves a nearly empty last round of the 1024 resident blocks outside throughput mode (61 441..65 536
+ * pairings: exactly 2^16 is one round).  4: k_miller_x60 for every batch; `mode` is then a development mode word, validated: bits
+ * 0-1 role placement (0 by SIMD id, 1 wave 2 consumes, 2 rotate by block), bit 2 consumer priority, bit 3 producer priority, bit 4
+ * the 64-pairing block form (clear: the 60-pairing form); values above 31 are rejected.  5: the 32-bit fused kernel
+ * (k_miller_ab64) for every batch.  `mode` is ignored for shapes 0 and 5; any other shape is BGLS_ERR_ARG (shapes 1-3, the Miller loop
+ * as two kernels joined through a line table in HBM, were removed in round 5: never faster than the fused kernels).
  * Results (partial products, GT bytes, verdicts) are identical for every shape. */
-int bgls_set_miller_shape(int shape, int pairings_per_group);
+int bgls_set_miller_shape(int shape, int mode);
 /* Contexts 0..15: each owns a HIP stream, its device workspaces and stage timers; the calling thread works on the one it
  * selected (default 0).  Two contexts let one host thread keep two verifications in flight (bench.py). */
 int bgls_select_context(int index);

@@ -87,7 +87,7 @@ def test_every_abi_body_is_guarded():
     src = ""
     csrc = os.path.join(ROOT, "bgls_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith(".hip"):
+        if f.endswith((".hip", ".inc")):
             src += open(os.path.join(csrc, f)).read()
     block = src[src.index('extern "C" {'):]
     names = [m.group(1) for m in re.finditer(r"^int (bgls_[a-z0-9_]+)\(", block, flags=re.M)]

@@ -81,7 +81,7 @@ def test_key_sum_tree_shapes_match_the_oracle(gpu_lib, cid, fp):
     partial, two, odd counts whose single nodes pass through levels unpaired, counts around the 128-key blocks of the main pass,
     the 3072-partial cap -- same bytes as the oracle's sequential additions and as (sum sk) g2; with the point at infinity and a
     repeated key (P + P in the tree: the doubling case of the group law) among the inputs; and the same sums with the tree as one
-    launch per level (BGLS_SUMTREE=0 is read once per process, so that form runs in the legacy-path tests)."""
+    launch per level (BGLS_LEGACY bit 16 is read once per process, so that form runs in the legacy-path tests)."""
     lib = gpu_lib
     rnd = random.Random(77 + cid)
     nmax = 70000

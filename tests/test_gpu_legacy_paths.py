@@ -1,7 +1,9 @@
-"""GPU tier: the kernels that round 3 replaced stay selectable for A/B measurements (BGLS_FINALX=0: 36-lane final exponentiation
-on 32-bit limbs, BGLS_LATX=0: k_miller_lat, BGLS_SUMX=0 / 1: key sums on 32-bit limbs / on one lane, BGLS_EPIX=0: k_cofactor_epilogue, BGLS_SUMTREE=0: k_sum_coop per level instead of k_sum_tree, BGLS_SUMTREEX=0: the tree's additions on 32-bit limbs (k_sum_tree) instead of k_sum_tree_x, BGLS_G1X=0: BLS12-381 Sign / ScalePoints / HashToG1 cofactor clearing on 32-bit limbs, BGLS_REDUCEX=0: every reduce pass on k_reduce_coop).  The switches are read once
-per process, so each combination runs in a child process: PairingProduct of a handful of pairings (the latency path: k_miller_lat(x)
-+ reduce + final exponentiation) must give the C oracle's GT bytes, and a 300-key aggregate of public keys the oracle's point."""
+"""GPU tier: ONE 32-bit-limb fallback per stage stays selectable for A/B measurements, all behind the bit mask BGLS_LEGACY (read
+once per process, so each combination runs in a child process): 1 k_final36 (final exponentiation), 2 k_miller_lat (latency Miller
+loop), 4 k_cofactor_epilogue, 8 k_sum_main (G2 key sums), 16 the key-sum tree as one launch per level, 32 BLS12-381 G1 scalar
+multiplications on 32-bit limbs, 64 every reduce pass on k_reduce_coop; BGLS_MILLER_SHAPE=5 puts the Miller stage on the 32-bit fused
+kernel k_miller_ab64.  PairingProduct of a handful of pairings (latency Miller loop + reduce + final exponentiation) must give the C
+oracle's GT bytes, a 700-key aggregate of public keys the oracle's point, a small verification the oracle's verdict."""
 import json
 import os
 import subprocess
@@ -62,8 +64,9 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("env", [{"BGLS_FINALX": "0", "BGLS_LATX": "0", "BGLS_SUMX": "0", "BGLS_EPIX": "0"}, {"BGLS_SUMX": "1"}, {"BGLS_SUMTREE": "0"}, {"BGLS_SUMTREEX": "0"}, {"BGLS_G1X": "0"}, {"BGLS_REDUCEX": "0"}, {"BGLS_LATX2": "0"}, {}],
-                         ids=["32-bit tails and key sum", "one-lane key sum", "key-sum tree as one launch per level", "key-sum tree with 32-bit additions", "32-bit G1 scalar multiplications", "six-lane reduce passes", "one-wave accumulator in the latency Miller kernel", "defaults"])
+@pytest.mark.parametrize("env", [{"BGLS_LEGACY": "15"}, {"BGLS_LEGACY": "16"}, {"BGLS_LEGACY": "32"}, {"BGLS_LEGACY": "64"}, {"BGLS_LEGACY": "127", "BGLS_MILLER_SHAPE": "5"}, {}],
+                         ids=["32-bit tails and key sum", "key-sum tree as one launch per level", "32-bit G1 scalar multiplications", "six-lane reduce passes",
+                              "every fallback at once", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
     golden = os.path.join(ROOT, "tests", "golden")
     code = CHILD % (ROOT, golden)

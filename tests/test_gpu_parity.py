@@ -314,9 +314,9 @@ def test_bad_encodings_are_errors_not_accepts(gpu_lib, curve):
 
 
 def test_throughput_mode_agrees(gpu_lib, curve):
-    """bgls_set_throughput_mode is the one runtime switch the library keeps: alt-bn128 batches then take the 60-pairing
-    Miller shape (k_miller_s60, signature pair in the epilogue kernel).  Same golden GT bytes, same verdicts, same
-    canonical partial-product bytes as the default shape."""
+    """bgls_set_throughput_mode tells the engine that several verifications are in flight: no fork onto the side stream, the
+    60-pairing block form and no producer priority even for a batch that is one round of blocks.  Same golden GT bytes, same
+    verdicts, same canonical partial-product bytes as the default mode."""
     import torch
     cid, n_fp = curve["id"], curve["fp"]
     lib = gpu_lib
