@@ -273,7 +273,9 @@ class Lanes:
         while len(Lanes._streams) < L:
             Lanes._streams.append(torch.cuda.Stream(device=dev))
         self.lanes = [{"stream": Lanes._streams[k], "part": torch.zeros(gtb, dtype=torch.uint8, device=dev),
-                       "flags": torch.zeros(1, dtype=torch.int32, device=dev), "probe": torch.zeros(1, dtype=torch.int32, device=dev)} for k in range(L)]
+                       "words": torch.zeros(2, dtype=torch.int32, device=dev)} for k in range(L)]
+        for ln in self.lanes:
+            ln["flags"] = ln["words"][0:1]       # the verification's status word; word 1 is the rank's share of the digest probe (multi-GPU)
 
     def run(self, count, submit, overlap, settle=None):
         """settle(k, verdict) -> verdict: called after a lane's verdict has been collected (its stream is idle then); the
@@ -338,18 +340,19 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         h = ln["stream"].cuda_stream
         check(lib.bgls_select_context(k), "select_context")
         with torch.cuda.stream(ln["stream"]):
-            ln["flags"].zero_()
+            ln["words"].zero_()
             if h2d:                       # messages arrive from the host inside the timed region (keys stay resident)
                 msgs_t.copy_(h_msgs, non_blocking=True)
             if world > 1:
                 # duplicates may straddle shards (containsDuplicateMessage is a rule about the whole list): the ranks exchange
-                # 16-byte digests of their messages, not the messages (16 MiB instead of 64 MiB at 2^20), and scan those; a hit is
-                # settled exactly when the verdict is collected (settle below)
-                ln["probe"].zero_()
+                # 16-byte digests of their messages, not the messages (16 MiB instead of 64 MiB at 2^20), and rank r scans the digests
+                # whose first byte is r mod world (round 5: 1 / world of the inserts each; equal digests share a bucket); the probe word
+                # travels with the status word, so every rank holds the OR; a hit is settled exactly when the verdict is collected
                 ln["msgs"] = msgs_t
                 enqueue_digest_probe(lambda m, cnt: digests_of(m, cnt, h),
-                                     lambda buf, rl, cnt: check(lib.bgls_duplicate_scan_dev(buf.data_ptr(), rl, rl, cnt, ln["probe"].data_ptr(), h), "duplicate_scan_dev"),
-                                     msgs_t, n, world)
+                                     lambda buf, rl, cnt, bucket, nb: check(lib.bgls_duplicate_scan_bucket_dev(buf.data_ptr(), rl, rl, cnt, bucket, nb, ln["words"].data_ptr() + 4, h),
+                                                                            "duplicate_scan_bucket_dev"),
+                                     msgs_t, n, world, rank=rank)
             if handle is not None:
                 check(lib.bgls_miller_product_keys_dev(handle, t_sig.data_ptr(), msgs_t.data_ptr(), 64, 64, n, 1, ln["part"].data_ptr(), ln["flags"].data_ptr(), h),
                       "miller_product_keys_dev")
@@ -359,7 +362,8 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
             if world == 1:
                 check(lib.bgls_final_verify_submit_dev(cid, ln["part"].data_ptr(), 1, ln["flags"].data_ptr(), h), "final_verify_submit_dev")
             else:
-                parts, merged = gather_partials_and_flags(ln["part"], ln["flags"], world)
+                parts, merged = gather_partials_and_flags(ln["part"], ln["words"], world)      # word 0: status, word 1: this rank's bucket of the digest probe
+                ln["merged"] = merged
                 check(lib.bgls_final_verify_submit_dev(cid, parts.data_ptr(), world, merged.data_ptr(), h), "final_verify_submit_dev")
 
     gate = {"digest_hits": 0}
@@ -373,7 +377,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         """A digest hit of lane k's global duplicate scan (a real duplicate or a 2^-128 collision) is settled by the exact scan over
         the gathered messages; a duplicate makes the verification false (bgls/bgls.go:98-100)."""
         ln = lanes.lanes[k]
-        if world == 1 or int(ln["probe"].item()) == 0:
+        if world == 1 or int(ln["merged"][1].item()) == 0:
             return verdict
         gate["digest_hits"] += 1
         word = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "bgls_gt_identity": (ci, [ci, u8p]),
     "bgls_miller_product_dev": (ci, [ci, vp, vp, vp, sz, sz, sz, ci, vp, vp, vp]),
     "bgls_duplicate_scan_dev": (ci, [vp, sz, sz, sz, vp, vp]),
+    "bgls_duplicate_scan_bucket_dev": (ci, [vp, sz, sz, sz, ctypes.c_uint, ctypes.c_uint, vp, vp]),
     "bgls_message_digests_dev": (ci, [vp, sz, sz, sz, vp, vp]),
     "bgls_final_verify_submit_dev": (ci, [ci, vp, sz, vp, vp]),
     "bgls_final_verify_collect": (ci, [ci]),

@@ -23,11 +23,16 @@ __device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n) {
   return h;
 }
 
-__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
+// bucket / n_buckets (n_buckets > 1): only the records whose first byte is `bucket` mod n_buckets enter the table -- equal records
+// share a bucket, so n_buckets scans (one per rank of a multi-GPU verification, over the all-gathered digests) find exactly what
+// one scan of everything finds, each on 1 / n_buckets of the inserts.  A table that fills up (a bucket far above its share: not
+// digests, or an adversary's) reports a hit, which the caller settles with the exact scan: never a miss.
+__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m = mv.ptr(i);
   const size_t len = mv.size(i);
+  if (n_buckets > 1 && (len == 0 ? 0u : (uint32_t)m[0]) % n_buckets != bucket) return;
   uint32_t slot = (uint32_t)msg_hash64(m, len) & mask;
   for (uint32_t probe = 0; probe <= mask; ++probe) {
     uint32_t prev = atomicCAS(&table[slot], 0u, (uint32_t)i + 1u);
@@ -48,6 +53,7 @@ __global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask
     }
     slot = (slot + 1u) & mask;
   }
+  atomicOr(flags, FLAG_DUP);          // every slot taken by other records: undecided, reported as a hit (see above)
 }
 
 // alt-bn128 try-and-increment as compacting rounds (curves/hash.go:53-77 has data-dependent trip
@@ -433,8 +439,8 @@ namespace kl {
 
 void msg_digest(hipStream_t st, MsgView mv, size_t n, uint8_t* out) { k_msg_digest<<<nblk(n, 256), 256, 0, st>>>(mv, n, out); }
 
-void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags) {
-  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags);
+void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets) {
+  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags, bucket, n_buckets);
 }
 
 // alt-bn128: (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.  Each

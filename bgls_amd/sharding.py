@@ -30,48 +30,72 @@ def all_gather_bytes(part, world):
 
 
 def gather_partials_and_flags(part, flags, world):
-    """One all-gather carries every rank's partial product AND its status word (duplicate / bad encoding / hash failure
+    """One all-gather carries every rank's partial product AND its status words (duplicate / bad encoding / hash failure
     bits, include/bgls_hip.h): a malformed key seen by one rank must make EVERY rank answer false, as the single-GPU call
-    does.  part: uint8[gt_size]; flags: int32[1] on the same device.  Returns (uint8[world * gt_size] in rank order,
-    int32[1] = OR over ranks)."""
+    does.  part: uint8[gt_size]; flags: int32[k] on the same device, k >= 1 -- word 0 is the verification's status word, further
+    words ride along (word 1 in bench.py: the rank's share of the bucketed digest probe).  Returns (uint8[world * gt_size] in
+    rank order, int32[k] = OR over ranks, word by word)."""
     g = part.numel()
+    k = flags.numel()
     both = all_gather_bytes(torch.cat([part.reshape(-1), flags.reshape(-1).view(torch.uint8)]), world)
     parts = both[:, :g].contiguous().reshape(-1)
-    words = both[:, g:].contiguous().view(torch.int32).reshape(-1)
-    merged = words[0:1].clone()
+    words = both[:, g:].contiguous().view(torch.int32).reshape(world, k)
+    merged = words[0].clone()
     for r in range(1, world):
-        merged |= words[r:r + 1]
+        merged |= words[r]
     return parts, merged
 
 
-def global_duplicate_scan(scan, msgs, n_local, world, digest=None, msg_len=64, probe=None):
+def _bucketed(fn, rank, world):
+    """probe callbacks come in two shapes: fn(buffer, record_len, count) scans everything (rounds 3-4), fn(buffer, record_len,
+    count, bucket, n_buckets) scans one bucket (round 5: bgls_duplicate_scan_bucket_dev).  rank None keeps the old call."""
+    if rank is None:
+        return lambda buf, rl, cnt: fn(buf, rl, cnt)
+    return lambda buf, rl, cnt: fn(buf, rl, cnt, rank, world)
+
+
+def global_duplicate_scan(scan, msgs, n_local, world, digest=None, msg_len=64, probe=None, rank=None):
     """containsDuplicateMessage (bgls/bgls.go:139-150) is a property of the WHOLE message list: two equal messages may sit
     in different shards.  `scan(buffer, record_len, count)` is the exact scan over `count` fixed-stride records
     (bgls_duplicate_scan_dev on the GPU path: sets the duplicate bit of the caller's status word).
 
     With `digest` (messages -> uint8[n_local * 16], bgls_message_digests_dev) the ranks exchange 16-byte digests instead of the
-    messages -- 16 MiB instead of 64 MiB at 2^20 signers -- and every rank scans the world * n_local digests with
-    `probe(buffer, 16, count) -> bool` (the same exact scan on a scratch status word).  Equal messages have equal digests, so
+    messages -- 16 MiB instead of 64 MiB at 2^20 signers -- and scan those with `probe`.  Equal messages have equal digests, so
     "no two digests equal" proves the rule; a hit (a real duplicate, or a 2^-128 collision) is settled by gathering the
-    messages and running the exact scan, as the digest-free path always does.  Every rank takes the same branch: all of
-    them scan the same gathered digests."""
+    messages and running the exact scan, as the digest-free path always does.
+
+    rank=None (rounds 3-4): `probe(buffer, 16, count) -> bool` scans ALL world * n_local digests on every rank -- the scan does not
+    get shorter with more GPUs.  rank=r (round 5): `probe(buffer, 16, count, bucket, n_buckets) -> bool` scans the digests whose first
+    byte is r mod world (bgls_duplicate_scan_bucket_dev): 1 / world of the inserts per rank; equal digests share a bucket, so the OR
+    of the ranks' answers (one all-reduce of a single word) is the answer of the full scan.  EVERY rank must pass the same
+    digest / probe / rank-or-None choice: the collectives are entered in the same order on all of them.  Returns None when the
+    digests prove that there is no duplicate, otherwise what `scan` returns."""
     if world == 1:
         return scan(msgs, msg_len, n_local)
     if digest is not None and probe is not None:
         digests = all_gather_bytes(digest(msgs, n_local), world).reshape(-1)
-        if not probe(digests, 16, world * n_local):
+        hit = bool(_bucketed(probe, rank, world)(digests, 16, world * n_local))
+        if rank is not None:
+            word = torch.tensor([1 if hit else 0], dtype=torch.int32, device=digests.device)
+            if word.is_cuda and dist.get_backend() == "gloo":
+                word = word.cpu()
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)
+            hit = bool(int(word.item()))
+        if not hit:
             return None
     return scan(all_gather_bytes(msgs, world).reshape(-1), msg_len, world * n_local)
 
 
-def enqueue_digest_probe(digest, probe_scan, msgs, n_local, world):
+def enqueue_digest_probe(digest, probe_scan, msgs, n_local, world, rank=None):
     """The asynchronous half of the digest path, for pipelined callers (bench.py: several verifications in flight): enqueue the
-    digests, their all-gather and the scan over them -- `probe_scan(buffer, 16, count)` ORs the duplicate bit into a word of
-    the caller's that is NOT the verification's status word.  Nothing is read back here.  When the verdict is collected the
-    caller reads that word; if it is set, `settle_digest_hit` runs the exact scan over the gathered messages (every rank sees
-    the same digests, so every rank takes the same branch)."""
+    digests, their all-gather and the scan over them -- `probe_scan(buffer, 16, count[, bucket, n_buckets])` ORs the duplicate bit
+    into a word of the caller's that is NOT the verification's status word.  Nothing is read back here.  With rank=r the scan covers
+    bucket r of `world` only; the caller then sends its probe word along with its status word (gather_partials_and_flags takes
+    several words) so that every rank holds the OR.  When the verdict is collected the caller reads that word; if it is set,
+    `settle_digest_hit` runs the exact scan over the gathered messages (every rank sees the same OR, so every rank takes the same
+    branch)."""
     digests = all_gather_bytes(digest(msgs, n_local), world).reshape(-1)
-    probe_scan(digests, 16, world * n_local)
+    _bucketed(probe_scan, rank, world)(digests, 16, world * n_local)
 
 
 def settle_digest_hit(scan, msgs, n_local, world, msg_len=64):

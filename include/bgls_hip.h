@@ -232,6 +232,14 @@ int bgls_miller_product_dev(int curve, const void* d_sig, const void* d_keys, co
  * (a duplicate may straddle two shards); the per-shard scan inside bgls_miller_product_dev covers one GPU. */
 int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_stride, size_t n, void* d_flags,
                             void* stream);
+/* The same scan restricted to ONE bucket of the records: only those whose first byte is `bucket` mod n_buckets (bucket < n_buckets
+ * <= 256) enter the table.  Equal records share a bucket, so rank r of an N-rank verification scanning bucket r of the all-gathered
+ * 16-byte digests finds, between the ranks, exactly what one scan of everything finds -- with 1/N of the inserts each, so the scan
+ * scales with the number of GPUs (the OR of the ranks' words travels with their status words).  The table is sized for twice the
+ * bucket's fair share; if it fills up (records that are not digests, or chosen by an adversary) bit 0 is set: callers treat a hit
+ * as "undecided" and settle it with the exact scan over the messages, so this can cost time but never miss a duplicate. */
+int bgls_duplicate_scan_bucket_dev(const void* d_recs, size_t rec_len, size_t rec_stride, size_t n, unsigned bucket,
+                                   unsigned n_buckets, void* d_flags, void* stream);
 /* 16-byte digests (the first 16 bytes of BLAKE2b-512) of n device-resident fixed-stride messages, to d_out16 (n x 16 bytes,
  * 16-byte aligned).  What the ranks of a multi-GPU verification exchange for the global containsDuplicateMessage rule
  * (bgls/bgls.go:139-150) instead of the messages themselves: no two equal digests => no two equal messages; a pair of equal

@@ -139,6 +139,85 @@ def test_two_rank_flags_and_cross_shard_duplicates():
         assert without_dup == (None, 1, 1, 2 * 4 * 16), without_dup    # no digest hit: no exact scan, no message ever gathered
 
 
+def _worker_bucketed(rank, world, port, q):
+    """Round 5: the digest scan itself is sharded.  Rank r scans only the digests whose first byte is r mod world (what
+    bgls_duplicate_scan_bucket_dev does on the GPU), the ranks' answers are OR-ed, and the result must be what the scan of
+    everything gives: a straddling duplicate is found by exactly one rank (the bucket's owner) and known to both; a forced digest
+    collision between two DIFFERENT messages is settled as "no duplicate" by the exact scan; a clean batch gathers no message."""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, ln = 64, 64
+    rnd = __import__("random").Random(977)
+    all_msgs = [rnd.randbytes(ln) for _ in range(world * n_local)]
+    stats = {"own_hits": 0, "inserted": 0, "exact": 0, "exact_dup": None}
+    forced = {}
+
+    def dig(m):
+        return forced.get(bytes(m), hashlib.blake2b(bytes(m)).digest()[:16])
+
+    def digest(m, cnt):
+        raw = bytes(m.numpy())
+        return torch.frombuffer(bytearray(b"".join(dig(raw[i * ln:(i + 1) * ln]) for i in range(cnt))), dtype=torch.uint8)
+
+    def probe(buf, rl, count, bucket, n_buckets):
+        raw = bytes(buf.numpy())
+        mine = [raw[i * rl:(i + 1) * rl] for i in range(count) if raw[i * rl] % n_buckets == bucket]
+        stats["inserted"] += len(mine)
+        hit = len(set(mine)) != len(mine)
+        stats["own_hits"] += hit
+        return hit
+
+    def exact(buf, rl, count):
+        raw = bytes(buf.numpy())
+        items = [raw[i * rl:(i + 1) * rl] for i in range(count)]
+        stats["exact"] += 1
+        stats["exact_dup"] = len(set(items)) != len(items)
+        return stats["exact_dup"]
+
+    def run(msgs):
+        mine = b"".join(msgs[rank * n_local:(rank + 1) * n_local])
+        return global_duplicate_scan(exact, torch.frombuffer(bytearray(mine), dtype=torch.uint8), n_local, world, digest=digest, msg_len=ln,
+                                     probe=probe, rank=rank)
+
+    clean = run(all_msgs)                                             # None: proven duplicate-free by the digests, no message gathered
+    inserted_clean, exact_clean = stats["inserted"], stats["exact"]
+    dup = list(all_msgs)
+    dup[world * n_local - 3] = dup[5]                                 # message 5 of rank 0 again near the end of the last rank's range
+    with_dup = run(dup)
+    hits_dup = stats["own_hits"]
+    stats["own_hits"] = 0
+    forced[bytes(all_msgs[7])] = dig(all_msgs[n_local + 9])           # two DIFFERENT messages, one digest (a 2^-128 event, forced)
+    collided = run(all_msgs)
+    # several status words in one gather: word 0 = status, word 1 = this rank's probe word
+    parts, merged = gather_partials_and_flags(torch.full((384,), rank + 1, dtype=torch.uint8), torch.tensor([0, 1 if rank == 1 else 0], dtype=torch.int32), world)
+    q.put((rank, clean, inserted_clean, exact_clean, with_dup, hits_dup, collided, stats["own_hits"], stats["exact"], merged.tolist(), parts.numel()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_digest_scan():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert sum(r[2] for r in res) == 2 * 64                         # every digest entered exactly one rank's table
+    assert all(0 < r[2] < 2 * 64 for r in res)                      # ... and neither rank scanned them all
+    assert sum(r[5] for r in res) == 1                              # the duplicate pair was found by exactly one rank (its bucket's owner)
+    assert sum(r[7] for r in res) == 1                              # the forced collision likewise
+    for rank, clean, inserted_clean, exact_clean, with_dup, hits_dup, collided, own_coll, exact_total, merged, nparts in res:
+        assert clean is None and exact_clean == 0                   # no hit anywhere: no rank gathered a message
+        assert with_dup is True                                     # both ranks learn of the duplicate, both run the exact scan
+        assert collided is False                                    # equal digests of different messages: the exact scan says "no duplicate"
+        assert exact_total == 2
+        assert merged == [0, 1] and nparts == 2 * 384               # the probe word rides with the status word
+
+
 def _worker_multisig(rank, world, port, cid, keys, sig, bad_sig, msg, n, q):
     """BASELINE config 4 over N ranks (bench.py bench_multisig_sharded's data path, SURVEY 8e multisig variant): every rank adds its
     contiguous range of the keys, ONE all-gather of the partial key sums, every rank adds the N partials and runs the

@@ -419,6 +419,52 @@ def test_duplicate_scan_across_shards(gpu_lib):
     assert scan(b"".join(msgs[:2]), 2) == 0 and scan(msgs[0] + msgs[0], 2) & 1 and scan(msgs[0], 1) == 0
 
 
+def test_bucketed_digest_scan_agrees_with_the_full_scan(gpu_lib):
+    """Round 5: the multi-GPU duplicate rule with the digest scan itself sharded.  Rank r scans the digests whose first byte is
+    r mod N (bgls_duplicate_scan_bucket_dev); over the N buckets exactly one scan reports the duplicate, none reports anything on a
+    clean batch, every digest belongs to one bucket -- and a bucket that overflows its table (records that all share one first
+    byte: not digests) reports a hit instead of missing a duplicate."""
+    import hashlib
+    import torch
+    dev = torch.device("cuda:0")
+    rnd = random.Random(91)
+    n, ln = 40000, 64
+    msgs = [rnd.randbytes(ln) for _ in range(n)]
+    t_msgs = torch.frombuffer(bytearray(b"".join(msgs)), dtype=torch.uint8).to(dev)
+    dig = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+    assert gpu_lib.bgls_message_digests_dev(t_msgs.data_ptr(), ln, ln, n, dig.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    raw = bytes(dig.cpu().numpy())
+    for i in (0, 777, n - 1):
+        assert raw[16 * i:16 * i + 16] == hashlib.blake2b(msgs[i]).digest()[:16]
+
+    def buckets(t, count, nb, rl=16):
+        out = []
+        for b in range(nb):
+            f = torch.zeros(1, dtype=torch.int32, device=dev)
+            assert gpu_lib.bgls_duplicate_scan_bucket_dev(t.data_ptr(), rl, rl, count, b, nb, f.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            out.append(int(f.item()) & 1)
+        return out
+    for nb in (1, 2, 3, 8):
+        assert buckets(dig, n, nb) == [0] * nb
+    d2 = dig.clone()
+    d2[16 * 31234:16 * 31234 + 16] = d2[16 * 99:16 * 99 + 16]            # digest 99 again at 31234 (a duplicate message, or a collision)
+    torch.cuda.synchronize()
+    for nb in (1, 2, 3, 8):
+        got = buckets(d2, n, nb)
+        assert sum(got) == 1 and got[raw[16 * 99] % nb] == 1, (nb, got)
+    assert gpu_lib.bgls_duplicate_scan_bucket_dev(d2.data_ptr(), 16, 16, n, 8, 8, None, None) < 0      # bucket out of range / NULL word
+    f = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert gpu_lib.bgls_duplicate_scan_bucket_dev(d2.data_ptr(), 16, 16, n, 3, 2, f.data_ptr(), None) < 0
+    # 40 000 distinct records with the same first byte all land in bucket 1 of 8, whose table is sized for twice a fair share:
+    # the scan must say "hit" (undecided -> the caller's exact scan), never a silent miss
+    same = bytearray(b"".join(b"\x09" + rnd.randbytes(15) for _ in range(n)))
+    t_same = torch.frombuffer(same, dtype=torch.uint8).to(dev)
+    got = buckets(t_same, n, 8)
+    assert got[1] == 1 and sum(got) == 1
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The N > 1 path of bench.py end to end on real kernels: two ranks on cuda:0 exchanging over gloo
     (BGLS_BENCH_SHARE_GPU=1) -- shard ranges, global duplicate scan, partial + status all-gather, final verification and
