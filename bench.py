@@ -480,7 +480,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     # the other stages: what one launch costs the machine over the timed region is the region divided by the launches in it
     # (every other stage's time included -- the conservative reading); the exclusive figure is the kernel by itself.
     shared_launch_s = med / launches_per_step
-    cname = "BN254" if cid == 0 else "BLS381"
+    cname = "BN254W" if cid == 0 else "BLS381"      # the kernel's number form: alt-bn128 on nine 29-bit limbs since round 5 (struct BN254W), as rocprofv3 names it
     # the Miller kernel the engine takes for this batch (engine.hip Engine::miller): k_miller_x60 with 60 pairings per block, or its
     # 64-pairing block form where that saves a nearly empty last round of the 1024 resident blocks and one verification is in
     # flight (61 441 .. 65 536 pairings: exactly 2^16 is one round) -- the exclusive measurement
@@ -490,7 +490,7 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
     kernel_excl = "k_miller_x60<%s, 0, %d>" % (cname, 64 if form64_alone else 60)
     kernel_timed = "k_miller_x60<%s, 0, 60>" % cname if use_tp else kernel_excl
     if prepared:
-        kernel_excl = kernel_timed = "k_fold_prep<%s>" % cname
+        kernel_excl = kernel_timed = "k_fold_prep<%s>" % ("BN254" if cid == 0 else "BLS381")
     traffic, tdet = traffic_for(kernel_timed.split("<")[0] + "_" + CNAME[cid])
     rec = {
         "metric": "aggregate-verify signer-pairs/sec", "value": value, "unit": "signer-pairs/s",

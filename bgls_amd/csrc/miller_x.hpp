@@ -483,6 +483,10 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
   } else {
     // ---------------------------------------------------------------- consumer: 10 groups x 6 lanes, lane = 10 j + g
     if (rot_mode & 4) __builtin_amdgcn_s_setprio(3);       // the consumer is the long pole of a block's step: let it issue first
+#ifdef MX_PRIO_EXP                                         // development tools only (tools/mb_x60.hip): intermediate priorities in mode bits 5-6
+    if (((rot_mode >> 5) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+    if (((rot_mode >> 5) & 3) == 2) __builtin_amdgcn_s_setprio(2);
+#endif
     const bool live = lane < 60;
     const int cl = live ? lane : lane - 12;                // lanes 60..63 shadow lanes 48..51 (same 16-lane group of a ds_read_b128: broadcast)
     const int g = cl % 10;
