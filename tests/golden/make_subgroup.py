@@ -34,6 +34,28 @@ for cv in (BN254, BLS381):
     bad = bytearray(G.g2_bytes(G.g2_mul(cv.g2, 5))); bad[-1] ^= 1
     rows.append({"pt": bytes(bad).hex(), "on_twist": False, "in_subgroup": False, "note": "off the twist"})
     assert any(r["in_subgroup"] for r in rows) and any(r["on_twist"] and not r["in_subgroup"] for r in rows)
+    # does the Miller loop's walk over this key degenerate (running point's Z becomes 0: T = +-Q in an addition, a 2-torsion point or
+    # infinity in a doubling)?  Walked with the Python oracle's own point steps (oracle/pyref/pairing.py, no field shortcuts); the GPU
+    # tier reads the answer from the fixture (the Python oracle stays in the build container).
+    from oracle.pyref import pairing
+    pr = pairing.Pairing(cv)
+
+    def degenerates(q):
+        if q is None:
+            return False
+        rr, nq = (q[0], q[1], (1, 0)), pr.G.g2_neg(q)
+        for d in pr.digits[1:]:
+            rr, _ = pr.dbl_step(rr)
+            if d:
+                rr, _ = pr.add_step(rr, q if d > 0 else nq)
+        if cv.name == "altbn128":
+            t = pr.T
+            g1, g2 = t.gamma[1], t.gamma[2]
+            rr, _ = pr.add_step(rr, (t.f2_mul(t.f2_conj(q[0]), g1[2]), t.f2_mul(t.f2_conj(q[1]), g1[3])))
+            rr, _ = pr.add_step(rr, (t.f2_mul(q[0], g2[2]), t.f2_neg(t.f2_mul(q[1], g2[3]))))
+        return rr[2] == (0, 0)
+    for r in rows:
+        r["miller_degenerates"] = bool(r["on_twist"] and degenerates(G.g2_from_bytes(bytes.fromhex(r["pt"]))))
     for r in rows:      # the endomorphism criterion agrees with the definition on every row
         if r["on_twist"]:
             assert S.in_subgroup_fast(G.g2_from_bytes(bytes.fromhex(r["pt"]))) == r["in_subgroup"], r["note"]
