@@ -191,7 +191,7 @@ def _num(x, digits=4):
 
 def collective_info(cid, world):
     """what the N > 1 exchange is: one all-gather of GT partials + status words per step"""
-    info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 4), "op": "all_gather",
+    info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 8), "op": "all_gather",
             "digest_bytes_per_signer": 16}       # + one all-gather of 16-byte message digests (global duplicate rule), 16 B per signer of the batch
     try:
         info["backend"] = dist.get_backend()
