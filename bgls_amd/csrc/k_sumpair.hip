@@ -17,19 +17,23 @@ namespace bgls {
 // 1 = a key set's Montgomery affine points (no checks: validated at upload; two conversions into the carry-free form per key);
 // 2 = a key set's SUM-READY records (k_g2_sumready below): the carry-free limbs of (x_re, y_re | x_im, y_im), 2 NL dwords per
 // lane, fetched with 16-byte loads -- nothing but the mixed addition is left in the loop (11 Fp2 products per key instead of 16).
+template <class C>
+struct SumRec {
+  static constexpr int LANE_DW = (2 * C::RX_NL + 3) & ~3;      // x limbs, y limbs, padding
+};
 template <class C, int SRC>
 __device__ __forceinline__ bool sumpair_fetch(AffP<C>& q, const uint8_t* pts, size_t k, bool odd) {
   if constexpr (SRC == 2) {
     constexpr int N = C::RX_NL;
-    static_assert((2 * N) % 4 == 0, "a lane's record is whole 16-byte words");
-    const uint4* rec = reinterpret_cast<const uint4*>(pts) + (k * 4 * N + (odd ? 2 * N : 0)) / 4;
-    u32 w[2 * N];
+    constexpr int RS = SumRec<C>::LANE_DW;                      // a lane's record: whole 16-byte words (2 N limbs, padded: 20 / 20 / 28 dwords)
+    const uint4* rec = reinterpret_cast<const uint4*>(pts) + (k * 2 * RS + (odd ? RS : 0)) / 4;
+    u32 w[RS];
 #pragma unroll
-    for (int j = 0; j < (2 * N) / 4; ++j) {
+    for (int j = 0; j < RS / 4; ++j) {
       const uint4 v = rec[j];
       w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
     }
-    q.inf = (w[0] >> 31) != 0;                                  // the flag rides on bit 31 of the record's first limb (limbs are 28 bits)
+    q.inf = (w[0] >> 31) != 0;                                  // the flag rides on bit 31 of the record's first limb (limbs are 28 / 29 bits)
     w[0] &= 0x7FFFFFFFu;
 #pragma unroll
     for (int i = 0; i < N; ++i) { q.x.v[i] = (i32)w[i]; q.y.v[i] = (i32)w[N + i]; }
@@ -142,7 +146,7 @@ __device__ __noinline__ JacP<C> sumpair_block_tree(JacP<C> acc, bool odd) {
       const Sx<C, SX_F> R2 = get(0, partner), Z3 = get(1, partner);
       JacP<C> r;
       r.X = sx_normf<C>(sx_sub<C>(sx_sub<C>(R2, P2), sx_mulc<2, C>(P3)));
-      r.Y = sx_as<SX_F, C>(pair_mulsub<C>(rr, sx_normf<C>(sx_sub<C>(P3, r.X)), sx_mulc<2, C>(S), P2, odd));
+      r.Y = pair_mulsub_f<C>(rr, sx_normf<C>(sx_sub<C>(P3, r.X)), sx_mulc<2, C>(S), P2, odd);
       r.Z = Z3;
       r.inf = false;
       acc = r;
@@ -199,38 +203,54 @@ __global__ void k_g2_sumready(const Aff<F2<C>>* in, size_t n, u32* out) {
   if (i >= n) return;
   const Aff<F2<C>> a = in[i];
   const Ux<C> xr = to_ux<C>(a.x.c0), xi = to_ux<C>(a.x.c1), yr = to_ux<C>(a.y.c0), yi = to_ux<C>(a.y.c1);
-  u32* o = out + i * 4 * N;
+  constexpr int RS = SumRec<C>::LANE_DW;
+  u32* o = out + i * 2 * RS;
   const u32 f = a.inf ? 0x80000000u : 0u;
+#pragma unroll
+  for (int k = 0; k < RS; ++k) o[k] = o[RS + k] = 0u;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     o[k] = a.inf ? 0u : xr.v[k];
     o[N + k] = a.inf ? 0u : yr.v[k];
-    o[2 * N + k] = a.inf ? 0u : xi.v[k];
-    o[3 * N + k] = a.inf ? 0u : yi.v[k];
+    o[RS + k] = a.inf ? 0u : xi.v[k];
+    o[RS + N + k] = a.inf ? 0u : yi.v[k];
   }
   o[0] |= f;
-  o[2 * N] |= f;
+  o[RS] |= f;
 }
 
 namespace kl {
+
+// The number form the key-sum kernels run on: alt-bn128 on nine limbs of 29 bits (BN254W, as k_miller_x60 since round 5: 81 instead of
+// 100 multiplier instructions per limb product, one reduction more per addition), BLS12-381 on fourteen of 28.  Points and partial
+// sums cross the launchers in the library's 32-bit Montgomery form, whose layout does not depend on the form class.
+template <class C>
+struct SumForm { typedef C type; };
+#ifndef SUM_BN_W28
+template <>
+struct SumForm<BN254> { typedef BN254W type; };
+#endif
 
 // `pairs` = lane pairs in the launch (a multiple of 32); pairs / 32 Jacobian partial sums are written, one per block.
 // src: 0 wire bytes, 1 Montgomery affine points of a key set, 2 its sum-ready records
 template <class C>
 void sumpair_main(hipStream_t st, int src, const uint8_t* pts, size_t n, unsigned pairs, void* out, uint32_t* flags) {
-  if (src == 2) k_sumpair_main<C, 2><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
-  else if (src == 1) k_sumpair_main<C, 1><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
-  else k_sumpair_main<C, 0><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<C>>*)out, flags);
+  typedef typename SumForm<C>::type X;
+  if (src == 2) k_sumpair_main<X, 2><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<X>>*)out, flags);
+  else if (src == 1) k_sumpair_main<X, 1><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<X>>*)out, flags);
+  else k_sumpair_main<X, 0><<<pairs / 32, 64, 0, st>>>(pts, n, (Jac<F2<X>>*)out, flags);
 }
 template <class C>
 void g2_sumready(hipStream_t st, const void* mont, size_t n, void* out) {
-  k_g2_sumready<C><<<nblk(n, 128), 128, 0, st>>>((const Aff<F2<C>>*)mont, n, (u32*)out);
+  typedef typename SumForm<C>::type X;
+  k_g2_sumready<X><<<nblk(n, 128), 128, 0, st>>>((const Aff<F2<X>>*)mont, n, (u32*)out);
 }
 template <class C>
-size_t g2_sumready_bytes() { return 4 * C::RX_NL * 4; }
+size_t g2_sumready_bytes() { return 2 * SumRec<typename SumForm<C>::type>::LANE_DW * 4; }
 template <class C>
 void sumpairseg_main(hipStream_t st, const uint8_t* pts, const uint64_t* off, size_t nsets, unsigned P, void* out, uint32_t* flags) {
-  k_sumpairseg_main<C><<<(unsigned)(nsets * (P / 32)), 64, 0, st>>>(pts, off, P, (Jac<F2<C>>*)out, flags);
+  typedef typename SumForm<C>::type X;
+  k_sumpairseg_main<X><<<(unsigned)(nsets * (P / 32)), 64, 0, st>>>(pts, off, P, (Jac<F2<X>>*)out, flags);
 }
 template void sumpair_main<BN254>(hipStream_t, int, const uint8_t*, size_t, unsigned, void*, uint32_t*);
 template void sumpair_main<BLS381>(hipStream_t, int, const uint8_t*, size_t, unsigned, void*, uint32_t*);

@@ -50,6 +50,15 @@ RX_DEV bool affp_on_curve(const AffP<C>& q, bool odd) {
   return pair_both(sx_is_zero_mod_p<C>(d)) || q.inf;
 }
 
+// own half of a b - c d as a lazy value (SX_F): one interleaved reduction on the 28-bit forms; on the 29-bit form, whose columns hold
+// two products of near-tight factors, the two products are reduced apart and subtracted (c, whose bound is doubled by the callers,
+// goes through a parallel carry step first)
+template <class C, int LA, int LB, int LC, int LD>
+RX_DEV Sx<C, SX_F> pair_mulsub_f(const Sx<C, LA>& a, const Sx<C, LB>& b, const Sx<C, LC>& c, const Sx<C, LD>& d, bool odd) {
+  if constexpr (rx_fits<C>(2 * LA * LB + 2 * LC * LD)) return sx_as<SX_F, C>(pair_mulsub<C>(a, b, c, d, odd));
+  else return sx_normf<C>(sx_sub<C>(pair_mul<C>(a, b, odd), pair_mul<C>(sx_normf<C>(c), d, odd)));
+}
+
 // 2 p (dbl-2009-l); the rare branch of the mixed addition (a key met twice in one pair's slice)
 template <class C>
 RX_DEV JacP<C> jacp_dbl(const JacP<C>& p, bool odd) {
@@ -95,7 +104,7 @@ RX_DEV JacP<C> jacp_madd(const JacP<C>& p, const AffP<C>& q, bool odd) {
   const Sx<C, SX_T> V = pair_mul<C>(p.X, I, odd);
   JacP<C> r;
   r.X = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(rr, odd), J), sx_mulc<2, C>(V)));
-  r.Y = sx_as<SX_F, C>(pair_mulsub<C>(rr, sx_normf<C>(sx_sub<C>(V, r.X)), sx_mulc<2, C>(p.Y), J, odd));
+  r.Y = pair_mulsub_f<C>(rr, sx_normf<C>(sx_sub<C>(V, r.X)), sx_mulc<2, C>(p.Y), J, odd);
   r.Z = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(p.Z, H)), odd), Z1Z1), HH));
   r.inf = false;
   return r;
@@ -123,7 +132,7 @@ RX_DEV JacP<C> jacp_add(const JacP<C>& p, const JacP<C>& q, bool odd) {
   const Sx<C, SX_T> V = pair_mul<C>(U1, I, odd);
   JacP<C> r;
   r.X = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(rr, odd), J), sx_mulc<2, C>(V)));
-  r.Y = sx_as<SX_F, C>(pair_mulsub<C>(rr, sx_normf<C>(sx_sub<C>(V, r.X)), sx_mulc<2, C>(S1), J, odd));
+  r.Y = pair_mulsub_f<C>(rr, sx_normf<C>(sx_sub<C>(V, r.X)), sx_mulc<2, C>(S1), J, odd);
   const Sx<C, SX_F> zz = sx_normf<C>(sx_sub<C>(sx_sub<C>(pair_sqr<C>(sx_normf<C>(sx_add<C>(p.Z, q.Z)), odd), Z1Z1), Z2Z2));
   r.Z = sx_as<SX_F, C>(pair_mul<C>(zz, H, odd));
   r.inf = false;
@@ -150,7 +159,7 @@ RX_DEV AffP<C> affp_from_mont(const Aff<F2<C>>& a, bool odd) {
   r.y = ux_to_sx<C>(to_ux<C>(odd ? a.y.c1 : a.y.c0));
   return r;
 }
-// R' form (limbs below 2^29, |value| < 8 p) -> the library's form (see rx_jac.hpp sx_to_mont)
+// R' form (limbs below 2^(W+1), |value| < 8 p) -> the library's form (see rx_jac.hpp sx_to_mont)
 template <class C, int LA>
 RX_DEV Fp<C> sxp_to_mont(const Sx<C, LA>& a) {
   constexpr int N = C::RX_NL;

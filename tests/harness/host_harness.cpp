@@ -630,5 +630,5 @@ static int rx_sumpair(const uint8_t* pts, int n, uint8_t* out) {
   return memcmp(out, other, 4 * C::FP_BYTES) ? -5 : 0;
 }
 extern "C" int ht_rx_sumpair(int curve, const uint8_t* pts, int n, uint8_t* out) {
-  return curve == 0 ? rx_sumpair<BN254>(pts, n, out) : rx_sumpair<BLS381>(pts, n, out);
+  return curve == 0 ? rx_sumpair<BN254>(pts, n, out) : (curve == 2 ? rx_sumpair<BN254W>(pts, n, out) : rx_sumpair<BLS381>(pts, n, out));
 }

@@ -167,15 +167,19 @@ def test_key_sum_on_carry_free_limbs(host_harness, cname, cid):
         assert rc == 0, rc
         want = G.g2_bytes(G.g2_sum([p for p in pts]))
         assert bytes(ref) == want and bytes(got) == want, len(pts)
-        # the same sum on an emulated lane pair (rx_jacpair.hpp: the shipped key-sum kernel's arithmetic)
-        gp = (ctypes.c_uint8 * (4 * n_fp))()
-        rc = host_harness.ht_rx_sumpair(cid, (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw), len(pts), gp)
-        assert rc == 0, rc
-        assert bytes(gp) == want, len(pts)
+        # the same sum on an emulated lane pair (rx_jacpair.hpp: the shipped key-sum kernel's arithmetic; alt-bn128 also on the nine
+        # 29-bit limbs the kernel runs on since round 5: harness curve id 2)
+        for hid in ((cid, 2) if cid == 0 else (cid,)):
+            gp = (ctypes.c_uint8 * (4 * n_fp))()
+            rc = host_harness.ht_rx_sumpair(hid, (ctypes.c_uint8 * len(raw)).from_buffer_copy(raw), len(pts), gp)
+            assert rc == 0, (hid, rc)
+            assert bytes(gp) == want, (hid, len(pts))
     bad = bytearray(G.g2_bytes(base[0])); bad[-1] ^= 1
     got, ref = (ctypes.c_uint8 * (4 * n_fp))(), (ctypes.c_uint8 * (4 * n_fp))()
     assert host_harness.ht_rx_sum(cid, (ctypes.c_uint8 * len(bad)).from_buffer_copy(bytes(bad)), 1, got, ref) == -2
     assert host_harness.ht_rx_sumpair(cid, (ctypes.c_uint8 * len(bad)).from_buffer_copy(bytes(bad)), 1, got) == -2
+    if cid == 0:
+        assert host_harness.ht_rx_sumpair(2, (ctypes.c_uint8 * len(bad)).from_buffer_copy(bytes(bad)), 1, got) == -2
 
 
 @pytest.mark.parametrize("cid", [0, 1])
