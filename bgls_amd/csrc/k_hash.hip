@@ -102,19 +102,33 @@ __global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const
 // a^((p + 1) / 4) (M1 = false) or a^((p - 3) / 4) (M1 = true) on the carry-free limbs (rx_pow.hpp); `tab` is the wave's
 // LDS table, RXP_W-bit sliding windows.  Same field element as fp_pow_w4 on the same exponent.
 constexpr int RXP_W = 3;
+// the number form of the powers: alt-bn128 on nine limbs of 29 bits (BN254W, round 5: a squaring is 45 + 81 multiplier instructions
+// instead of 55 + 100), BLS12-381 on fourteen of 28
 template <class C>
-constexpr int rxp_lds_words() { return (1 << (RXP_W - 1)) * C::RX_NL * 64; }
+struct PowForm { typedef C type; };
+template <>
+struct PowForm<BN254> { typedef BN254W type; };
+template <class C>
+constexpr int rxp_lds_words() { return (1 << (RXP_W - 1)) * PowForm<C>::type::RX_NL * 64; }
 template <class C, bool M1>
 __device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
-  constexpr int N = C::RX_NL;
+  typedef typename PowForm<C>::type X;
+  constexpr int N = X::RX_NL;
   const int lane = threadIdx.x & 63;
   auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
   auto st = [&](int e, int i, i32 v) { tab[(e * N + i) * 64 + lane] = v; };
-  const Sx<C, SX_T> r = sx_pow_sqrt<C, RXP_W, M1>(ux_to_sx<C>(to_ux<C>(a)), ld, st);   // (the low word of (p + 1) / 4 is odd: M1 borrows nothing)
-  Ux<C> u;
+  Fp<X> ax;
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) ax.v[i] = a.v[i];
+  const Sx<X, SX_T> r = sx_pow_sqrt<X, RXP_W, M1>(ux_to_sx<X>(to_ux<X>(ax)), ld, st);   // (the low word of (p + 1) / 4 is odd: M1 borrows nothing)
+  Ux<X> u;
 #pragma unroll
   for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];
-  return from_ux<C>(u);
+  const Fp<X> rx = from_ux<X>(u);
+  Fp<C> out;
+#pragma unroll
+  for (int i = 0; i < C::L; ++i) out.v[i] = rx.v[i];
+  return out;
 }
 
 // second half of the Legendre-symbol rounds: y = sqrt(x^3+3) with the reference's sign rule, once per message

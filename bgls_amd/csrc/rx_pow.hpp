@@ -1,4 +1,4 @@
-// Fixed-exponent powers in Fp on the carry-free 28-bit limbs (rx.hpp): the square roots of the hash-to-G1 maps.
+// Fixed-exponent powers in Fp on the carry-free limbs (rx.hpp; any limb width C::RX_W): the square roots of the hash-to-G1 maps.
 //
 // The reference takes these roots with big.Int arithmetic per message (curves/hash.go:53-77 try-and-increment on alt-bn128,
 // curves/hash.go:109-139 Fouque-Tibouchi on BLS12-381: y = sqrt(x^3 + b) by the exponent (p + 1) / 4); on the device one lane owns
@@ -18,12 +18,14 @@ namespace bgls {
 template <class C>
 BGLS_HD Sx<C, SX_T> sx_redc_cols(i64 (&t)[2 * C::RX_NL]) {
   constexpr int N = C::RX_NL;
+  constexpr i32 W = C::RX_W;
+  constexpr u32 RX_MASK = C::RX_MASK;
   i32 m = (i32)(((u32)t[0] * C::RX_NP) & RX_MASK);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     // the next row's factor needs this row's first two products only: they go first, the scalar chain hides under the rest
     rx_rows_blk<2, true>(t + i, m, (const i32*)C::RX_P);
-    t[i + 1] += t[i] >> 28;
+    t[i + 1] += t[i] >> W;
     const i32 m_next = (i32)(((u32)t[i + 1] * C::RX_NP) & RX_MASK);
     rx_rows<N - 2, true>(t + i + 2, m, (const i32*)C::RX_P + 2);
     m = m_next;
@@ -32,9 +34,9 @@ BGLS_HD Sx<C, SX_T> sx_redc_cols(i64 (&t)[2 * C::RX_NL]) {
 #pragma unroll
   for (int k = N; k < 2 * N - 1; ++k) {
     r.v[k - N] = (i32)((u32)t[k] & RX_MASK);
-    if (k + 1 < 2 * N - 1) t[k + 1] += t[k] >> 28;
+    if (k + 1 < 2 * N - 1) t[k + 1] += t[k] >> W;
   }
-  r.v[N - 1] = (i32)(t[2 * N - 2] >> 28);     // column 2 NL - 1 would receive this carry and nothing else: it does not exist
+  r.v[N - 1] = (i32)(t[2 * N - 2] >> W);     // column 2 NL - 1 would receive this carry and nothing else: it does not exist
   return r;
 }
 
@@ -53,12 +55,13 @@ BGLS_HD void sx_sqr_rows(i64* t, const i32* a, const i32* d) {
   }
 }
 
-// a^2 / R': the NL squares and the NL (NL - 1) / 2 cross products against the doubled limbs.  a tight (|limb| < 2^28):
-// a column collects at most NL products below 2^57 and the reduction's NL below 2^56.
+// a^2 / R': the NL squares and the NL (NL - 1) / 2 cross products against the doubled limbs.  a tight (|limb| < 2^W):
+// a column collects at most NL products below 2^(2W+1) and the reduction's NL below 2^(2W).
 template <class C>
 BGLS_HD Sx<C, SX_T> sx_sqr(const Sx<C, SX_T>& a) {
   constexpr int N = C::RX_NL;
-  static_assert(N * 3 < 64, "column budget: NL * (2^57 + 2^56) < 2^63");
+  // exact count: a column holds at most (NL - 1) / 2 doubled cross products and one square = NL products' worth of 2^(2W), the reduction adds NL more
+  static_assert(2 * N < (1 << (63 - 2 * C::RX_W)), "column budget: 2 NL 2^(2W) < 2^63");
   i64 t[2 * N];
   i32 d[N];
 #pragma unroll

@@ -411,11 +411,11 @@ static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
   const Fp<C> want = op == 1 ? fp_sqrt_candidate<C>(a) : fp_pow_w4<C, C::L>(a, e);
   fp_to_be<C>(bytes, fp_from_mont<C>(back(r4)));
   if (g_rx_overflow) return -3;
-  for (int i = 0; i < N; ++i) if (r3.v[i] < 0 || r4.v[i] < 0 || (i + 1 < N && ((u32)r3.v[i] > RX_MASK || (u32)r4.v[i] > RX_MASK))) return -2;
+  for (int i = 0; i < N; ++i) if (r3.v[i] < 0 || r4.v[i] < 0 || (i + 1 < N && ((u32)r3.v[i] > C::RX_MASK || (u32)r4.v[i] > C::RX_MASK))) return -2;
   return (fp_eq<C>(back(r3), want) ? 0 : 1) + (fp_eq<C>(back(r4), want) ? 0 : 2);
 }
 extern "C" int ht_rx_pow(int curve, int op, uint8_t* bytes, i32* limbs) {
-  return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs);
+  return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : (curve == 2 ? rx_pow<BN254W>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs));
 }
 
 // ---- rx_pair.hpp: the whole sequence of point steps of one Miller loop on an emulated lane pair, every line (as handed

@@ -323,3 +323,30 @@ def test_29bit_form_point_steps_match_the_library_steps(host_harness):
         g2 = G.g2_bytes(G.g2_mul(c.g2, rnd.randrange(1, c.r)))
         rc = host_harness.ht_rx_miller(2, (ctypes.c_uint8 * len(g1)).from_buffer_copy(g1), (ctypes.c_uint8 * len(g2)).from_buffer_copy(g2))
         assert rc == 0, "29-bit lane-pair point steps differ from pairing.hpp (code %d: 1 + first differing step, -3 = column overflow)" % rc
+
+
+def test_29bit_form_sqrt_powers(host_harness):
+    """rx_pow.hpp on nine 29-bit limbs (alt-bn128's hash-to-G1 square root since round 5): the symmetric squaring on worst-case limbs
+    stays inside the signed columns (a column holds NL products' worth of 2^58 plus the reduction's NL: 18 of 32 units), the
+    sliding-window powers give fp.hpp's field elements."""
+    p = CURVES["altbn128"].p
+    Rp = 1 << (W29 * N29)
+    Rinv = pow(Rp, -1, p)
+    rnd = random.Random(2977)
+    host_harness.ht_rx_pow.restype = ctypes.c_int
+    top_p = p >> (W29 * (N29 - 1))
+    cases = [[MASK29] * (N29 - 1) + [2 * top_p + 1], limbs29(p - 1), limbs29(0), limbs29(1)] + [limbs29(rnd.randrange(2 * p)) for _ in range(8)]
+    for l in cases:
+        lim = (ctypes.c_int32 * N29)(*l)
+        assert host_harness.ht_rx_pow(2, 0, None, lim) == 0, "column overflow in the squaring"
+        out = list(lim)
+        assert all(0 <= x <= MASK29 for x in out[:-1])
+        v = val29(l)
+        got = val29(out)
+        assert got % p == v * v * Rinv % p and 0 <= got < v * v // Rp + p + 1
+    for op, e in [(1, (p + 1) // 4), (2, (p - 3) // 4)]:
+        for x in [0, 1, 2, p - 1, rnd.randrange(p), rnd.randrange(p), rnd.randrange(p)]:
+            buf = (ctypes.c_uint8 * 32)(*x.to_bytes(32, "big"))
+            rc = host_harness.ht_rx_pow(2, op, buf, None)
+            assert rc == 0, (op, x, rc)
+            assert int.from_bytes(bytes(buf), "big") == pow(x, e, p)
