@@ -815,7 +815,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 20, help="signers of the headline batch (whole job)")
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
-    ap.add_argument("--in-flight", type=int, default=4, help="verifications kept in flight (1 = strictly sequential, max 16)")
+    ap.add_argument("--in-flight", type=int, default=8, help="verifications kept in flight (1 = strictly sequential, max 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="keep the 64-pairing Miller kernel also when launches overlap")
     ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "multisig_batch", "small"], help="run ONE record (profiling runs): --curve, --n apply")

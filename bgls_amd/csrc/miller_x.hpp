@@ -209,23 +209,36 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) {
       });
 }
 
-// The 29-bit form's squaring (rx.hpp ux_sqr_dot3): the row's doubled slots and its plain slots as two piles.  The split of the
-// row is a per-lane constant, made once before the step loop: dsl = up to three table bytes (0xff = unused), psl = up to two.
-__device__ __forceinline__ void mx_sq_split(unsigned row, unsigned& dsl, unsigned& psl) {
-  dsl = 0xffffffu;
-  psl = 0xffffu;
+// The 29-bit form's squaring (rx.hpp ux_sqr_dot3): the row's slots as two piles of two.  The split of the row is a per-lane constant, made once
+// before the step loop: pa / pb = the table bytes of pile A's / pile B's two slots (0xff = unused); bit 16 of pa = "pile A is doubled after its
+// reduction" (odd rows: A = d0 + d1 undoubled, B = 2 d2), else the first slot of each pile is doubled inside (even rows: A = 2 d0 + p0, B = 2 d1 + p1).
+__device__ __forceinline__ void mx_sq_split(unsigned row, unsigned& pa, unsigned& pb) {
+  unsigned d[3] = {0xffu, 0xffu, 0xffu}, p[2] = {0xffu, 0xffu};
   int nd = 0, np = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const unsigned e = (row >> (8 * t)) & 0xFFu;
     if ((e & 7u) == 7u) continue;
-    if (e & 0x80u) { dsl = (dsl & ~(0xFFu << (8 * nd))) | (e << (8 * nd)); ++nd; }
-    else { psl = (psl & ~(0xFFu << (8 * np))) | (e << (8 * np)); ++np; }
+    if (e & 0x80u) {
+      if (nd == 0) d[0] = e; else if (nd == 1) d[1] = e; else d[2] = e;
+      ++nd;
+    } else {
+      if (np == 0) p[0] = e; else p[1] = e;
+      ++np;
+    }
+  }
+  if (nd == 3) {               // odd coefficient: (2, 2, 2)
+    pa = d[0] | (d[1] << 8) | (1u << 16);
+    pb = d[2] | (0xffu << 8);
+  } else {                     // even coefficient: (1, 2, 2, 1)
+    pa = d[0] | (p[0] << 8);
+    pb = d[1] | (p[1] << 8);
   }
 }
 template <class C, int NP>
-__device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned dsl, unsigned psl) {
+__device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned pa, unsigned pb) {
   typedef MX<C, NP> K;
+  const bool twice = (pa >> 16) & 1u;
   auto fetch = [&](unsigned sl, int t, int side, int h) __attribute__((always_inline)) {
     const unsigned e = (sl >> (8 * t)) & 0xFFu;
     const bool unused = (e & 7u) == 7u;
@@ -238,7 +251,8 @@ __device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned dsl, unsigned psl) {
     }
     return a;
   };
-  return ux_sqr_dot3<C>([&](int t, int side, int h) { return fetch(dsl, t, side, h); }, [&](int t, int side, int h) { return fetch(psl, t, side, h); });
+  return ux_sqr_dot3<C>([&](int t, int side, int h) { return fetch(pa, t, side, h); }, [&](int t, int side, int h) { return fetch(pb, t, side, h); },
+                        [&](int t) { return t == 0 && !twice; }, [&](int t) { return t == 0; }, twice);
 }
 
 // A producer lane's parked values: its own region of the workspace, NPARK slots of HS dwords (16-byte aligned), moved with

@@ -515,21 +515,33 @@ BGLS_HD Ux2<C> ux_sqr_dot(KD&& kind, LA&& lda, LB&& ldb) {
   return r;
 }
 
-// The symmetric squaring on the 29-bit form: a pile holds three term-equivalents, so the row's doubled products (at most three,
-// accumulated UNdoubled) and its plain products (at most two) are two three-term dot products and
-//   c = 2 * reduce(doubled) + reduce(plain),    then a quasi-reduction back below 2 p
-// (operands below 2 p / 3 p: each pile reduces below 1.5 p, c below 4.5 p).  Five slot products and four reductions per lane
-// against the 28-bit form's four and two, on 81 instead of 100 multiplier instructions each.
-//   ldd(t, side, h): slot t < 3 of the doubled pile, side 0 / 1 = left / right operand, half h; zeros for an unused slot.  ldp: the plain pile (t < 2).
-template <class C, class LD, class LP>
-BGLS_HD Ux2<C> ux_sqr_dot3(LD&& ldd, LP&& ldp) {
-  const Ux2<C> d = ux_dot_k2p<C, 3>([&](int t, int h) { return ldd(t, 0, h); }, [&](int t, int h) { return ldd(t, 1, h); });
-  const Ux2<C> p = ux_dot_k2p<C, 2>([&](int t, int h) { return ldp(t, 0, h); }, [&](int t, int h) { return ldp(t, 1, h); });
+// The symmetric squaring on the 29-bit form.  A pile holds three term-equivalents and the row has six -- (2, 2, 2) on odd coefficients,
+// (1, 2, 2, 1) on even ones -- so it is TWO piles of two slots each, four slot products and four reductions (the 28-bit form: four and two):
+//     even row:  A = 2 d0 + p0,   B = 2 d1 + p1           (the doubling inside the pile: the doubled slot's left operand is shifted)
+//     odd row:   A = d0 + d1 (undoubled), B = 2 d2          c = 2 A + B
+// one instruction stream for both kinds of rows: the lane's `twice` says whether pile A is doubled after its reduction (odd rows) or
+// its first slot inside (even rows).  Operands below 2 p / 3 p: each pile reduces below 1.5 p, c below 4.5 p, then a quasi-reduction
+// back below 2 p.  (The first version ran the doubled and the plain products as a three-slot and a two-slot pile: five slot products.)
+//   lda(t, side, h) / ldb(t, side, h): slot t < 2 of pile A / B, side 0 / 1 = left / right operand, half h; zeros for an unused slot.
+//   sha(t) / shb(t): 1 if the slot's left operand is doubled.
+template <class C, class LA, class LB, class SA, class SB>
+BGLS_HD Ux2<C> ux_sqr_dot3(LA&& lda, LB&& ldb, SA&& sha, SB&& shb, bool twice) {
+  constexpr int N = C::RX_NL;
+  auto left = [&](auto& ld, auto& sh, int t, int h) __attribute__((always_inline)) {
+    Ux<C> a = ld(t, 0, h);
+    const u32 s = sh(t) ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < N; ++q) a.v[q] <<= s;
+    return a;
+  };
+  const Ux2<C> d = ux_dot_k2p<C, 2>([&](int t, int h) { return left(lda, sha, t, h); }, [&](int t, int h) { return lda(t, 1, h); });
+  const Ux2<C> p = ux_dot_k2p<C, 2>([&](int t, int h) { return left(ldb, shb, t, h); }, [&](int t, int h) { return ldb(t, 1, h); });
+  const u32 ps = twice ? 1u : 0u;
   Ux2<C> s;
 #pragma unroll
-  for (int i = 0; i < C::RX_NL; ++i) {
-    s.c0.v[i] = 2 * d.c0.v[i] + p.c0.v[i];
-    s.c1.v[i] = 2 * d.c1.v[i] + p.c1.v[i];
+  for (int i = 0; i < N; ++i) {
+    s.c0.v[i] = (d.c0.v[i] << ps) + p.c0.v[i];
+    s.c1.v[i] = (d.c1.v[i] << ps) + p.c1.v[i];
   }
   return ux_quasi<C, 2, 1>(s);
 }

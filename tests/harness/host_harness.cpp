@@ -338,9 +338,15 @@ static int rx_raw(int op, int arg, const u32* A, const u32* Bv, u32* out) {
     else return -1;
   }
   else if (op == 2) { Ux2<C> a = {ld(A, 0, 0), ld(A, 0, 1)}; r = ux_mulxi<C>(a); }
-  else if (op == 3) {   // the 29-bit form's squaring: doubled pile = operands 0..2, plain pile = operands 3..4 (A, B hold FIVE operands); arg bit t = slot t used
-    auto lm = [&](const u32* base, int t, int h) { Ux<C> v = ld(base, t, h); if (!((arg >> t) & 1)) for (int i = 0; i < N; ++i) v.v[i] = 0; return v; };
-    r = ux_sqr_dot3<C>([&](int t, int side, int h) { return side ? ld(Bv, t, h) : lm(A, t, h); }, [&](int t, int side, int h) { return side ? ld(Bv, 3 + t, h) : lm(A, 3 + t, h); });
+  else if (op == 3) {   // the 29-bit form's squaring: pile A = operands 0, 1, pile B = operands 2, 3 (A, B hold FOUR operands); arg bit 0: odd row
+    // (A undoubled and doubled after its reduction, B = 2 x operand 2, operand 3 unused), else even row (operands 0 and 2 doubled inside)
+    const bool twice = arg & 1;
+    auto lm = [&](const u32* base, int t, int h, bool used) { Ux<C> v = ld(base, t, h); if (!used) for (int i = 0; i < N; ++i) v.v[i] = 0; return v; };
+    if constexpr (!rx_lazy<C>)
+      r = ux_sqr_dot3<C>([&](int t, int side, int h) { return side ? ld(Bv, t, h) : lm(A, t, h, true); },
+                         [&](int t, int side, int h) { return side ? ld(Bv, 2 + t, h) : lm(A, 2 + t, h, !(twice && t == 1)); },
+                         [&](int t) { return t == 0 && !twice; }, [&](int t) { return t == 0; }, twice);
+    else return -1;
   }
   else if (op == 4) {   // quasi-reduction, levels arg >> 4 .. arg & 15, of A[0] (raw limbs, not necessarily tight)
     Ux2<C> a = {ld(A, 0, 0), ld(A, 0, 1)};

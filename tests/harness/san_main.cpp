@@ -49,7 +49,7 @@ int main() {
     }
     CHECK(ht_rx_raw(cid, 0, 0, A.data(), B.data(), o.data()) == 0);          // three-term fold
     CHECK(ht_rx_raw(cid, 2, 0, A.data(), B.data(), o.data()) == 0);          // xi multiple
-    if (cid == 2) CHECK(ht_rx_raw(cid, 3, 0x1f, A.data(), B.data(), o.data()) == 0);       // two-pile squaring
+    if (cid == 2) { CHECK(ht_rx_raw(cid, 3, 0, A.data(), B.data(), o.data()) == 0); CHECK(ht_rx_raw(cid, 3, 1, A.data(), B.data(), o.data()) == 0); }      // two-pile squaring, even / odd row
     else CHECK(ht_rx_raw(cid, 1, 2 | (2 << 2) | (2 << 4), A.data(), B.data(), o.data()) == 0);
     uint8_t be[48] = {0};
     be[cid == 1 ? 47 : 31] = 7;

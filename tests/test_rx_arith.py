@@ -286,16 +286,16 @@ def test_29bit_form_conversions_and_consumer_arithmetic(host_harness):
         assert tight29(r0) and tight29(r1), (it, r0, r1)
         assert val29(r0) % p == (9 * v0 - v1) % p and val29(r1) % p == (9 * v1 + v0) % p
         assert val29(r0) < 3.001 * p and val29(r1) < 3.001 * p
-    # the squaring as two piles + quasi-reduction: slot masks as the table's rows have them, worst-case limbs included
-    for used in (0b00111, 0b11011, 0b11111, 0b11110):
+    # the squaring as two piles of two slots + quasi-reduction: even rows (2 d0 + p0) + (2 d1 + p1), odd rows 2 (d0 + d1) + 2 d2; worst-case limbs included
+    for odd_row in (0, 1):
         for kind in ["rand"] * 6 + ["max"]:
-            A = [operand29(rnd, p, kind, 2 if kind == "rand" else 4) for _ in range(5)]
-            Bv = [operand29(rnd, p, kind, 3 if kind == "rand" else 4) for _ in range(5)]
-            ovf, r0, r1 = run29(lib, 3, used, A, Bv)
-            assert ovf == 0, (kind, used)
-            ks = [2, 2, 2, 1, 1]
-            re = sum(k * (val29(a[0]) * val29(b[0]) - val29(a[1]) * val29(b[1])) for t, (k, a, b) in enumerate(zip(ks, A, Bv)) if (used >> t) & 1)
-            im = sum(k * (val29(a[0]) * val29(b[1]) + val29(a[1]) * val29(b[0])) for t, (k, a, b) in enumerate(zip(ks, A, Bv)) if (used >> t) & 1)
+            A = [operand29(rnd, p, kind, 2 if kind == "rand" else 4) for _ in range(4)]
+            Bv = [operand29(rnd, p, kind, 3 if kind == "rand" else 4) for _ in range(4)]
+            ovf, r0, r1 = run29(lib, 3, odd_row, A, Bv)
+            assert ovf == 0, (kind, odd_row)
+            ks = [2, 2, 2, 0] if odd_row else [2, 1, 2, 1]
+            re = sum(k * (val29(a[0]) * val29(b[0]) - val29(a[1]) * val29(b[1])) for k, a, b in zip(ks, A, Bv))
+            im = sum(k * (val29(a[0]) * val29(b[1]) + val29(a[1]) * val29(b[0])) for k, a, b in zip(ks, A, Bv))
             assert tight29(r0) and tight29(r1)
             assert val29(r0) % p == re * Rinv % p and val29(r1) % p == im * Rinv % p
             assert val29(r0) < 2.001 * p and val29(r1) < 2.001 * p
