@@ -5,8 +5,10 @@
 // CurveSystem / Point / PointT interfaces (curves/curve.go:12-70).  Lives INSIDE package curves
 // because CurveSystem has unexported methods (curves/curve.go:38-44).
 //
-// NOT COMPILED IN THE BUILD CONTAINER (no Go toolchain there); written against the C ABI that is
-// tested through ctypes.  Build:  CGO_CFLAGS=-I$REPO/include CGO_LDFLAGS="-L$REPO/bgls_amd -lbgls_hip" go build ./...
+// UNVERIFIED TEXT: THIS FILE HAS NEVER MET A GO COMPILER (no Go toolchain in the build container, no network for the
+// reference's un-vendored modules).  It is the binding a maintainer would start from, written against the C ABI that IS
+// tested (ctypes in tests/, the C++ mirror in tests/cpp) -- not a tested drop-in.  The ABI never lets a C++ exception
+// unwind into a cgo frame (every entry point is guarded; BGLS_ERR_NOMEM = -6 since round 5; anything but 1 maps to false).  Build:  CGO_CFLAGS=-I$REPO/include CGO_LDFLAGS="-L$REPO/bgls_amd -lbgls_hip" go build ./...
 package curves
 
 /*
