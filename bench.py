@@ -134,7 +134,7 @@ def traffic_for(kernel_key):
     builder-held constant of the evidence run, not measured in this process (labelled as such).  The same file carries the
     evidence run's SQ readings of the kernel: valu_busy = rocprofiler's VALUBusy (sum SQ_ACTIVE_INST_VALU / CUs /
     GRBM_GUI_ACTIVE per XCD) and lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
-    for rnd in ("r4", "r3", "r2"):
+    for rnd in ("r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(path):
             det = json.load(open(path))
