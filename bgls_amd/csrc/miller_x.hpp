@@ -64,6 +64,7 @@ struct MX {
   static constexpr int HS = PACKED ? NL : ((NL + 3) & ~3);                  // dwords per half: 12 / 14
   static constexpr int ES = 2 * HS;                                         // per Fp2 entry: 24 / 28
   static constexpr int NLINES = NP == 64 ? 7 : 6;
+  static constexpr int FOLD_UNROLL = (!rx_lazy<C> && NLINES % 3 == 0) ? 3 : 1;                   // the consumer's loop over a step's lines (k_miller_x60)
   static constexpr int KS = PACKED ? 2 * ES : ES;                           // accumulator entry stride: 24 / 56
   static constexpr int WS = PACKED ? 368 : 176;                             // xi copies
   static constexpr int GROUP_DW = PACKED ? (NP == 64 ? 940 : 844) : (NP == 64 ? 828 : 764);
@@ -525,7 +526,9 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
     if constexpr (!rx_lazy<C>) mx_sq_split(COOP_SQ_TAB[j], sq_d, sq_p);
     auto fold_all = [&]() __attribute__((always_inline)) {
       if constexpr (DBG == 1) return;
-#pragma unroll 1
+      // unrolled by three on the 29-bit form (same-box A/B at 2^20 pairings: 54.4 -> 54.0 ms; by two 54.3, by six 54.1), rolled on BLS12-381
+      // (unrolled by two or three: 86.8 -> 87.2 ms)
+#pragma unroll K::FOLD_UNROLL
       for (int m = 0; m < K::NLINES; ++m) {
         fj = mx_fold<C, NP>(gb, m, j);
         mx_publish<C, NP>(gb, j, fj, live);
