@@ -762,6 +762,31 @@ BGLS_HD Sx<C, SX_T> sx_montr(const i32* const (&cols)[NP], Row&& row) {
   return r;
 }
 
+// Centred quasi-reduction of a signed value: subtract round(value / p) p, read off the top limb, and carry-normalise -- tight limbs, signed
+// top limb, |result| below 0.51 p.  a: limbs of any bound below 2^31 (a few tight values added up or multiplied by small constants), |value|
+// below 2^6 p.  The point steps use it where a product by a SMALL curve constant is formed with additions instead of a Montgomery product
+// (BLS12-381's 3 b' = 12 (1 + i), rx_pair.hpp): the sum is 25 p large, and every later use -- the P-free line coefficient E - B above all,
+// which must reach the consumer below 32 p -- wants the small representative a reduction would have returned.  NL multiplier instructions.
+template <class C, int LA>
+BGLS_HD Sx<C, SX_T> sx_quasi_center(const Sx<C, LA>& a) {
+  constexpr int N = C::RX_NL;
+  constexpr int W = C::RX_W;
+  constexpr float QI = 1.0f / ((float)C::RX_P[N - 1] + 0.5f);
+  // the limbs below the top one are worth a few units of the top limb together (LA / 16 of them); p's top limb is 2^17 (BLS12-381) / 2^21 (alt-bn128) units
+  const float qf = (float)a.v[N - 1] * QI;
+  const i32 q = (i32)(qf + (qf < 0.0f ? -0.5f : 0.5f));
+  Sx<C, SX_T> r;
+  i64 c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    const i64 t = (i64)a.v[i] - (i64)q * (i64)(i32)C::RX_P[i] + c;
+    r.v[i] = (i32)((u32)t & C::RX_MASK);
+    c = t >> W;
+  }
+  r.v[N - 1] = (i32)((i64)a.v[N - 1] - (i64)q * (i64)(i32)C::RX_P[N - 1] + c);
+  return r;
+}
+
 // value == 0 (mod p)?  a: limbs below 2^30, value in (-3 p, 5 p) (differences of a few reductions' outputs).  v + 3p lies in
 // (0, 8p): after a full carry it equals one of 0, p, .. 8p limb for limb iff v is a multiple of p.
 template <class C, int LA>

@@ -142,12 +142,23 @@ RX_DEV Sx<C, SX_T> pair_sqrsub3(const Sx<C, LG>& g, const Sx<C, LE>& e, bool odd
     return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -3 * pair_even1(e.v[i], odd) : -3 * pair_odd1(e.v[i], odd));
   });
 }
-// 3 b' z of the doubling step: a product by the constant on both curves.  (BLS12-381's 3 b' = 12 (1 + i) could be formed with
-// additions, as pairing.hpp does, but the VALUE would grow to 25 p and the P-free line coefficient E - B must reach the
-// consumer below 32 p after the fat multiple of p that makes it non-negative; a reduction is what brings it back.)
+// 3 b' z of the doubling step.  alt-bn128: a product by the constant (3 b' = 9 / (9 + i) is a full-size element).  BLS12-381: 3 b' = 12 (1 + i)
+// (the M-type twist y^2 = x^3 + 4 (1 + i): curves/bls12_381.go), so the product is 12 (z0 - z1) + 12 (z0 + z1) i -- the partner's half
+// by one DPP move per limb, an addition, x 3, x 4 with parallel carry steps between them (the limb bounds of Sx) -- and, since that integer is up to
+// 25 p large, a centred quasi-reduction (sx_quasi_center: NL multiplier instructions) that hands every later use the small tight representative a
+// Montgomery product would have: the same field element, so the same lines and partial products bit for bit.  Round 5: 2 NL^2 + NL^2 multiplier
+// instructions and a reduction's bookkeeping (~725 instructions per lane on fourteen limbs) become ~250; same-box A/B with a timing stand-in
+// 86.3 -> 84.8 ms per 2^20 pairings.  (Rounds 3-4 kept the constant product because the VALUE had to reach the consumer below 32 p.)
 template <class C, int LA>
 RX_DEV Sx<C, SX_T> pair_mul_3b(const Sx<C, LA>& z, bool odd) {
-  return pair_mul_const<C>(z, C::RX_B2X3_RE, C::RX_B2X3_IM, odd);
+  if constexpr (C::CURVE_ID == 1) {
+    static_assert(C::XI_RE == 1 && !C::TWIST_D, "3 b' = 12 (1 + i): BLS12-381's M-type twist");
+    const auto t = sx_normf<C>(sx_add<C>(z, pair_swap_neg_even<C>(z, odd)));            // z0 - z1 | z1 + z0
+    const auto t12 = sx_mulc<4, C>(sx_normf<C>(sx_mulc<3, C>(t)));
+    return sx_quasi_center<C>(t12);
+  } else {
+    return pair_mul_const<C>(z, C::RX_B2X3_RE, C::RX_B2X3_IM, odd);
+  }
 }
 
 template <class C>
