@@ -437,10 +437,15 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
       else e[entry] = sx_to_ux_k<1, C>(v);              // the P-free coefficient, a difference of two reductions' outputs: + 2 p, below 3.1 p
     };
     auto hand_over = [&]() __attribute__((always_inline)) {
-      if (DBG == 2 || !valid) {           // the constant line 1
-        e[0] = odd ? ux_zero<C>() : ux_load<C>(C::RX_ONE);
-        e[1] = ux_zero<C>();
-        e[2] = ux_zero<C>();
+      // the constant line 1 for a pairing that is not there (a batch's ragged end, a key or hash point at infinity).  Decided per WAVE first: the lanes
+      // that own no pairing never store their line, so only an OWNED invalid pairing needs the selects, and a wave without one -- all but the last
+      // block of a batch -- branches over the 3 NL of them
+      if (DBG == 2 || __builtin_amdgcn_ballot_w64(owner && !valid) != 0) {
+        if (DBG == 2 || !valid) {
+          e[0] = odd ? ux_zero<C>() : ux_load<C>(C::RX_ONE);
+          e[1] = ux_zero<C>();
+          e[2] = ux_zero<C>();
+        }
       }
       __syncthreads();                    // A: the consumer has finished with the previous lines
       if (owner) {
