@@ -20,6 +20,13 @@
 
 using namespace bgls;
 
+// The hand-over between waves below (relaxed agent-scope atomics, s_waitcnt vmcnt(0) in front of the ticket, no release / acquire fence) is correct
+// under the memory behaviour of THIS architecture -- stores counted in vmcnt, sc1 write-through to the shared level -- and has only been validated
+// there.  Building the library for anything else must fail loudly rather than verify against a stale key sum.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_sumtree.hip: the fence-free ticket hand-over is written for gfx950 (MI355X) only"
+#endif
+
 // Hand-over of a parked sum between two waves on different CUs / XCDs.  The per-XCD L2s are not coherent with each other and
 // an agent-scope release fence writes a whole L2's dirty lines back (MI355X_MICROARCH.md, inter-workgroup visibility: ~3.5 us
 // per __threadfence(), several times that next to the main pass's freshly written partials -- the first version of this kernel
