@@ -108,8 +108,11 @@ template <class C>
 struct PowForm { typedef C type; };
 template <>
 struct PowForm<BN254> { typedef BN254W type; };
+// BLS12-381 keeps table entry 0 in registers (sx_pow_sqrt's E0REG): three entries in LDS, twelve waves per CU instead of eleven
 template <class C>
-constexpr int rxp_lds_words() { return (1 << (RXP_W - 1)) * PowForm<C>::type::RX_NL * 64; }
+constexpr bool rxp_e0reg() { return C::CURVE_ID == 1; }
+template <class C>
+constexpr int rxp_lds_words() { return ((1 << (RXP_W - 1)) - (rxp_e0reg<C>() ? 1 : 0)) * PowForm<C>::type::RX_NL * 64; }
 template <class C, bool M1>
 __device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
   typedef typename PowForm<C>::type X;
@@ -120,7 +123,7 @@ __device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
   Fp<X> ax;
 #pragma unroll
   for (int i = 0; i < C::L; ++i) ax.v[i] = a.v[i];
-  const Sx<X, SX_T> r = sx_pow_sqrt<X, RXP_W, M1>(ux_to_sx<X>(to_ux<X>(ax)), ld, st);   // (the low word of (p + 1) / 4 is odd: M1 borrows nothing)
+  const Sx<X, SX_T> r = sx_pow_sqrt<X, RXP_W, M1, rxp_e0reg<C>()>(ux_to_sx<X>(to_ux<X>(ax)), ld, st);   // (the low word of (p + 1) / 4 is odd: M1 borrows nothing)
   Ux<X> u;
 #pragma unroll
   for (int i = 0; i < N; ++i) u.v[i] = (u32)r.v[i];

@@ -176,28 +176,38 @@ struct SqrtSchedTab {
   static constexpr typename SqrtSched<C, W, M1>::Tab tab = SqrtSched<C, W, M1>::make();
 };
 
-template <class C, int W, bool M1, class Ld, class St>
+//
+// E0REG: table entry 0 (a itself) stays in the caller's registers and the table holds a^3, a^5, .. in slots 0 .. 2^(W-1) - 2 (ld / st see slot numbers):
+// BLS12-381's four entries of fourteen limbs are 14 336 B per wave, eleven waves per CU; three entries are 10 752 B, and the register limit's
+// twelve waves fit (k_bls_sw_jacobi: fourteen more live registers, still under the 168 of three waves per SIMD).
+template <class C, int W, bool M1, bool E0REG = false, class Ld, class St>
 BGLS_HD Sx<C, SX_T> sx_pow_sqrt(const Sx<C, SX_T>& a, Ld&& ld, St&& st) {
   constexpr int N = C::RX_NL;
   constexpr int TE = 1 << (W - 1);
+  constexpr int E0 = E0REG ? 1 : 0;
   {
     const Sx<C, SX_T> a2 = sx_sqr<C>(a);
     Sx<C, SX_T> o = a;
+    if constexpr (!E0REG) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) st(0, i, o.v[i]);
+      for (int i = 0; i < N; ++i) st(0, i, o.v[i]);
+    }
 #pragma unroll 1
     for (int e = 1; e < TE; ++e) {
       o = sx_mul<C>(o, a2);
 #pragma unroll
-      for (int i = 0; i < N; ++i) st(e, i, o.v[i]);
+      for (int i = 0; i < N; ++i) st(e - E0, i, o.v[i]);
     }
   }
   const int nops = SqrtSchedTab<C, W, M1>::tab.n;
   Sx<C, SX_T> r;
   {
     const int idx = (int)(SqrtSchedTab<C, W, M1>::tab.op[0] >> 10) - 1;
+    if (E0REG && idx == 0) r = a;
+    else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) r.v[k] = ld(idx, k);
+      for (int k = 0; k < N; ++k) r.v[k] = ld(idx - E0, k);
+    }
   }
 #pragma unroll 1
   for (int o = 1; o < nops; ++o) {
@@ -205,9 +215,10 @@ BGLS_HD Sx<C, SX_T> sx_pow_sqrt(const Sx<C, SX_T>& a, Ld&& ld, St&& st) {
     const int nsq = op & 1023, idx = (op >> 10) - 1;
 #pragma unroll 1
     for (int s = 0; s < nsq; ++s) r = sx_sqr<C>(r);
-    if (idx >= 0) {
+    if (E0REG && idx == 0) r = sx_mul<C>(r, a);
+    else if (idx >= 0) {
       const i32* const cols[1] = {r.v};
-      r = sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int k) { return ld(idx, k); });
+      r = sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int k) { return ld(idx - E0, k); });
     }
   }
   return r;

@@ -414,6 +414,8 @@ static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
   };
   const Sx<C, SX_T> r5 = op == 2 ? sx_pow_sqrt<C, 3, true>(x, ld, st) : sx_pow_sqrt<C, 3, false>(x, ld, st);   // the compile-time schedule
   for (int i = 0; i < N; ++i) if (r5.v[i] != r3.v[i]) return -5;
+  const Sx<C, SX_T> r6 = op == 2 ? sx_pow_sqrt<C, 3, true, true>(x, ld, st) : sx_pow_sqrt<C, 3, false, true>(x, ld, st);   // entry 0 in registers, three slots
+  for (int i = 0; i < N; ++i) if (r6.v[i] != r3.v[i]) return -6;
   const Fp<C> want = op == 1 ? fp_sqrt_candidate<C>(a) : fp_pow_w4<C, C::L>(a, e);
   fp_to_be<C>(bytes, fp_from_mont<C>(back(r4)));
   if (g_rx_overflow) return -3;
