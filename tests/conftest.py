@@ -37,13 +37,11 @@ def curve(request):
 @pytest.fixture(scope="session")
 def host_harness():
     """The device arithmetic headers compiled for the host (test-only build)."""
-    so = os.path.join(ROOT, "tests", "harness", "libhost_harness.so")
-    src = os.path.join(ROOT, "tests", "harness", "host_harness.cpp")
-    csrc = os.path.join(ROOT, "bgls_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-o", so, src],
-                       check=True, timeout=900)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("build_harness", os.path.join(ROOT, "tests", "harness", "build_harness.py"))
+    bh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bh)
+    so = bh.build()
     return ctypes.CDLL(so)
 
 

@@ -12,12 +12,24 @@
 #include "../../bgls_amd/csrc/rx_pair.hpp"
 #include "../../bgls_amd/csrc/rx_pow.hpp"
 
+// The file compiles as ONE translation unit (no HT_PART: the sanitizer build includes it whole) or as four parts compiled in parallel and linked
+// together (-DHT_PART=0..3; tests/conftest.py, __graft_entry__.py): the single unit takes five minutes of an -O1 compile, the parts under two.
+#ifdef HT_PART
+#define HT_HAS(p) (HT_PART == (p))
+#else
+#define HT_HAS(p) 1
+#endif
+
+#if HT_HAS(0)
 namespace bgls { int g_rx_overflow = 0; }
+#endif
+#if HT_HAS(0)
 
 // ---- host emulation of a lane pair (rx_pair.hpp): two threads in lock-step, values exchanged through a rendezvous
 static std::atomic<int> g_pair_slot[2];
-static std::atomic<int> g_pair_cnt{0}, g_pair_gen{0};
-static thread_local int tl_pair_lane = 0;
+std::atomic<int> g_pair_cnt{0};
+static std::atomic<int> g_pair_gen{0};
+thread_local int tl_pair_lane = 0;
 static void pair_barrier() {
   const int gen = g_pair_gen.load();
   if (g_pair_cnt.fetch_add(1) == 1) {
@@ -35,7 +47,14 @@ int rx_host_pair_swap(int v) {
   return r;
 }
 
+#else
+extern thread_local int tl_pair_lane;
+extern std::atomic<int> g_pair_cnt;
+int rx_host_pair_swap(int v);
+#endif
 using namespace bgls;
+
+#if HT_HAS(0)
 
 template <class C>
 static int fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -321,6 +340,9 @@ int ht_r28(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   return -1;
 }
 }
+#endif  // part 0
+
+#if HT_HAS(1)
 
 // ---- rx.hpp, consumer side, on RAW limbs (so that the unit tests can feed worst-case limb patterns): A and B hold three
 // Fp2 operands each as [t][half][NL] u32; out = [half][NL].  Returns the overflow flag of the checked column arithmetic.
@@ -425,6 +447,9 @@ static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
 extern "C" int ht_rx_pow(int curve, int op, uint8_t* bytes, i32* limbs) {
   return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : (curve == 2 ? rx_pow<BN254W>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs));
 }
+#endif  // part 1
+
+#if HT_HAS(2)
 
 // ---- rx_pair.hpp: the whole sequence of point steps of one Miller loop on an emulated lane pair, every line (as handed
 // to the consumer: three tight Fp2 entries, scaled by the hash point) and the final point compared with pairing.hpp's
@@ -540,6 +565,9 @@ static int rx_miller_check(const uint8_t* g1, const uint8_t* g2) {
 extern "C" int ht_rx_miller(int curve, const uint8_t* g1, const uint8_t* g2) {
   return curve == 0 ? rx_miller_check<BN254>(g1, g2) : (curve == 2 ? rx_miller_check<BN254W>(g1, g2) : rx_miller_check<BLS381>(g1, g2));
 }
+#endif  // part 2
+
+#if HT_HAS(3)
 
 // ---- rx_jac.hpp: a G2 key sum on the carry-free arithmetic (jacx_madd over the wire-format points, in order) against the
 // library's own Jacobian mixed additions; exceptional cases included by the caller's choice of points.  out = the sum's
@@ -640,3 +668,5 @@ static int rx_sumpair(const uint8_t* pts, int n, uint8_t* out) {
 extern "C" int ht_rx_sumpair(int curve, const uint8_t* pts, int n, uint8_t* out) {
   return curve == 0 ? rx_sumpair<BN254>(pts, n, out) : (curve == 2 ? rx_sumpair<BN254W>(pts, n, out) : rx_sumpair<BLS381>(pts, n, out));
 }
+
+#endif  // part 3
