@@ -810,8 +810,8 @@ def bench_small(lib, dev, inst, n, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--n", "--signers", dest="n", type=int, default=1 << 20, help="signers of the headline batch (whole job)")
     ap.add_argument("--curve", default="altbn128", choices=["altbn128", "bls12"])
