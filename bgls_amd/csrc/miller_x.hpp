@@ -6,9 +6,23 @@
 //   one CONSUMER wave   10 groups x 6 lanes; a group shares ONE Fp12 accumulator among its six pairings
 //                       (f <- f^2 l_1 ... l_6, coop.hpp); lane j owns coefficient j of  f = sum e_j w^j
 // Per line step:   producers: point step (lines stay in registers) | barrier A | store lines | barrier B
-//                  consumer:  barrier A | f <- f^2 (doubling steps)  | barrier B | fold six lines
-// so the producers' step s+1 overlaps the consumer's folds of step s, and the squaring overlaps the stores; one line
-// buffer instead of two (38.6 KB of LDS per block: four blocks per CU).
+//                  consumer:  fold six lines | f <- f^2 (doubling steps) | barrier A | barrier B
+// so the producers' step s+1 overlaps the consumer's folds of step s AND its squaring (round 6: rounds 3-5 squared between A
+// and B, where both producer waves parked for it -- 15 % of their time by the barrier stamps of tools/mb_stamps.hip; ahead of A
+// nobody does: 53.9 -> 53.3 ms alt-bn128, 84.3 -> 83.1 ms BLS12-381 per 2^20 pairings, same bytes); one line buffer instead of
+// two (38.6 KB of LDS per block: four blocks per CU).
+//
+// Why the hand-over stays two block barriers on ONE buffer (round 6, profiles/r6/miller_handover.md).  The stamps show who waits:
+// the consumer arrives last at A in 70 % of the steps and waits there 9.5 % of its time -- all of it in the first twenty steps of
+// a block's life, when its two producers are the YOUNGEST waves of their SIMDs (the issue arbiter serves the oldest ready wave
+// first: a block's period falls from 112 k clocks to 62 k as it ages).  -DMX_EXP_FLAGS=D replaces the barriers by LDS sequence
+// words and lets the producers store D / 2 steps ahead (wrong results beyond D = 2: the single buffer is overwritten -- timing
+// only): D = 2 / 3 / 4 / 6 measured 53.3 / 53.2 / 52.9 / 52.6 ms (alt-bn128), 84.2 / 84.6 / 84.6 / 84.2 ms (BLS12-381) -- a ring of
+// three half-step slots, the most that 160 KB of LDS hold at four blocks per CU, would buy 0.3 %, two whole buffers 0.9 %.
+// Likewise the consumer's exposed LDS round trips: fetching every operand one stage ahead (-DMX_EXP_Q, rx.hpp ux_dot_k2q) takes a
+// consumer wave ALONE from 38.9 to 34.9 ms and the whole kernel from 53.9 to 55.2 ms: the old blocks' consumers issue denser and
+// the young blocks' producers starve longer.  What bounds the kernel is instruction issue: 2.73e10 vector instructions per launch
+// at the 4.4-4.5 clocks a mixed stream of three waves per SIMD pays per instruction (probe in tools/mb_stamps.hip) are 50 of the 54 ms.
 //
 // What the 32-bit kernels (k_miller_ab64 / k_miller_s60) lose and this one does not: three VALU instructions per multiplier
 // instruction (carry add, re-zeroed addend) -- here every dot product is bare v_mad_u64_u32 into 64-bit columns; a producer
@@ -84,7 +98,12 @@ struct MX {
 #define MX_P_LDS_LIMIT 40960
 #endif
   static constexpr bool P_IN_LDS = (10 * GROUP_DW + NP * 2 * HS) * 4 <= MX_P_LDS_LIMIT;
+  static constexpr int SEQ_DW = 10 * GROUP_DW + (P_IN_LDS ? NP * 2 * HS : 0);          // MX_EXP_FLAGS: four sequence words behind everything else
+#ifdef MX_EXP_FLAGS
+  static constexpr int BLOCK_BYTES = (SEQ_DW + 16) * 4;
+#else
   static constexpr int BLOCK_BYTES = (10 * GROUP_DW + (P_IN_LDS ? NP * 2 * HS : 0)) * 4;
+#endif
   static constexpr int NPARK_Q = C::CURVE_ID == 0 ? 6 : 2;                  // xq yq [x1 y1 x2 y2]
   static constexpr int NPARK = NPARK_Q + (P_IN_LDS ? 0 : 2);                // ... nyP xP   (PS dwords each)
   static constexpr int PS = (NL + 3) & ~3;                                  // parked values stay 16-byte aligned
@@ -178,6 +197,18 @@ __device__ __forceinline__ Ux2<C> mx_fold(int gb, int m, int j) {
   // powers of w the line's three entries sit at: {0, 1, 3} (D-type twist) / {0, 2, 3} (M-type), as arithmetic on t: a table in
   // constant memory costs a scalar load and a wait for it in front of every operand fetch
   auto sh = [](int t) { return C::TWIST_D ? t + (t == 2 ? 1 : 0) : t + (t >= 1 ? 1 : 0); };
+#ifdef MX_EXP_Q
+  if constexpr (C::RX_NL <= 10)
+    return ux_dot_k2q<C, 3>(
+      [&](int t, int h) { return mx_ld_half<C, K::PACKED>(gb + K::line_off(3 * m + t) + h * K::HS, h != 0); },
+      [&](int t, int h) {
+        int k = j - sh(t);
+        const int wrap = k < 0 ? 1 : 0;
+        k += 6 * wrap;
+        return mx_ld_half<C, K::PACKED>(gb + K::acc_off(k, wrap) + h * K::HS, h != 0);
+      });
+  else
+#endif
   return ux_dot_k2p<C, 3, (C::RX_NL <= 10)>(
       [&](int t, int h) { return mx_ld_half<C, K::PACKED>(gb + K::line_off(3 * m + t) + h * K::HS, h != 0); },
       [&](int t, int h) {
@@ -316,6 +347,41 @@ struct MxPark {
 // results, used to time the two roles separately.
 // (Round 3's variant with two consumer waves per block -- 20 partial products, the squaring done twice -- measured slower in
 // steady state and is gone.)
+// DBG == 4 (development tools only, tools/mb_stamps.hip): time stamps (s_memtime, low word) at the arrival at and the release from the two
+// barriers of every line step, per wave of the sampled blocks: who waits for whom.  Record of a wave: MX_STAMP_DW dwords,
+// [0] HW_ID [1] XCC_ID [2..3] s_memrealtime at the start [4..5] at the end [6] role [7] s_memtime at the start [8] at the end [9] line steps,
+// [16 + 4 s + k]: step s, k = 0 arrival at A, 1 release from A, 2 arrival at B, 3 release from B.
+// MX_EXP_FLAGS = D (experiment): the hand-over through LDS sequence words instead of the two block barriers.  cons (word 0) counts the HALF steps the
+// consumer has finished with (three lines each), prod[w] (words 1, 2) the steps producer wave w has stored.  A producer may store step s once
+// cons >= 2 s + 2 - D: D = 2 is the single line buffer (what the barriers enforce), D = 3 a ring of three half-step slots, D = 4 two whole buffers.
+// With D > 2 on the single-buffer layout the lines are overwritten early: WRONG RESULTS, timing only -- it prices the decoupling before the ring is built.
+__device__ __forceinline__ u32 mx_seq_ld(int dw) {
+  u32 v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(dw * 4) : "memory");
+  return (u32)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void mx_seq_st(int dw, u32 val) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"(dw * 4), "v"(val) : "memory");
+}
+__device__ __forceinline__ void mx_seq_wait(int dw, int target) {
+  while ((int)mx_seq_ld(dw) - target < 0) __builtin_amdgcn_s_sleep(1);
+}
+
+constexpr int MX_STAMP_STEPS = 96;
+constexpr int MX_STAMP_DW = 16 + 4 * MX_STAMP_STEPS;
+constexpr int MX_STAMP_EVERY = 16;          // every sixteenth block is sampled
+template <int DBG>
+__device__ __forceinline__ void mx_stamp(u32* rec, int slot) {
+  if constexpr (DBG == 4) {
+    if (rec != nullptr) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if ((threadIdx.x & 63) == 0) rec[slot] = (u32)t;
+    }
+  } else {
+    (void)rec; (void)slot;
+  }
+}
+
 #ifndef MX_WAVES
 #define MX_WAVES 3          // waves per SIMD the register allocation is made for (tools: -DMX_WAVES=4 tries five blocks per CU)
 #endif
@@ -362,6 +428,25 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
     const int rot = rmode == 2 ? (int)(blockIdx.x % 3u) : 0;
     role = w + rot;
     if (role >= 3) role -= 3;
+  }
+#ifdef MX_EXP_FLAGS
+  if (threadIdx.x < 4) lds_roles[K::SEQ_DW + threadIdx.x] = 0u;
+  __syncthreads();
+#endif
+  u32* srec = nullptr;                 // DBG == 4: this wave's stamp record (sampled blocks only)
+  int sstep = 0;
+  if constexpr (DBG == 4) {
+    if (rec_dbg != nullptr && blockIdx.x % MX_STAMP_EVERY == 0) {
+      srec = rec_dbg + ((size_t)(blockIdx.x / MX_STAMP_EVERY) * 3 + w) * MX_STAMP_DW;
+      if (lane == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        srec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        srec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        srec[2] = (u32)t; srec[3] = (u32)(t >> 32);
+        srec[6] = (u32)role;
+        srec[7] = (u32)__builtin_readcyclecounter();
+      }
+    }
   }
   if (role < 2) {
     // ---------------------------------------------------------------- producer: PPW pairings, one per lane pair
@@ -436,6 +521,7 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
       else if constexpr (std::is_same<std::decay_t<decltype(v)>, Sx<C, SX_T>>::value) e[entry] = sx_to_ux_p<C>(v);    // a reduction's output: + p, below 2.1 p
       else e[entry] = sx_to_ux_k<1, C>(v);              // the P-free coefficient, a difference of two reductions' outputs: + 2 p, below 3.1 p
     };
+    int pstep = 0;                        // MX_EXP_FLAGS: line steps stored so far
     auto hand_over = [&]() __attribute__((always_inline)) {
       // the constant line 1 for a pairing that is not there (a batch's ragged end, a key or hash point at infinity).  Decided per WAVE first: the lanes
       // that own no pairing never store their line, so only an OWNED invalid pairing needs the selects, and a wave without one -- all but the last
@@ -447,13 +533,27 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
           e[2] = ux_zero<C>();
         }
       }
+      mx_stamp<DBG>(srec, 16 + 4 * sstep);
+#ifdef MX_EXP_FLAGS
+      mx_seq_wait(K::SEQ_DW, 2 * pstep + 2 - (MX_EXP_FLAGS));
+#else
       __syncthreads();                    // A: the consumer has finished with the previous lines
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 1);
       if (owner) {
         mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m), odd, e[0]);
         mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m + 1), odd, e[1]);
         mx_st_half<C, K::PACKED>(rl_base + K::line_off(3 * m + 2), odd, e[2]);
       }
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 2);
+#ifdef MX_EXP_FLAGS
+      ++pstep;
+      mx_seq_st(K::SEQ_DW + 1 + role, (u32)pstep);          // LDS serves a wave's accesses in order: the lines are in place when this word is
+#else
       __syncthreads();                    // B: lines visible
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 3);
+      if constexpr (DBG == 4) ++sstep;
     };
     struct Env {
       const u32* pk;
@@ -528,38 +628,101 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
     }
     mx_publish<C, NP>(gb, j, fj, live);
     unsigned sq_d = 0, sq_p = 0;
+    int cstep = 0;                        // MX_EXP_FLAGS: line steps folded so far
+    (void)cstep;
     if constexpr (!rx_lazy<C>) mx_sq_split(COOP_SQ_TAB[j], sq_d, sq_p);
     auto fold_all = [&]() __attribute__((always_inline)) {
-      if constexpr (DBG == 1) return;
+      if constexpr (DBG == 1) {
+#ifdef MX_EXP_FLAGS
+        mx_seq_st(K::SEQ_DW, (u32)(2 * cstep + 2));
+        ++cstep;
+#endif
+        return;
+      }
       // unrolled by three on the 29-bit form (same-box A/B at 2^20 pairings: 54.4 -> 54.0 ms; by two 54.3, by six 54.1), rolled on BLS12-381
       // (unrolled by two or three: 86.8 -> 87.2 ms)
 #pragma unroll K::FOLD_UNROLL
       for (int m = 0; m < K::NLINES; ++m) {
         fj = mx_fold<C, NP>(gb, m, j);
+#ifdef MX_EXP_FLAGS
+        if (m == 2) mx_seq_st(K::SEQ_DW, (u32)(2 * cstep + 1));                 // the fold's fetches are in LDS's queue ahead of this word
+        if (m == K::NLINES - 1) mx_seq_st(K::SEQ_DW, (u32)(2 * cstep + 2));
+#endif
         mx_publish<C, NP>(gb, j, fj, live);
       }
+#ifdef MX_EXP_FLAGS
+      ++cstep;
+#endif
     };
+#ifdef MX_EXP_FLAGS
+    auto lines_ready = [&]() __attribute__((always_inline)) {
+      mx_seq_wait(K::SEQ_DW + 1, cstep + 1);
+      mx_seq_wait(K::SEQ_DW + 2, cstep + 1);
+    };
+#endif
 #pragma unroll 1
     for (int i = 1; i < C::LOOP_LEN; ++i) {
-      __syncthreads();                    // A
-      if (DBG != 1 && i > 1) {            // f = 1 before the first step
+#ifndef MX_SQR_LATE
+      if (DBG != 1 && i > 1) {            // f = 1 before the first step.  The squaring needs no line: it goes AHEAD of A (round 6), so that the producers never park for it at B
         if constexpr (rx_lazy<C>) fj = mx_sqr<C, NP>(gb, j);
         else fj = mx_sqr3<C, NP>(gb, sq_d, sq_p);
         mx_publish<C, NP>(gb, j, fj, live);
       }
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep);
+#ifdef MX_EXP_FLAGS
+      lines_ready();
+#else
+      __syncthreads();                    // A
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 1);
+#ifdef MX_SQR_LATE                     // -DMX_SQR_LATE: rounds 3-5, the squaring between A and B (A/B measurements)
+      if (DBG != 1 && i > 1) {
+        if constexpr (rx_lazy<C>) fj = mx_sqr<C, NP>(gb, j);
+        else fj = mx_sqr3<C, NP>(gb, sq_d, sq_p);
+        mx_publish<C, NP>(gb, j, fj, live);
+      }
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 2);
+#ifndef MX_EXP_FLAGS
       __syncthreads();                    // B
+#endif
+      mx_stamp<DBG>(srec, 16 + 4 * sstep + 3);
+      if constexpr (DBG == 4) ++sstep;
       fold_all();
       if (C::LOOP_NAF[i] != 0) {
+        mx_stamp<DBG>(srec, 16 + 4 * sstep);
+#ifdef MX_EXP_FLAGS
+        lines_ready();
+#else
         __syncthreads();
+#endif
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 1);
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 2);
+#ifndef MX_EXP_FLAGS
         __syncthreads();
+#endif
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 3);
+        if constexpr (DBG == 4) ++sstep;
         fold_all();
       }
     }
     if constexpr (C::CURVE_ID == 0) {
 #pragma unroll 1
       for (int s = 0; s < 2; ++s) {
+        mx_stamp<DBG>(srec, 16 + 4 * sstep);
+#ifdef MX_EXP_FLAGS
+        lines_ready();
+#else
         __syncthreads();
+#endif
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 1);
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 2);
+#ifndef MX_EXP_FLAGS
         __syncthreads();
+#endif
+        mx_stamp<DBG>(srec, 16 + 4 * sstep + 3);
+        if constexpr (DBG == 4) ++sstep;
         fold_all();
       }
     }
@@ -578,6 +741,14 @@ __global__ void __launch_bounds__(192, MX_WAVES) k_miller_x60(const Aff<F1<C>>* 
       const unsigned long long t = __builtin_amdgcn_s_memrealtime();
       rec[4] = (u32)t; rec[5] = (u32)(t >> 32);
       rec[6] = (u32)role;
+    }
+  }
+  if constexpr (DBG == 4) {
+    if (srec != nullptr && lane == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      srec[4] = (u32)t; srec[5] = (u32)(t >> 32);
+      srec[8] = (u32)__builtin_readcyclecounter();
+      srec[9] = (u32)sstep;
     }
   }
 }

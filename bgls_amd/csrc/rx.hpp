@@ -427,6 +427,61 @@ BGLS_HD Ux2<C> ux_dot_k2p(LA&& lda, LB&& ldb) {
   return r;
 }
 
+// The same dot product with every operand fetch issued ONE STAGE AHEAD of its use (round 6).  The multiplier rows are volatile asm statements,
+// so the compiler leaves each fetch where the source puts it: ux_dot_k2p's second pass (fetch two halves, subtract, fetch two halves, subtract,
+// multiply) waits out an LDS round trip in front of every term, six times per line fold -- tools/mb_stamps.bin: a consumer wave alone runs at
+// 60 % of its issue rate.  Here the halves of term t + 1 are requested before the 81 / 196 multiplier instructions of term t go out, pass 2's
+// first term before the first reduction, and (PRE) the caller may hand in halves it requested even earlier.  Same products, same piles, same
+// order of accumulation: bit-identical results.  Live at the peak (pass 1): two piles, the two halves being multiplied, the two in flight.
+template <class C, int NT, class LA, class LB>
+BGLS_HD Ux2<C> ux_dot_k2q(LA&& lda, LB&& ldb) {
+  constexpr int N = C::RX_NL;
+  static_assert(NT >= 1 && NT <= 3, "column budget");
+  u64 d[2 * N], e[2 * N];
+  Ux<C> a0 = lda(0, 0), b0 = ldb(0, 0);
+  Ux<C> a1 = lda(0, 1), b1 = ldb(0, 1);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t == 0) ux_acc_new<C>(d, a0, b0); else ux_acc<C>(d, a0, b0);
+    if (t + 1 < NT) { a0 = lda(t + 1, 0); b0 = ldb(t + 1, 0); }
+    else { a0 = lda(0, 0); b0 = ldb(0, 0); }                       // pass 2, term 0
+    if (t == 0) ux_acc_new<C>(e, a1, b1); else ux_acc<C>(e, a1, b1);
+    if (t + 1 < NT) { a1 = lda(t + 1, 1); b1 = ldb(t + 1, 1); }
+    else { a1 = lda(0, 1); b1 = ldb(0, 1); }
+  }
+  Ux2<C> r;
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) {
+    const u64 dk = d[k], ek = e[k];
+    e[k] = dk + C::RX_BIAS_D3[k] - ek;
+    d[k] = dk + ek;
+  }
+  r.c0 = ux_redc<C>(e);
+#if RX_HOST_CHECK
+  u64 chk[2 * N];
+  for (int k = 0; k < 2 * N; ++k) chk[k] = 0;
+#endif
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    i32 sa[N], sb[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) { sa[q] = (i32)a1.v[q] - (i32)a0.v[q]; sb[q] = (i32)b0.v[q] - (i32)b1.v[q]; }
+#if RX_HOST_CHECK
+    ux_acc<C>(chk, lda(t, 0), ldb(t, 1));
+    ux_acc<C>(chk, lda(t, 1), ldb(t, 0));
+#endif
+    if (t + 1 < NT) { a0 = lda(t + 1, 0); a1 = lda(t + 1, 1); b0 = ldb(t + 1, 0); b1 = ldb(t + 1, 1); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) rx_rows_wrap<N>(d + i, sa[i], sb);
+  }
+#if RX_HOST_CHECK
+  for (int k = 0; k < 2 * N; ++k)
+    if (chk[k] != d[k]) g_rx_overflow = 1;
+#endif
+  r.c1 = ux_redc<C>(d);
+  return r;
+}
+
 // c = sum over up to four slots of A_t * B_t with doubled slots (the symmetric squaring of coop.hpp: at most six
 // term-equivalents per lane), Karatsuba over i in the two passes of ux_dot_k2p (round 4; schoolbook until then: 16 NL^2
 // multiplier instructions per lane and squaring, now 12):
@@ -537,8 +592,13 @@ BGLS_HD Ux2<C> ux_sqr_dot3(LA&& lda, LB&& ldb, SA&& sha, SB&& shb, bool twice) {
     for (int q = 0; q < N; ++q) a.v[q] <<= s;
     return a;
   };
+#ifdef MX_EXP_Q
+  const Ux2<C> d = ux_dot_k2q<C, 2>([&](int t, int h) { return left(lda, sha, t, h); }, [&](int t, int h) { return lda(t, 1, h); });
+  const Ux2<C> p = ux_dot_k2q<C, 2>([&](int t, int h) { return left(ldb, shb, t, h); }, [&](int t, int h) { return ldb(t, 1, h); });
+#else
   const Ux2<C> d = ux_dot_k2p<C, 2>([&](int t, int h) { return left(lda, sha, t, h); }, [&](int t, int h) { return lda(t, 1, h); });
   const Ux2<C> p = ux_dot_k2p<C, 2>([&](int t, int h) { return left(ldb, shb, t, h); }, [&](int t, int h) { return ldb(t, 1, h); });
+#endif
   const u32 ps = twice ? 1u : 0u;
   Ux2<C> s;
 #pragma unroll
