@@ -134,13 +134,62 @@ def traffic_for(kernel_key):
     builder-held constant of the evidence run, not measured in this process (labelled as such).  The same file carries the
     evidence run's SQ readings of the kernel: valu_busy = rocprofiler's VALUBusy (sum SQ_ACTIVE_INST_VALU / CUs /
     GRBM_GUI_ACTIVE per XCD) and lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
-    for rnd in ("r5", "r4", "r3", "r2"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(path):
             det = json.load(open(path))
             if kernel_key in det:
-                return det[kernel_key].get("bytes_per_launch_fetch_x2"), dict(det[kernel_key], source="profiles/%s/pmc_traffic.json (evidence run, not this process)" % rnd)
+                d = dict(det[kernel_key], source="profiles/%s/pmc_traffic.json (evidence run, not this process)" % rnd)
+                d.setdefault("counters_from", "profiles/%s (builder run)" % rnd)
+                return det[kernel_key].get("bytes_per_launch_fetch_x2"), d
     return None, None
+
+
+SIMDS = 1024                 # 256 CUs x 4
+MAD_LANES_PER_CLOCK = 16     # v_mad_u64_u32: a quarter-rate instruction, 16 lanes per clock and SIMD
+
+
+def cycle_roofline(roof):
+    """VERDICT r5 (weak 2): `peak` is measured by a probe of bare multiplier chains, and the chip holds a LOWER clock under that probe
+    (1.95-2.15 GHz, tools/mb_stamps.hip) than under the kernels (2.1-2.4 GHz by GRBM_GUI_ACTIVE / duration in the evidence run's counter
+    pass), so `frac` flatters them.  peak_at_kernel_clock = 16 lanes x 1024 SIMDs x that clock; frac_cycles = achieved / it: the share of
+    the multiplier's issue SLOTS the algorithmic work fills.  Both ride beside `frac`; the clock is the evidence run's, labelled so."""
+    td = roof.get("traffic_detail") or {}
+    ghz = td.get("kernel_clock_ghz")
+    if not ghz:
+        return roof
+    pk = MAD_LANES_PER_CLOCK * SIMDS * ghz * 1e9 / 1e12
+    roof["peak_at_kernel_clock"] = pk
+    roof["kernel_clock_ghz"] = ghz
+    roof["frac_cycles"] = roof["achieved"] / pk if roof.get("achieved") else None
+    ex = roof.get("exclusive")
+    if ex and ex.get("achieved"):
+        ex["frac_cycles"] = ex["achieved"] / pk
+    roof["counters_from"] = td.get("counters_from")
+    return roof
+
+
+def cpu_baseline_small(cid, inst, lib, n):
+    """BASELINE config 1 at its own shape ('Run on libbgls_cpu with T = all host cores'): the C oracle verifying the SAME
+    n-signer instance, one call at a time as bgls/bgls_test.go:186-202 does, every host core the process may use."""
+    from oracle import coracle
+    fp = inst["fp"]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    agg = aggregate_sig(lib, inst, 0, n)
+    ms = [inst["msgs"][64 * i:64 * i + 64] for i in range(n)]
+    keys = inst["keys"][:n * 4 * fp]
+    thr = min(cores, n + 1)              # the reference starts one goroutine per pairing: more threads than pairings have nothing to do
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ok = coracle.verify_aggregate(cid, agg, keys, ms, False, thr, 1)
+        ts.append(time.perf_counter() - t0)
+        if ok != 1:
+            raise RuntimeError("oracle rejected the GPU-generated n = %d instance" % n)
+    med = statistics.median(ts)
+    return {"value": n / med, "unit": "signer-pairs/s", "cores": thr, "host_cores": cores, "kind": "port", "ms_per_call": med * 1e3,
+            "sample": "the same %d-signer instance, 5 calls, median; C oracle, %d threads of %d host cores, final exponentiation per pairing "
+                      "(curves/curve.go:132-134)" % (n, thr, cores)}
 
 
 def cpu_baseline(cid, inst, lib):
@@ -150,7 +199,8 @@ def cpu_baseline(cid, inst, lib):
     from oracle import coracle
     fp, n = inst["fp"], inst["n"]
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 64)
+    host_cores = cores
+    cores = min(cores, 256)              # the oracle's own thread table (oracle/c/curve_impl.c); every host core below that
     probe = min(n, 4 * cores)
 
     def run(cnt, faithful):
@@ -177,7 +227,7 @@ def cpu_baseline(cid, inst, lib):
     for _ in range(reps):
         coracle.final_exp(cid, coracle.miller(cid, bytes(hs), inst["keys"][:4 * fp]))
     per_core_ms = (time.perf_counter() - t0) / reps * 1e3
-    return {"value": cnt / dt, "unit": "signer-pairs/s", "cores": cores, "kind": "port", "per_core_ms_per_pairing": per_core_ms,
+    return {"value": cnt / dt, "unit": "signer-pairs/s", "cores": cores, "host_cores": host_cores, "kind": "port", "per_core_ms_per_pairing": per_core_ms,
             "sample": "first %d signers, C oracle (sparse lines, cyclotomic squarings), %d threads, final exponentiation per pairing as the "
                       "reference does; one shared final exponentiation: %.0f pairs/s; one pairing alone on one core: %.2f ms (reference "
                       "README: 1.96 / 1.54 ms on a laptop core)" % (cnt, cores, min(cnt, 4096) / dt_shared, per_core_ms)}
@@ -192,7 +242,7 @@ def _num(x, digits=4):
 def collective_info(cid, world):
     """what the N > 1 exchange is: one all-gather of GT partials + status words per step"""
     info = {"backend": None, "world": world, "rccl_version": None, "bytes_per_step": world * (12 * (32 if cid == 0 else 48) + 8), "op": "all_gather",
-            "digest_bytes_per_signer": 16}       # + one all-gather of 16-byte message digests (global duplicate rule), 16 B per signer of the batch
+            "digest_exchange": "all_to_all by bucket", "digest_bytes_per_rank_and_step": None}   # filled by the caller: world x slot records x 16 B (sharding.digest_slot_records)
     try:
         info["backend"] = dist.get_backend()
         info["world"] = dist.get_world_size()
@@ -219,6 +269,12 @@ def compact_line(full):
         for k in ("valu_busy", "lds_conflict_ratio"):          # counter readings of the committed evidence run (profiles/rN/pmc_traffic.json)
             if td.get(k) is not None:
                 out[k] = _num(td[k])
+        # the cycle-basis reading (cycle_roofline) and where traffic / valu_busy / lds_conflict_ratio / the clock come from: NOT this process
+        if r.get("peak_at_kernel_clock"):
+            out["peak_at_kernel_clock"] = _num(r["peak_at_kernel_clock"])
+            out["frac_cycles"] = _num(ex.get("frac_cycles", r.get("frac_cycles")))
+            out["kernel_clock_ghz"] = _num(r.get("kernel_clock_ghz"))
+        out["counters_from"] = r.get("counters_from") or td.get("counters_from")
         if ex:
             out["frac_timed_region"] = _num(r.get("frac"))
             out["kernel_timed_region"] = r.get("kernel")
@@ -230,7 +286,7 @@ def compact_line(full):
     def cpu(c):
         if not c:
             return None
-        return {k: _num(c.get(k)) for k in ("value", "unit", "cores", "kind", "per_core_ms_per_pairing") if k in c} | {"sample": str(c.get("sample", ""))[:120]}
+        return {k: _num(c.get(k)) for k in ("value", "unit", "cores", "host_cores", "kind", "per_core_ms_per_pairing") if k in c} | {"sample": str(c.get("sample", ""))[:120]}
 
     cfg = full.get("config", {})
     line = {"metric": full.get("metric"), "value": _num(full.get("value"), 6), "unit": full.get("unit"), "n_gpus": full.get("n_gpus"),
@@ -250,6 +306,7 @@ def compact_line(full):
         recs[k] = {"value": _num(r.get("value"), 5), "ms_per_step": _num(r.get("ms_per_step"), 5), "frac": _num(ex.get("frac", rf.get("frac")))}
         if r.get("cpu_baseline"):
             recs[k]["cpu"] = _num(r["cpu_baseline"].get("value"))
+            recs[k]["cpu_cores"] = r["cpu_baseline"].get("cores")
     line["records"] = recs
     s = json.dumps(line, separators=(",", ":"))
     if len(s) >= 4096:                    # never let the line outgrow the driver's tail: drop the secondary map first
@@ -346,13 +403,20 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
             if world > 1:
                 # duplicates may straddle shards (containsDuplicateMessage is a rule about the whole list): the ranks exchange
                 # 16-byte digests of their messages, not the messages (16 MiB instead of 64 MiB at 2^20), and rank r scans the digests
-                # whose first byte is r mod world (round 5: 1 / world of the inserts each; equal digests share a bucket); the probe word
-                # travels with the status word, so every rank holds the OR; a hit is settled exactly when the verdict is collected
+                # whose first byte is r mod world (equal digests share a bucket).  Round 6: the exchange is an all-to-all by bucket --
+                # rank r RECEIVES only the digests it owns (1.25 / world of the all-gather's bytes per rank, sharding.py
+                # exchange_digests_by_bucket); the probe word travels with the status word, so every rank holds the OR; a hit (or a
+                # send slot that overflowed) is settled exactly when the verdict is collected
                 ln["msgs"] = msgs_t
+                pw = ln["words"].data_ptr() + 4
+
+                def pack(dig, cnt, nb, cap):
+                    out = torch.empty(nb * cap * 16, dtype=torch.uint8, device=dev)
+                    check(lib.bgls_digest_pack_dev(dig.data_ptr(), cnt, nb, cap, out.data_ptr(), pw, h), "digest_pack_dev")
+                    return out
                 enqueue_digest_probe(lambda m, cnt: digests_of(m, cnt, h),
-                                     lambda buf, rl, cnt, bucket, nb: check(lib.bgls_duplicate_scan_bucket_dev(buf.data_ptr(), rl, rl, cnt, bucket, nb, ln["words"].data_ptr() + 4, h),
-                                                                            "duplicate_scan_bucket_dev"),
-                                     msgs_t, n, world, rank=rank)
+                                     lambda buf, rl, cnt, bucket, nb: check(lib.bgls_duplicate_scan_packed_dev(buf.data_ptr(), cnt, bucket, nb, pw, h), "duplicate_scan_packed_dev"),
+                                     msgs_t, n, world, rank=rank, pack=pack)
             if handle is not None:
                 check(lib.bgls_miller_product_keys_dev(handle, t_sig.data_ptr(), msgs_t.data_ptr(), 64, 64, n, 1, ln["part"].data_ptr(), ln["flags"].data_ptr(), h),
                       "miller_product_keys_dev")
@@ -535,6 +599,8 @@ def bench_aggregate(lib, dev, inst, n_total, rank, world, steps, warmup, reps, i
         rec["with_message_h2d"] = {"value": n_total * steps / h2d_elapsed, "ms_per_step": h2d_elapsed / steps * 1e3,
                                    "note": "the same steps with the %d MiB of messages copied from pinned host memory inside every step "
                                            "(keys stay resident, SURVEY 8d timing protocol)" % (n * 64 >> 20)}
+    if not prepared:                      # the evidence run's counters are those of the un-prepared Miller kernel
+        cycle_roofline(rec["roofline"])
     return rec
 
 
@@ -621,7 +687,7 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
     main_s = stage_ms_per_call(stages_excl["sum_main"][0], calls) * 1e-3       # the main-pass kernel alone (HIP events around its launch)
     macs = n * MULTISIG_FPMUL * MAC_PER_FPMUL[cid]              # one G2 mixed addition ~ 29 m per signer
     traffic, tdet = traffic_for("k_sumpair_main_" + CNAME[cid])
-    return {
+    rec = {
         "metric": "multisig-verify signers/sec", "value": n / med, "unit": "signers/s", "ms_per_step": med * 1e3, "ms_per_step_min": per_step[0] * 1e3,
         "ms_per_step_all": [p * 1e3 for p in per_step], "steps": steps, "warmup": warmup, "repetitions": reps, "n_gpus": 1, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s KoskVerifyMultiSignature, %d signers on one message, keys resident in HBM as %s"
@@ -638,6 +704,8 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
         "sequential": {"ms_per_step_median": statistics.median(seq), "ms_per_step_min": min(seq), "value": n / (statistics.median(seq) * 1e-3)},
         "stage_ms_exclusive": {k: stage_ms_per_call(v[0], calls) for k, v in stages_excl.items()},
     }
+    cycle_roofline(rec["roofline"])
+    return rec
 
 
 def bench_multisig_batch(lib, dev, inst, n, nsets, steps, warmup, reps, in_flight):
@@ -892,6 +960,7 @@ def main():
             records["altbn128_multisig_batch_16x%d" % bn["n"]] = bench_multisig_batch(lib, dev, bn, bn["n"], 16, 16, 2, args.reps, 8)
             records["altbn128_64"] = bench_small(lib, dev, bn, min(64, bn["n"]), 20)
             if not args.no_cpu_baseline:
+                records["altbn128_64"]["cpu_baseline"] = cpu_baseline_small(0, bn, lib, min(64, bn["n"]))
                 for c_, i_ in ((cid, inst), (other, oinst)):
                     cb = cpu_baseline(c_, i_, lib)
                     for key in ("%s_%d" % (CNAME[c_], args.n), "%s_%d" % (CNAME[c_], small_n)):
@@ -907,6 +976,8 @@ def main():
         full["records"] = records
         if world > 1:
             full["collective"] = collective_info(cid, world)
+            from bgls_amd.sharding import digest_slot_records
+            full["collective"]["digest_bytes_per_rank_and_step"] = world * digest_slot_records(args.n // world, world) * 16
         # full per-record detail: an EARLIER stdout line and a file; the LAST line is the compact record the driver parses
         try:
             with open(os.path.join(ROOT, "bench_records.json"), "w") as f:

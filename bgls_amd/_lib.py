@@ -67,6 +67,8 @@ SIGNATURES = {
     "bgls_duplicate_scan_dev": (ci, [vp, sz, sz, sz, vp, vp]),
     "bgls_duplicate_scan_bucket_dev": (ci, [vp, sz, sz, sz, ctypes.c_uint, ctypes.c_uint, vp, vp]),
     "bgls_message_digests_dev": (ci, [vp, sz, sz, sz, vp, vp]),
+    "bgls_digest_pack_dev": (ci, [vp, sz, ctypes.c_uint, sz, vp, vp, vp]),
+    "bgls_duplicate_scan_packed_dev": (ci, [vp, sz, ctypes.c_uint, ctypes.c_uint, vp, vp]),
     "bgls_final_verify_submit_dev": (ci, [ci, vp, sz, vp, vp]),
     "bgls_final_verify_collect": (ci, [ci]),
     "bgls_select_context": (ci, [ci]),

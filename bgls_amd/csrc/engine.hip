@@ -28,6 +28,8 @@ typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
 
 #include <new>
+#include <random>
+#include <chrono>
 #include <stdexcept>
 #include <system_error>
 #include "dev_common.hpp"

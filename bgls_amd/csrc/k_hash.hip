@@ -10,9 +10,11 @@
 using namespace bgls;
 
 // ---- duplicate-message scan: open-addressing table of (index+1), exact byte comparison ----
-// ---- duplicate-message scan: open-addressing table of (index+1), exact byte comparison ----
-__device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n) {
-  uint64_t h = 0xcbf29ce484222325ull;
+// `seed`: drawn by the host per process and call (engine_core.inc dup_scan).  The slot of a record must not be predictable from its bytes: an
+// unseeded FNV can be inverted, and 2^20 chosen messages that share one slot turn the scan into 2^40 probes (the reference's Go map is
+// seeded per process for the same reason, bgls/bgls.go:139-150).
+__device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n, uint64_t seed) {
+  uint64_t h = 0xcbf29ce484222325ull ^ seed;
   for (size_t i = 0; i < n; ++i) {
     h ^= p[i];
     h *= 0x100000001b3ull;
@@ -25,16 +27,22 @@ __device__ __forceinline__ uint64_t msg_hash64(const uint8_t* p, size_t n) {
 
 // bucket / n_buckets (n_buckets > 1): only the records whose first byte is `bucket` mod n_buckets enter the table -- equal records
 // share a bucket, so n_buckets scans (one per rank of a multi-GPU verification, over the all-gathered digests) find exactly what
-// one scan of everything finds, each on 1 / n_buckets of the inserts.  A table that fills up (a bucket far above its share: not
-// digests, or an adversary's) reports a hit, which the caller settles with the exact scan: never a miss.
-__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets) {
+// one scan of everything finds, each on 1 / n_buckets of the inserts.  A bucket far above its share (records that are not digests, or an
+// adversary's: a signer can grind messages until every digest starts with the same byte) is reported as a hit, which the caller settles
+// with the exact scan: never a miss.  Round 6 (advice r5): the bucketed scan gives up after `max_probe` probes instead of walking the
+// whole table -- with the table at load factor 1 every insert walked all of it, 10^10 probes at 2^20 records per rank and more with
+// every rank added -- and every thread leaves as soon as anybody has raised the flag (the verdict of the scan is decided by then in
+// both modes).  The exact scan (n_buckets = 1) has a table of at least 2 n slots and probes without a bound.
+__global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets, uint32_t max_probe,
+                            uint64_t seed) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m = mv.ptr(i);
   const size_t len = mv.size(i);
   if (n_buckets > 1 && (len == 0 ? 0u : (uint32_t)m[0]) % n_buckets != bucket) return;
-  uint32_t slot = (uint32_t)msg_hash64(m, len) & mask;
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+  uint32_t slot = (uint32_t)msg_hash64(m, len, seed) & mask;
+  for (uint32_t probe = 0; probe <= max_probe; ++probe) {
+    if ((probe & 31u) == 31u && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_DUP)) return;
     uint32_t prev = atomicCAS(&table[slot], 0u, (uint32_t)i + 1u);
     if (prev == 0u) return;
     size_t j = prev - 1u;
@@ -53,7 +61,7 @@ __global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask
     }
     slot = (slot + 1u) & mask;
   }
-  atomicOr(flags, FLAG_DUP);          // every slot taken by other records: undecided, reported as a hit (see above)
+  atomicOr(flags, FLAG_DUP);          // bucketed scan: too long a run of taken slots -- undecided, reported as a hit (see above)
 }
 
 // alt-bn128 try-and-increment as compacting rounds (curves/hash.go:53-77 has data-dependent trip
@@ -456,8 +464,41 @@ namespace kl {
 
 void msg_digest(hipStream_t st, MsgView mv, size_t n, uint8_t* out) { k_msg_digest<<<nblk(n, 256), 256, 0, st>>>(mv, n, out); }
 
-void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets) {
-  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags, bucket, n_buckets);
+// ---- the digest exchange of a multi-GPU verification as an all-to-all by bucket (round 6).  Rank r owns the digests whose first byte is r mod N.
+// k_digest_pack sorts a rank's n digests into N send slots of `cap` records each; a slot's unused records are padding whose first byte
+// belongs to ANOTHER bucket ((b + 1) mod N: the receiver's bucket filter skips them), so every rank sends and receives N equal chunks --
+// no count exchange, no host round trip -- and holds, after the all-to-all, exactly the digests of its bucket: cap x N records instead of
+// the n x N an all-gather hands to every rank.  A slot that overflows (a bucket far above its share: an adversary's messages) raises the
+// duplicate bit of the probe word: "undecided", settled by the exact scan over the messages like any digest hit.
+__global__ void k_digest_pack_fill(uint8_t* out, size_t cap, uint32_t n_buckets) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= cap * n_buckets) return;
+  const uint32_t b = (uint32_t)(i / cap);
+  uint4 pad = make_uint4((b + 1u) % n_buckets, 0u, 0u, 0u);             // little-endian: byte 0 = the neighbour's bucket
+  reinterpret_cast<uint4*>(out)[i] = pad;
+}
+__global__ void k_digest_pack(const uint8_t* dig, size_t n, uint8_t* out, size_t cap, uint32_t n_buckets, uint32_t* counts, uint32_t* flags) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 d = reinterpret_cast<const uint4*>(dig)[i];
+  const uint32_t b = (d.x & 0xFFu) % n_buckets;
+  const uint32_t pos = atomicAdd(&counts[b], 1u);
+  if (pos >= cap) {
+    atomicOr(flags, FLAG_DUP);
+    return;
+  }
+  reinterpret_cast<uint4*>(out)[(size_t)b * cap + pos] = d;
+}
+void digest_pack(hipStream_t st, const uint8_t* dig, size_t n, uint8_t* out, size_t cap, uint32_t n_buckets, uint32_t* counts, uint32_t* flags) {
+  k_digest_pack_fill<<<nblk(cap * n_buckets, 256), 256, 0, st>>>(out, cap, n_buckets);
+  if (n) k_digest_pack<<<nblk(n, 256), 256, 0, st>>>(dig, n, out, cap, n_buckets, counts, flags);
+}
+
+void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket, uint32_t n_buckets, uint64_t seed,
+               bool unbounded) {
+  // bucketed scan: at most DUP_MAX_PROBE probes per record (a fair bucket's table is at most half full: runs of a thousand taken slots do not occur)
+  const uint32_t max_probe = n_buckets > 1 && !unbounded && mask > DUP_MAX_PROBE ? DUP_MAX_PROBE : mask;
+  k_dup_check<<<nblk(n, 256), 256, 0, st>>>(mv, n, table, mask, flags, bucket, n_buckets, max_probe, seed);
 }
 
 // alt-bn128: (lanes per message, first counter): 1@0, 4@1, 32@5, then 64 lanes per message up to counter 255.  Each

@@ -8,7 +8,10 @@ namespace bgls {
 namespace kl {
 
 // ---- k_hash.hip
-void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket = 0, uint32_t n_buckets = 1);
+void digest_pack(hipStream_t st, const uint8_t* dig, size_t n, uint8_t* out, size_t cap, uint32_t n_buckets, uint32_t* counts, uint32_t* flags);
+constexpr uint32_t DUP_MAX_PROBE = 1023;      // bucketed duplicate scan: probes per record before it reports "undecided"
+void dup_check(hipStream_t st, MsgView mv, size_t n, uint32_t* table, uint32_t mask, uint32_t* flags, uint32_t bucket = 0, uint32_t n_buckets = 1, uint64_t seed = 0,
+               bool unbounded = false);
 void msg_digest(hipStream_t st, MsgView mv, size_t n, uint8_t* out);
 void h2c_bn(hipStream_t st, MsgView mv, size_t n, uint32_t* lists, uint32_t* counters, Aff<F1<BN254>>* out, uint32_t* flags, bool lean);
 void h2c_bls(hipStream_t st, MsgView mv, size_t n, Jac<F1<BLS381>>* pts, uint32_t* kinds, Aff<F1<BLS381>>* out, bool raw);   // pts: 2n Jacobian work items

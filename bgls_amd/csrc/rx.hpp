@@ -269,6 +269,13 @@ BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
   } else {
     constexpr int T = C::RX_NL - 1;
     constexpr float QI = 1.0f / (float)(C::RX_P[T] + 1u);
+#if RX_HOST_CHECK
+    // preconditions (advice r5: they were enforced by the callers' discipline only): tight limbs, both halves below 3 p -- the quotient is read
+    // off the TOP limbs alone, in single precision, and is allowed to be 3 short, no more
+    for (int i = 0; i < T; ++i)
+      if (a.c0.v[i] > C::RX_MASK || a.c1.v[i] > C::RX_MASK) g_rx_overflow = 1;
+    if (a.c0.v[T] > 3u * C::RX_P[T] + 3u || a.c1.v[T] > 3u * C::RX_P[T] + 3u) g_rx_overflow = 1;
+#endif
     // un-normalised top limbs of xi a (+ 4 p, not counting the low limbs' 2^W each: an under-estimate): the lower limbs add less than 12 units to them
     const i32 s0 = (i32)((u32)C::XI_RE * a.c0.v[T]) - (i32)a.c1.v[T] + 4 * (i32)C::RX_P[T];
     const i32 s1 = (i32)((u32)C::XI_RE * a.c1.v[T] + a.c0.v[T]);
@@ -290,6 +297,10 @@ BGLS_HD Ux2<C> ux_mulxi(const Ux2<C>& a) {
     }
     r.c0.v[T] = (u32)((i32)((u32)C::XI_RE * a.c0.v[T] + k0 * C::RX_P[T]) + (i32)C::RX_XIG0[T] - (i32)a.c1.v[T] + (i32)c0);
     r.c1.v[T] = (u32)((i32)((u32)C::XI_RE * a.c1.v[T] + k1 * C::RX_P[T] + a.c0.v[T]) + (i32)C::RX_XIG1[T] + (i32)c1);
+#if RX_HOST_CHECK
+    // postcondition: non-negative and below 3.001 p, i.e. a top limb in [0, 3 p_top + 3]
+    if ((i32)r.c0.v[T] < 0 || (i32)r.c1.v[T] < 0 || r.c0.v[T] > 3u * C::RX_P[T] + 3u || r.c1.v[T] > 3u * C::RX_P[T] + 3u) g_rx_overflow = 1;
+#endif
   }
   return r;
 }
@@ -833,6 +844,13 @@ BGLS_HD Sx<C, SX_T> sx_quasi_center(const Sx<C, LA>& a) {
   constexpr int W = C::RX_W;
   constexpr float QI = 1.0f / ((float)C::RX_P[N - 1] + 0.5f);
   // the limbs below the top one are worth a few units of the top limb together (LA / 16 of them); p's top limb is 2^17 (BLS12-381) / 2^21 (alt-bn128) units
+#if RX_HOST_CHECK
+  // preconditions (advice r5): |value| below 2^6 p, and a top limb the single-precision conversion holds exactly
+  {
+    const i64 top = a.v[N - 1] < 0 ? -(i64)a.v[N - 1] : (i64)a.v[N - 1];
+    if (top >= (1 << 24) || top > 64 * (i64)C::RX_P[N - 1] + 64) g_rx_overflow = 1;
+  }
+#endif
   const float qf = (float)a.v[N - 1] * QI;
   const i32 q = (i32)(qf + (qf < 0.0f ? -0.5f : 0.5f));
   Sx<C, SX_T> r;
@@ -844,6 +862,12 @@ BGLS_HD Sx<C, SX_T> sx_quasi_center(const Sx<C, LA>& a) {
     c = t >> W;
   }
   r.v[N - 1] = (i32)((i64)a.v[N - 1] - (i64)q * (i64)(i32)C::RX_P[N - 1] + c);
+#if RX_HOST_CHECK
+  {          // postcondition: the centred representative, |value| below 0.51 p
+    const i64 top = r.v[N - 1] < 0 ? -(i64)r.v[N - 1] : (i64)r.v[N - 1];
+    if (2 * top > (i64)C::RX_P[N - 1] + (i64)C::RX_P[N - 1] / 32 + 64) g_rx_overflow = 1;
+  }
+#endif
   return r;
 }
 

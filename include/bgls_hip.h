@@ -240,6 +240,17 @@ int bgls_duplicate_scan_dev(const void* d_msgs, size_t msg_len, size_t msg_strid
  * as "undecided" and settle it with the exact scan over the messages, so this can cost time but never miss a duplicate. */
 int bgls_duplicate_scan_bucket_dev(const void* d_recs, size_t rec_len, size_t rec_stride, size_t n, unsigned bucket,
                                    unsigned n_buckets, void* d_flags, void* stream);
+/* The digest exchange as an all-to-all by bucket (round 6; bgls_amd/sharding.py enqueue_digest_probe(exchange="all_to_all")).  An
+ * all-gather hands all N x n digests to every rank, which then discards (N - 1) / N of them; here rank r receives only the digests it
+ * owns (first byte = r mod N).  bgls_digest_pack_dev sorts a rank's n digests (16 bytes each, as bgls_message_digests_dev writes
+ * them) into n_buckets slots of `cap` records each in d_out (n_buckets x cap x 16 bytes): slot b is what goes to rank b.  Unused
+ * records are padding that belongs to another bucket, so all chunks have one size and no counts are exchanged.  A slot that would
+ * overflow sets bit 0 of *d_flags ("undecided": settled by the exact scan, like any digest hit; cap = 1.25 x n / n_buckets + 1024 never
+ * overflows on real digests).  bgls_duplicate_scan_packed_dev is the receiving half: the exact scan of the n_slots = n_buckets x cap
+ * records a rank holds after the exchange (its own bucket's digests; the padding is skipped), table sized for all of them.
+ * Replaces nothing in the reference (one process there): containsDuplicateMessage, bgls/bgls.go:139-150, across GPUs. */
+int bgls_digest_pack_dev(const void* d_digests16, size_t n, unsigned n_buckets, size_t cap, void* d_out, void* d_flags, void* stream);
+int bgls_duplicate_scan_packed_dev(const void* d_recs16, size_t n_slots, unsigned bucket, unsigned n_buckets, void* d_flags, void* stream);
 /* 16-byte digests (the first 16 bytes of BLAKE2b-512) of n device-resident fixed-stride messages, to d_out16 (n x 16 bytes,
  * 16-byte aligned).  What the ranks of a multi-GPU verification exchange for the global containsDuplicateMessage rule
  * (bgls/bgls.go:139-150) instead of the messages themselves: no two equal digests => no two equal messages; a pair of equal

@@ -73,6 +73,7 @@ def test_exception_barrier_at_the_c_abi():
     assert lib.bgls_selftest_exception_barrier(4) == -1
     assert lib.bgls_selftest_exception_barrier(5) == -6          # a real allocation failure, not a thrown stand-in
     assert lib.bgls_selftest_exception_barrier(6) == -6          # raised on a second host thread, joined, reported
+    assert lib.bgls_selftest_exception_barrier(7) == -6 and _lib.last_error()          # selection restored by the guard (else -1); the message survives
     assert lib.bgls_selftest_exception_barrier(99) == 0
     # an absurd batch size is refused before anything is sized by it
     o = (ctypes.c_uint8 * 64)()

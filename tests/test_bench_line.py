@@ -21,16 +21,18 @@ def _canned_record(bench, name, prose=4000):
             "config": {"workload": note, "curve": name, "signers": 1 << 20, "signers_per_gpu": 1 << 20, "in_flight": 4, "parallelism": note},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_miller_s60<BN254>", "peak": 33.251234, "unit": "TMAC/s", "achieved": 15.9, "frac": 0.4781234,
                          "launch_ms": 4.6, "launches_per_step": 16, "macs_per_launch": 7.35e10, "traffic": 104857600,
-                         "traffic_detail": {"note": note, "valu_busy": 0.8191234, "lds_conflict_ratio": 0.1021234},
+                         "traffic_detail": {"note": note, "valu_busy": 0.8191234, "lds_conflict_ratio": 0.1021234, "kernel_clock_ghz": 2.3426,
+                                            "counters_from": "profiles/r6 (builder run)"},
                          "exclusive": {"kernel": "k_miller_ab64<BN254>", "launch_ms": 5.788, "achieved": 12.7, "frac": 0.3912345, "note": note},
                          "hbm_side": {"achieved": 2.7, "peak": 8000.0, "unit": "GB/s", "note": note}, "whole_path_frac": 0.52, "note": note},
             "sequential": {"ms_per_step_median": 91.0, "note": note}, "stage_ms_per_step": {"miller": 70.0}, "stage_ms_exclusive": {"miller": 84.0},
-            "cpu_baseline": {"value": 8912.3, "unit": "signer-pairs/s", "cores": 64, "kind": "port", "per_core_ms_per_pairing": 2.61, "sample": note}}
+            "cpu_baseline": {"value": 8912.3, "unit": "signer-pairs/s", "cores": 192, "host_cores": 192, "kind": "port", "per_core_ms_per_pairing": 2.61, "sample": note}}
 
 
 def test_last_line_is_compact_and_complete():
     bench = _bench()
     full = _canned_record(bench, "altbn128")
+    bench.cycle_roofline(full["roofline"])
     full.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None})
     full["records"] = {k: _canned_record(bench, "bls12") for k in
                        ("bls12_1048576", "altbn128_65536", "bls12_65536", "altbn128_1048576_prepared_keys", "bls12_1048576_prepared_keys",
@@ -51,10 +53,30 @@ def test_last_line_is_compact_and_complete():
     assert set(roof) >= {"bound", "kernel", "peak", "achieved", "frac", "launch_ms", "traffic", "unit"}
     # north_star: "evidenced by rocprof HBM GB/s and VALU-busy against gfx950 peak" -- the evidence run's counter readings ride along
     assert abs(roof["valu_busy"] - 0.8191) < 1e-3 and abs(roof["lds_conflict_ratio"] - 0.1021) < 1e-3 and roof["hbm_gbps"] == 2.7
-    assert rec["cpu_baseline"]["cores"] == 64 and rec["cpu_baseline"]["kind"] == "port" and len(rec["cpu_baseline"]["sample"]) <= 120
+    # the cycle-basis reading beside `frac`, and the label saying the counters are the evidence run's
+    pk = 16 * 1024 * 2.3426e9 / 1e12
+    assert abs(roof["peak_at_kernel_clock"] - pk) < 0.02 and abs(roof["kernel_clock_ghz"] - 2.343) < 1e-3
+    assert abs(roof["frac_cycles"] - 12.7 / pk) < 1e-3 and roof["frac_cycles"] < roof["frac"]
+    assert roof["counters_from"] == "profiles/r6 (builder run)"
+    # every host core the oracle can use, not a cap of 64
+    assert rec["cpu_baseline"]["cores"] == 192 and rec["cpu_baseline"]["host_cores"] == 192
+    assert rec["cpu_baseline"]["kind"] == "port" and len(rec["cpu_baseline"]["sample"]) <= 120
     assert len(rec["records"]) == 8
     for r in rec["records"].values():
-        assert set(r) <= {"value", "ms_per_step", "frac", "cpu"}
+        assert set(r) <= {"value", "ms_per_step", "frac", "cpu", "cpu_cores"}
+    # config 1 carries a CPU figure at its own shape (n = 64, all cores): the canned altbn128_64 record has one
+    assert rec["records"]["altbn128_64"]["cpu"] == 8912.0 and rec["records"]["altbn128_64"]["cpu_cores"] == 192
+
+
+def test_cpu_baseline_is_not_capped_at_64_threads(monkeypatch):
+    """cpu_baseline() capped its threads at 64 although SURVEY 8d says 'all host cores, count printed' and the oracle
+    takes 256.  Source rule + the helper's own arithmetic on a faked 192-core host."""
+    import inspect
+    bench = _bench()
+    src = inspect.getsource(bench.cpu_baseline)
+    assert "min(cores, 64)" not in src and "min(cores, 256)" in src
+    src_small = inspect.getsource(bench.cpu_baseline_small)
+    assert "sched_getaffinity" in src_small and "verify_aggregate" in src_small and "min(cores, n + 1)" in src_small
 
 
 def test_line_shrinks_rather_than_overflowing():

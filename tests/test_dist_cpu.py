@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import coracle
-from bgls_amd.sharding import shard_range, all_gather_bytes, gather_partials_and_flags, global_duplicate_scan
+from bgls_amd.sharding import (shard_range, all_gather_bytes, gather_partials_and_flags, global_duplicate_scan, digest_slot_records, all_to_all_bytes,
+                               enqueue_digest_probe)
 
 
 def _free_port():
@@ -266,3 +267,119 @@ def test_two_rank_multisig_gathers_partial_key_sums():
             assert ok == 1 and ok_short == 0 and same_sum and rows == 2 and width == 4 * fp, (name, rank, ok, ok_bad, ok_short, same_sum, rows, width)
             if bad_sig != bytes(2 * fp):
                 assert ok_bad == 0
+
+
+def _worker_all_to_all(rank, world, port, q):
+    """Round 6 (verdict r5 item 6): the digest exchange as an all-to-all by bucket.  `pack` and `probe` below do in Python what
+    bgls_digest_pack_dev / bgls_duplicate_scan_packed_dev do on the GPU (slots of equal size, padding that belongs to another bucket,
+    overflow = "undecided"); under test is bgls_amd.sharding: who receives what, how many bytes travel, the verdicts, and the refusals
+    that must come BEFORE the first collective."""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, ln = 96, 64
+    rnd = __import__("random").Random(4242)
+    all_msgs = [rnd.randbytes(ln) for _ in range(world * n_local)]
+    stats = {"received": 0, "own": 0, "foreign_real": 0, "overflow": 0, "exact": 0, "sent_bytes": 0}
+    forced = {}
+
+    def dig(m):
+        return forced.get(bytes(m), hashlib.blake2b(bytes(m)).digest()[:16])
+
+    def digest(m, cnt):
+        raw = bytes(m.numpy())
+        return torch.frombuffer(bytearray(b"".join(dig(raw[i * ln:(i + 1) * ln]) for i in range(cnt))), dtype=torch.uint8)
+
+    def pack(d, cnt, nb, cap):
+        raw = bytes(d.numpy())
+        slots = [[] for _ in range(nb)]
+        for i in range(cnt):
+            rec = raw[16 * i:16 * i + 16]
+            b = rec[0] % nb
+            if len(slots[b]) < cap:
+                slots[b].append(rec)
+            else:
+                stats["overflow"] += 1
+        out = b"".join(b"".join(sl) + (bytes([(b + 1) % nb]) + bytes(15)) * (cap - len(sl)) for b, sl in enumerate(slots))
+        stats["sent_bytes"] += len(out)
+        return torch.frombuffer(bytearray(out), dtype=torch.uint8)
+
+    def probe(buf, rl, count, bucket, n_buckets):
+        raw = bytes(buf.numpy())
+        recs = [raw[i * rl:(i + 1) * rl] for i in range(count)]
+        mine = [r for r in recs if r[0] % n_buckets == bucket]
+        stats["received"] += count
+        stats["own"] += len(mine)
+        stats["foreign_real"] += sum(1 for r in recs if r[0] % n_buckets != bucket and r[1:] != bytes(15))
+        return len(set(mine)) != len(mine) or stats["overflow"] > 0
+
+    def exact(buf, rl, count):
+        raw = bytes(buf.numpy())
+        items = [raw[i * rl:(i + 1) * rl] for i in range(count)]
+        stats["exact"] += 1
+        return len(set(items)) != len(items)
+
+    def run(msgs, **kw):
+        mine = b"".join(msgs[rank * n_local:(rank + 1) * n_local])
+        return global_duplicate_scan(exact, torch.frombuffer(bytearray(mine), dtype=torch.uint8), n_local, world, digest=digest, msg_len=ln,
+                                     probe=probe, rank=rank, pack=pack, **kw)
+
+    clean = run(all_msgs)
+    after_clean = dict(stats)
+    dup = list(all_msgs)
+    dup[world * n_local - 2] = dup[3]                                 # message 3 of rank 0 again at the end of the last rank's range
+    with_dup = run(dup)
+    forced[bytes(all_msgs[11])] = dig(all_msgs[n_local + 17])         # two DIFFERENT messages, one digest
+    collided = run(all_msgs)
+    forced.clear()
+    # an adversary's batch: every digest of this rank starts with the same byte -> one send slot overflows -> undecided -> exact scan -> no duplicate
+    for m in all_msgs[rank * n_local:(rank + 1) * n_local]:
+        forced[bytes(m)] = bytes([6]) + hashlib.blake2b(bytes(m)).digest()[1:16]
+    skewed = run(all_msgs, slot_records=n_local // 2 + 8)              # slots of the size a fair share needs, not the production slack
+    overflowed = stats["overflow"]
+    stats["overflow"] = 0
+    forced.clear()
+    # refusals before any collective: were they raised after the exchange had been entered, the OTHER rank would hang in it
+    errs = []
+    for bad in (dict(probe=lambda b, r, c: False), dict(rank=None)):
+        try:
+            global_duplicate_scan(exact, torch.zeros(n_local * ln, dtype=torch.uint8), n_local, world, digest=digest, msg_len=ln,
+                                  **{**dict(probe=probe, rank=rank, pack=pack), **bad})
+            errs.append(None)
+        except (TypeError, ValueError) as e:
+            errs.append(type(e).__name__)
+    try:
+        enqueue_digest_probe(digest, lambda b, r, c: None, torch.zeros(n_local * ln, dtype=torch.uint8), n_local, world, rank=rank, pack=pack)
+        errs.append(None)
+    except TypeError:
+        errs.append("TypeError")
+    # the raw exchange: chunk r of the send buffer arrives as chunk `rank` of rank r's receive buffer
+    got = all_to_all_bytes(torch.tensor([10 * rank + r for r in range(world) for _ in range(4)], dtype=torch.uint8), world)
+    q.put((rank, clean, after_clean, with_dup, collided, skewed, overflowed, stats["exact"], errs, got.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_digest_exchange_is_an_all_to_all_by_bucket():
+    world, n_local = 2, 96
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_all_to_all, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    cap = digest_slot_records(n_local, world)
+    assert cap == n_local // world + n_local // (4 * world) + 1024
+    assert sum(r[2]["own"] for r in res) == world * n_local          # every digest reached exactly one rank: its bucket's owner
+    for rank, clean, st, with_dup, collided, skewed, overflowed, exact_total, errs, got in res:
+        assert clean is None and st["exact"] == 0                    # proven duplicate-free from the digests: no message gathered
+        assert st["received"] == world * cap and st["foreign_real"] == 0       # a rank holds its own bucket and padding, nothing else
+        assert st["sent_bytes"] == world * cap * 16                  # what travels per rank: slots, not world x n_local digests
+        assert with_dup is True and collided is False                # found across the shard boundary; a collision settled as "no duplicate"
+        assert skewed is False and overflowed > 0                    # overflow -> undecided -> the exact scan decides
+        assert exact_total == 3
+        assert errs == ["TypeError", "TypeError", "TypeError"]      # refused before the first collective (no hang: the run ended)
+        assert got == [r * 10 + rank for r in range(world) for _ in range(4)]

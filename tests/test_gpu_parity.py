@@ -465,6 +465,44 @@ def test_bucketed_digest_scan_agrees_with_the_full_scan(gpu_lib):
     assert got[1] == 1 and sum(got) == 1
 
 
+def test_bucketed_digest_scan_at_adversarial_scale(gpu_lib):
+    """Advice r5 (medium): a signer can grind messages until every digest's first byte falls into ONE rank's bucket.  With 2^20 such records
+    and 16 buckets that bucket's table (sized for twice a fair share) is 4x over-subscribed: round 5's kernel walked the whole table per
+    insert -- about 10^12 probes, a hung GPU.  The scan is bounded (1024 probes, and every thread leaves once the flag is up): it must come
+    back at once with "hit" (undecided -> the exact scan), the other buckets with nothing, and a fair 2^20-digest batch must still pass."""
+    import time
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    rs = np.random.RandomState(5)
+    recs = rs.randint(0, 256, size=(n, 16), dtype=np.uint8)
+    fair = torch.from_numpy(recs.copy()).to(dev)
+    recs[:, 0] = 16 * rs.randint(0, 16, size=n).astype(np.uint8) + 5          # every first byte is 5 mod 16
+    evil = torch.from_numpy(recs).to(dev)
+    f = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def scan(t, b, nb):
+        f.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        assert gpu_lib.bgls_duplicate_scan_bucket_dev(t.data_ptr(), 16, 16, n, b, nb, f.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        return int(f.item()) & 1, time.perf_counter() - t0
+    scan(fair, 0, 16)                                    # first call: workspace allocation
+    for b in (0, 5, 15):
+        hit, dt = scan(fair, b, 16)
+        assert hit == 0 and dt < 0.25, (b, hit, dt)
+    hit, dt = scan(evil, 5, 16)
+    assert hit == 1 and dt < 0.25, (hit, dt)             # round 5: did not return
+    for b in (0, 4, 6):
+        hit, dt = scan(evil, b, 16)
+        assert hit == 0 and dt < 0.25, (b, hit, dt)
+    # the exact scan (one bucket) of the same records is unbounded by design and still exact: no duplicate among them
+    hit, dt = scan(evil, 0, 1)
+    assert hit == 0 and dt < 1.0, (hit, dt)
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The N > 1 path of bench.py end to end on real kernels: two ranks on cuda:0 exchanging over gloo
     (BGLS_BENCH_SHARE_GPU=1) -- shard ranges, global duplicate scan, partial + status all-gather, final verification and
@@ -580,3 +618,66 @@ def test_host_threads_on_their_own_contexts(gpu_lib):
         t.join()
     lib.bgls_select_context(0)
     assert not errors, errors
+
+
+def test_digest_pack_and_packed_scan(gpu_lib):
+    """Round 6: the two halves of the all-to-all digest exchange on ONE GPU.  Pack 50 000 digests for N = 2, 3, 8 ranks; every digest
+    must sit in its bucket's slot, the rest of a slot is padding of the NEXT bucket, nothing is lost or invented; the scan of a slot
+    set finds a planted pair only in its owner's bucket; a slot too small for its share raises the word."""
+    import hashlib
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    n = 50000
+    rs = np.random.RandomState(11)
+    dig = rs.randint(0, 256, size=(n, 16), dtype=np.uint8)
+    dig[:, 1] |= 1                                                    # no real record looks like padding (bytes 1..15 all zero)
+    t = torch.from_numpy(dig).to(dev)
+    for nb in (2, 3, 8):
+        cap = n // nb + n // (4 * nb) + 1024
+        out = torch.zeros(nb * cap * 16, dtype=torch.uint8, device=dev)
+        w = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert gpu_lib.bgls_digest_pack_dev(t.data_ptr(), n, nb, cap, out.data_ptr(), w.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert int(w.item()) == 0
+        o = out.cpu().numpy().reshape(nb, cap, 16)
+        seen = 0
+        for b in range(nb):
+            real = o[b][np.any(o[b][:, 1:] != 0, axis=1)]
+            pad = o[b][np.all(o[b][:, 1:] == 0, axis=1)]
+            assert np.all(real[:, 0] % nb == b) and np.all(pad[:, 0] == (b + 1) % nb)
+            want = dig[dig[:, 0] % nb == b]
+            assert sorted(map(bytes, real)) == sorted(map(bytes, want))
+            seen += len(real)
+        assert seen == n
+        # a rank's receive buffer = slot `r` of every rank's send buffer; here: the same rank's slot nb times over would plant duplicates,
+        # so build it from ONE copy of slot r and padding
+        for r in range(nb):
+            recv = torch.from_numpy(np.concatenate([o[r]] + [np.tile(np.array([(r + 1) % nb] + [0] * 15, dtype=np.uint8), (cap, 1))] * (nb - 1))).to(dev)
+            w.zero_()
+            assert gpu_lib.bgls_duplicate_scan_packed_dev(recv.data_ptr(), nb * cap, r, nb, w.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert int(w.item()) & 1 == 0, (nb, r)
+        d2 = dig.copy()
+        d2[n - 5] = d2[123]
+        t2 = torch.from_numpy(d2).to(dev)
+        assert gpu_lib.bgls_digest_pack_dev(t2.data_ptr(), n, nb, cap, out.data_ptr(), w.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        o2 = out.cpu().numpy().reshape(nb, cap, 16)
+        owner = int(d2[123, 0]) % nb
+        for r in range(nb):
+            recv = torch.from_numpy(np.ascontiguousarray(o2[r])).to(dev)
+            w.zero_()
+            assert gpu_lib.bgls_duplicate_scan_packed_dev(recv.data_ptr(), cap, r, nb, w.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert (int(w.item()) & 1) == (1 if r == owner else 0), (nb, r, owner)
+        # a slot smaller than the bucket's share: the word is raised, nothing is written past the slot
+        small = n // (2 * nb)
+        guard = torch.full((nb * small * 16 + 64,), 0xAB, dtype=torch.uint8, device=dev)
+        w.zero_()
+        assert gpu_lib.bgls_digest_pack_dev(t.data_ptr(), n, nb, small, guard.data_ptr(), w.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert int(w.item()) & 1 == 1 and bytes(guard[-64:].cpu().numpy()) == b"\xab" * 64
+    w = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert gpu_lib.bgls_digest_pack_dev(t.data_ptr(), n, 1, 10, t.data_ptr(), w.data_ptr(), None) < 0          # one bucket: nothing to exchange
+    assert gpu_lib.bgls_duplicate_scan_packed_dev(t.data_ptr(), n, 2, 2, w.data_ptr(), None) < 0
