@@ -177,19 +177,25 @@ __device__ __forceinline__ void mx_st_half(int off, bool second, const Ux<C>& a)
   }
 }
 
-// ---- consumer pieces (one output coefficient per lane); gb = the group's base
-template <class C, int NP>
-__device__ __forceinline__ void mx_publish(int gb, int j, const Ux2<C>& v, bool live) {
-  typedef MX<C, NP> K;
+// ---- consumer pieces (one output coefficient per lane); gb = the group's base.  K = the LDS layout of a group: MX<C, NP> for the Miller kernel,
+// PrepX<C> (prepared.hpp) for the prepared-key fold -- PACKED, HS, acc_off(k, wrap), line_off(e).  XI3: only the xi copies of coefficients 3..5 are
+// stored (nothing ever reads the others: every wrapped factor of a fold or a squaring is one of e_3, e_4, e_5); the Miller kernel stores all six
+// because its layout has the room and a predicated store costs what it saves.
+template <class C, class K, bool XI3 = false>
+__device__ __forceinline__ void mxk_publish(int gb, int j, const Ux2<C>& v, bool live) {
   if (live) {
     mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 0), false, v.c0);
     mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 0) + K::HS, true, v.c1);
     const Ux2<C> x = ux_mulxi<C>(v);
-    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1), false, x.c0);
-    mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1) + K::HS, true, x.c1);
+    if (!XI3 || j >= 3) {
+      mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1), false, x.c0);
+      mx_st_half<C, K::PACKED>(gb + K::acc_off(j, 1) + K::HS, true, x.c1);
+    }
   }
   wave_sync();
 }
+template <class C, int NP>
+__device__ __forceinline__ void mx_publish(int gb, int j, const Ux2<C>& v, bool live) { mxk_publish<C, MX<C, NP>>(gb, j, v, live); }
 // f <- f * line_m:  c_j = sum_t L[3m + t] * B[(j - sh[t]) mod 6] * xi^[sh[t] > j]
 template <class C, int NP>
 __device__ __forceinline__ Ux2<C> mx_fold(int gb, int m, int j) {
@@ -219,9 +225,8 @@ __device__ __forceinline__ Ux2<C> mx_fold(int gb, int m, int j) {
       });
 }
 // f <- f^2 with the symmetric terms merged (COOP_SQ_TAB)
-template <class C, int NP>
-__device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) {
-  typedef MX<C, NP> K;
+template <class C, class K>
+__device__ __forceinline__ Ux2<C> mxk_sqr(int gb, int j) {
   const unsigned row = COOP_SQ_TAB[j];
   // table entry per slot: bits 0-2 = i (7 = unused), bits 3-5 = k, bit 6 = wrap (xi copy), bit 7 = doubled
   return ux_sqr_dot<C>(
@@ -240,6 +245,8 @@ __device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) {
         return mx_ld_half<C, K::PACKED>(gb + K::acc_off(unused ? 0 : (int)((e >> 3) & 7u), unused ? 0 : (int)((e >> 6) & 1u)) + h * K::HS, h != 0);
       });
 }
+template <class C, int NP>
+__device__ __forceinline__ Ux2<C> mx_sqr(int gb, int j) { return mxk_sqr<C, MX<C, NP>>(gb, j); }
 
 // The 29-bit form's squaring (rx.hpp ux_sqr_dot3): the row's slots as two piles of two.  The split of the row is a per-lane constant, made once
 // before the step loop: pa / pb = the table bytes of pile A's / pile B's two slots (0xff = unused); bit 16 of pa = "pile A is doubled after its
@@ -267,9 +274,8 @@ __device__ __forceinline__ void mx_sq_split(unsigned row, unsigned& pa, unsigned
     pb = d[1] | (p[1] << 8);
   }
 }
-template <class C, int NP>
-__device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned pa, unsigned pb) {
-  typedef MX<C, NP> K;
+template <class C, class K>
+__device__ __forceinline__ Ux2<C> mxk_sqr3(int gb, unsigned pa, unsigned pb) {
   const bool twice = (pa >> 16) & 1u;
   auto fetch = [&](unsigned sl, int t, int side, int h) __attribute__((always_inline)) {
     const unsigned e = (sl >> (8 * t)) & 0xFFu;
@@ -286,6 +292,9 @@ __device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned pa, unsigned pb) {
   return ux_sqr_dot3<C>([&](int t, int side, int h) { return fetch(pa, t, side, h); }, [&](int t, int side, int h) { return fetch(pb, t, side, h); },
                         [&](int t) { return t == 0 && !twice; }, [&](int t) { return t == 0; }, twice);
 }
+
+template <class C, int NP>
+__device__ __forceinline__ Ux2<C> mx_sqr3(int gb, unsigned pa, unsigned pb) { return mxk_sqr3<C, MX<C, NP>>(gb, pa, pb); }
 
 // A producer lane's parked values: its own region of the workspace, NPARK slots of HS dwords (16-byte aligned), moved with
 // 16-byte accesses off ONE address register.  (A lane-interleaved layout coalesces better but needs a separate 64-bit

@@ -8,23 +8,32 @@
 // (tests compare the final GT bytes with the unprepared path).  A verification then scales A by yP and B by xP and folds
 //      D-type:  f <- f * (A yP + B xP w + w^3)          M-type:  f <- f * (1 + B xP w^2 + A yP w^3)
 // which is two Fp2 products per lane and line plus one shifted copy of f, instead of three products, and no point steps:
-// k_fold_prep is the whole Miller stage.  The same shared-accumulator structure as k_fold (10 groups x 6 lanes per wave,
-// NG pairings per squaring, no block-level synchronisation), the ratios streamed from HBM through a two-slot LDS ring.
+// k_fold_prep is the whole Miller stage.  The same shared-accumulator structure as the Miller kernel's consumer (10 groups x 6 lanes per
+// wave, NG pairings per squaring, no block-level synchronisation), the ratios streamed from HBM through a two-slot LDS ring.
+//
+// Round 6: the fold runs on the carry-free limbs of rx.hpp -- alt-bn128 on nine limbs of 29 bits, BLS12-381 on fourteen of 28 -- with the
+// Miller kernel's own consumer pieces (miller_x.hpp: two-pile Karatsuba dot products, the two-pile / symmetric squaring, the xi copies of
+// e_3..e_5 only) at THREE waves per SIMD.  Rounds 2-5 ran it on the round-2 helpers (ten 28-bit limbs with three piles at two waves per SIMD
+// on alt-bn128, 32-bit Montgomery limbs on BLS12-381): 0.41 / 0.40 of the multiplier peak.  The table holds the ratios in the fold's limb form
+// (tight, below 2 p), 12 / 16 dwords per half.
 //
 // Degenerate steps (c2 = 0: the running point T satisfies y_T^2 = 3 b' Z_T^2 or the chord through T and Q is degenerate)
 // cannot occur for honestly generated keys except with probability ~2^-254 per step; a key that hits one is reported by
 // the upload (BGLS_ERR_ENCODING) instead of being prepared wrongly.
 #pragma once
 #include "miller_kernels.hpp"
+#include "miller_x.hpp"
 
 namespace bgls {
 
-template <class C, bool R28>
+// table formats (global memory); X = the fold's number form
+template <class C>
 struct Prep {
-  static constexpr int HALF_DW = R28 ? 12 : C::L;            // one Fp of a ratio: 10 limbs padded to 12 (r28) or L limbs
+  typedef typename MxForm<C>::type X;
+  static constexpr int HALF_DW = (X::RX_NL + 3) & ~3;         // one Fp of a ratio: 9 / 14 limbs padded to whole 16-byte words (12 / 16 dwords)
   static constexpr int LINE_DW = 4 * HALF_DW;                // A.c0 A.c1 B.c0 B.c1
-  static constexpr int P_DW = R28 ? 32 : 2 * C::L + 4;       // x, y (padded halves), skip word
-  static constexpr int P_SKIP = R28 ? 24 : 2 * C::L;
+  static constexpr int P_SKIP = 2 * HALF_DW;                 // x, y (padded halves), skip word
+  static constexpr int P_DW = 2 * HALF_DW + (HALF_DW == 12 ? 8 : 4);      // 32 / 36: entries stay 16-byte aligned
   static constexpr int NSTEPS = LineTab<C, false>::NSTEPS;
   static constexpr int TMP_DW = 8 * C::L;                    // per (step, key) scratch of k_prepare: c0, c1, c2, prefix product
 };
@@ -55,29 +64,29 @@ __device__ __forceinline__ Fp2<C> ld_f2_strided(const u32* p) {
   return r;
 }
 
-// one Fp of a ratio in the table's form
-template <class C, bool R28>
+// one Fp (the library's Montgomery form) into the table's form: the fold's carry-free limbs, tight, value below 2 p
+template <class C>
 __device__ __forceinline__ void st_half(u32* p, const Fp<C>& a) {
-  if constexpr (R28) {
-    const F28 r = to_r28<C>(a);
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-    q[2] = make_uint4(r.v[8], r.v[9], 0u, 0u);
-  } else {
-    uint4* q = reinterpret_cast<uint4*>(p);
+  typedef typename MxForm<C>::type X;
+  constexpr int HD = Prep<C>::HALF_DW;
+  Fp<X> ax;
 #pragma unroll
-    for (int k = 0; k < C::L / 4; ++k) q[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
-  }
+  for (int i = 0; i < C::L; ++i) ax.v[i] = a.v[i];
+  const Ux<X> u = to_ux<X>(ax);
+  u32 w[HD];
+#pragma unroll
+  for (int i = 0; i < HD; ++i) w[i] = i < X::RX_NL ? u.v[i] : 0u;
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int k = 0; k < HD / 4; ++k) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
-
 // thread per key i < n_pad (keys i >= n: padding up to whole fold groups).  keys: resident Montgomery affine points.
 // table[(s * n_pad + i) * LINE_DW ...] <- (A, B) of step s;  kinf[i] = 1 for infinite / padding keys (their lines are 1);
 // tmp: TMP_DW dwords per (step, key) of scratch, same indexing.
-template <class C, bool R28>
+template <class C>
 __global__ void __launch_bounds__(64) k_prepare(const Aff<F2<C>>* keys, size_t n, size_t n_pad, size_t i0, size_t count, u32* table, uint8_t* kinf,
                                                 u32* tmp, uint32_t* flags) {
-  typedef Prep<C, R28> T;
+  typedef Prep<C> T;
   const size_t li = (size_t)blockIdx.x * 64 + threadIdx.x;      // keys i0 .. i0 + count of the set; tmp is indexed within the chunk
   if (li >= count) return;
   const size_t i = i0 + li;
@@ -158,17 +167,17 @@ __global__ void __launch_bounds__(64) k_prepare(const Aff<F2<C>>* keys, size_t n
     const Fp2<C> A = f2_mul<C>(ld_f2_strided<C>(t), ic);
     const Fp2<C> B = f2_mul<C>(ld_f2_strided<C>(t + 2 * C::L), ic);
     u32* o = table + ((size_t)s * n_pad + i) * T::LINE_DW;
-    st_half<C, R28>(o, A.c0);
-    st_half<C, R28>(o + T::HALF_DW, A.c1);
-    st_half<C, R28>(o + 2 * T::HALF_DW, B.c0);
-    st_half<C, R28>(o + 3 * T::HALF_DW, B.c1);
+    st_half<C>(o, A.c0);
+    st_half<C>(o + T::HALF_DW, A.c1);
+    st_half<C>(o + 2 * T::HALF_DW, B.c0);
+    st_half<C>(o + 3 * T::HALF_DW, B.c1);
   }
 }
 
 // per pairing i < n_pad: the hash point in the fold's form + the skip word (infinite hash point, infinite or padding key)
-template <class C, bool R28>
+template <class C>
 __global__ void k_prep_points(const Aff<F1<C>>* g1s, const uint8_t* kinf, size_t n, size_t n_pad, u32* ptab) {
-  typedef Prep<C, R28> T;
+  typedef Prep<C> T;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   u32* o = ptab + i * T::P_DW;
@@ -180,74 +189,54 @@ __global__ void k_prep_points(const Aff<F1<C>>* g1s, const uint8_t* kinf, size_t
     x = P.x;
     y = P.y;
   }
-  st_half<C, R28>(o, x);
-  st_half<C, R28>(o + T::HALF_DW, y);
+  st_half<C>(o, x);
+  st_half<C>(o + T::HALF_DW, y);
   o[T::P_SKIP] = skip ? 1u : 0u;
 }
 
-// ---- r28 helpers of the prepared fold -----------------------------------------------------------------------------------
-// value back below ~4 p: a tight (limbs < 2^28), top limb < 2^12.  q = floor(top * 21 / 64) never exceeds a / p
-// (p > 3.03 * 2^252, 64 / 21 = 3.0476), so a - q p >= 0; what is left has top limb <= 3 + (top - 3.0476 q) < 8.
-template <class C>
-__device__ __forceinline__ F28 r28_reduce_small(const F28& a) {
-  const u32 q = (a.v[9] * 21u) >> 6;
-  F28 z;
-  int64_t carry = 0;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const int64_t t = (int64_t)a.v[i] - (int64_t)((u64)q * C::R28_P[i]) + carry;
-    if (i < 9) {
-      z.v[i] = (u32)((u64)t & R28_MASK);
-      carry = t >> 28;
-    } else {
-      z.v[i] = (u32)t;
-    }
-  }
-  return z;
-}
-__device__ __forceinline__ F28 lds_ld28h(int off) {           // one Fp (10 limbs) at a 8-byte aligned dword offset
-  extern __shared__ u32 lds[];
-  F28 r;
-  const uint2* p = reinterpret_cast<const uint2*>(lds + off);
-#pragma unroll
-  for (int k = 0; k < 5; ++k) { const uint2 v = p[k]; r.v[2 * k] = v.x; r.v[2 * k + 1] = v.y; }
-  return r;
-}
-__device__ __forceinline__ void lds_st28h(int off, const F28& a) {
-  extern __shared__ u32 lds[];
-  uint2* p = reinterpret_cast<uint2*>(lds + off);
-#pragma unroll
-  for (int k = 0; k < 5; ++k) p[k] = make_uint2(a.v[2 * k], a.v[2 * k + 1]);
-}
-
-// LDS of one prepared-fold wave: per group the accumulator region (12 entries, {e_k, xi e_k}) + two line slots of two
-// scaled entries each
-template <class C, bool R28>
-struct PrepLds {
-  static constexpr int S2 = R28 ? R28_S2 : 2 * C::L;
-  static constexpr bool XF = !R28 && C::XI_RE == 1;
-  static constexpr int RBN = XF ? 6 : 12;
-  static constexpr int RB = 0, RL = RBN * S2;
-  static constexpr int GROUP_DW = (RBN + 2 * 2) * S2;
+// LDS of one prepared-fold wave, per group (dwords): the accumulator where the Miller kernel's consumer has it (plain e_k, the xi copies of
+// e_3..e_5 only) and two line slots of two scaled entries each in the room the unused xi copies leave.
+//   alt-bn128 (entries of 24): plain e_k at 24 k [0, 144), line entry e = 2 slot + t at 144 + 24 e [144, 240), xi e_k at 176 + 24 k [248, 320);
+//                              stride 332: 13.3 KB per wave, eleven waves per CU (LDS is handed out in 2 KB steps)
+//   BLS12-381 (entries of 28): plain e_k at 56 k, xi e_k at 28 + 56 (k - 3), line entries at 196, 252, 308, 336; stride 364: 14.6 KB per wave, eight waves per CU (two per SIMD: registers)
+template <class X>
+struct PrepX {
+  static constexpr bool PACKED = MX<X>::PACKED;
+  static constexpr int HS = MX<X>::HS, ES = MX<X>::ES;
+  static constexpr int GROUP_DW = PACKED ? 364 : 332;
   static constexpr int WAVE_BYTES = 10 * GROUP_DW * 4;
+  static __device__ __forceinline__ int acc_off(int k, int wrap) {
+    if constexpr (PACKED) return wrap ? 28 + 56 * (k - 3) : 56 * k;
+    else return 24 * k + 176 * wrap;
+  }
+  static __device__ __forceinline__ int line_off(int e) {
+    if constexpr (PACKED) return e < 3 ? 196 + 56 * e : 336;
+    else return 144 + 24 * e;
+  }
+  static_assert(!PACKED || ES == 28, "BLS12-381 entries");
+  static_assert(PACKED || ES == 24, "alt-bn128 entries");
 };
 
-// KARA (r28 form only): three-pile Karatsuba dot products at two waves per SIMD (the shipped form), or the four-pile
-// schoolbook form that fits the 168 registers of three waves per SIMD -- measured at 2^20 alt-bn128 pairings: 39.4 ms
-// against 65.2 ms (the extra wave does not pay for a third more multiplications and 259 spilled registers)
-template <class C, bool R28, bool KARA = true>
-__global__ void __launch_bounds__(64, KARA ? 2 : 3) k_fold_prep(const u32* table, const u32* ptab, size_t n_pad, int ng, Fp2<C>* out) {
-  typedef Prep<C, R28> T;
-  typedef PrepLds<C, R28> K;
-  extern __shared__ u32 lds[];
+// one wave = 10 groups x 6 lanes (lane = 10 j + g, as the Miller kernel's consumer), ng pairings per group and squaring.
+// Waves per SIMD: three on alt-bn128 (168 registers, 7 spilled); BLS12-381's two 14-limb piles, its accumulator coefficient and the prefetched
+// line leave 243 registers spilled at 168, so it runs two waves per SIMD at 256.
+template <class C>
+constexpr int prep_fold_waves() { return C::CURVE_ID == 0 ? 3 : 2; }
+template <class C>
+__global__ void __launch_bounds__(64, prep_fold_waves<C>()) k_fold_prep(const u32* table, const u32* ptab, size_t n_pad, int ng, Fp2<C>* out) {
+  typedef typename MxForm<C>::type X;
+  typedef Prep<C> T;
+  typedef PrepX<X> K;
+  constexpr int NL = X::RX_NL;
   const int lane = threadIdx.x;
   const bool live = lane < 60;
-  const int g = live ? lane / 6 : 9;
-  const int j = live ? lane % 6 : lane - 60;
+  const int cl = live ? lane : lane - 12;                      // lanes 60..63 shadow lanes 48..51
+  const int g = cl % 10;
+  const int j = cl / 10;
   const int gb = g * K::GROUP_DW;
   const size_t G = (size_t)blockIdx.x * 10 + g;                 // pairings [G * ng, (G + 1) * ng)
   const size_t step_dw = n_pad * T::LINE_DW;
-  // lanes 0..3 of a group scale one half each: j = 0, 1 -> A.c0, A.c1 (by yP), j = 2, 3 -> B.c0, B.c1 (by xP)
+  // lanes j = 0..3 of a group scale one half each: j = 0, 1 -> A.c0, A.c1 (by yP), j = 2, 3 -> B.c0, B.c1 (by xP)
   const bool scaler = live && j < 4;
   const int hsel = j & 3;
   const u32* lsrc = table + (G * (size_t)ng) * T::LINE_DW + hsel * T::HALF_DW;
@@ -256,7 +245,7 @@ __global__ void __launch_bounds__(64, KARA ? 2 : 3) k_fold_prep(const u32* table
   constexpr int NV = T::HALF_DW / 4;
   uint4 pl[NV], pp[NV];
   u32 pskip = 0;
-  auto prefetch = [&](int s2, int m2) {
+  auto prefetch = [&](int s2, int m2) __attribute__((always_inline)) {
     const u32* a = lsrc + (size_t)s2 * step_dw + (size_t)m2 * T::LINE_DW;
     const u32* b = psrc + (size_t)m2 * T::P_DW;
     if (scaler) {
@@ -267,157 +256,90 @@ __global__ void __launch_bounds__(64, KARA ? 2 : 3) k_fold_prep(const u32* table
   };
   int s = 0, slot = 0;
   prefetch(0, 0);
-  if constexpr (R28) {
-    const int rbo = gb + K::RB;
-    F28x2 fj;
-    {
-      const F28 one = r28_load<C>(C::R28_ONE);
+  Ux2<X> fj;
+  {
+    const Ux<X> one = ux_load<X>(X::RX_ONE);
 #pragma unroll
-      for (int q = 0; q < 10; ++q) { fj.c0.v[q] = j == 0 ? one.v[q] : 0u; fj.c1.v[q] = 0u; }
-    }
-    coop_publish28<C>(rbo, j, fj, live);
-    auto fold_step = [&]() {
+    for (int k = 0; k < NL; ++k) { fj.c0.v[k] = j == 0 ? one.v[k] : 0u; fj.c1.v[k] = 0u; }
+  }
+  mxk_publish<X, K, true>(gb, j, fj, live);
+  unsigned sq_d = 0, sq_p = 0;
+  if constexpr (!rx_lazy<X>) mx_sq_split(COOP_SQ_TAB[j], sq_d, sq_p);
+  // the powers of w the two scaled entries sit at: D-type l = A yP + B xP w + w^3 -> {0, 1} (the unit coefficient at w^3);
+  // M-type l = 1 + B xP w^2 + A yP w^3 -> {2, 3} (the unit coefficient at w^0)
+  auto fold_step = [&]() __attribute__((always_inline)) {
 #pragma unroll 1
-      for (int m = 0; m < ng; ++m) {
-        // scale the prefetched halves into the slot, fetch the next line
-        const u32 skip = pskip;
-        if (scaler) {
-          F28 a, b;
+    for (int m = 0; m < ng; ++m) {
+      const u32 skip = pskip;
+      if (scaler) {               // scale the prefetched half into the slot
+        Ux<X> a, b;
 #pragma unroll
-          for (int q = 0; q < 10; ++q) { a.v[q] = reinterpret_cast<const u32*>(pl)[q]; b.v[q] = reinterpret_cast<const u32*>(pp)[q]; }
-          u64 col[20];
-#pragma unroll
-          for (int q = 0; q < 20; ++q) col[q] = 0;
-          r28_acc(col, a, b);
-          lds_st28h(gb + K::RL + slot * 2 * R28_S2 + (hsel >> 1) * R28_S2 + (hsel & 1) * 10, r28_redc<C>(col));
-        }
-        wave_sync();
-        {
-          int s2 = s, m2 = m + 1;
-          if (m2 == ng) { m2 = 0; ++s2; }
-          if (s2 < T::NSTEPS) prefetch(s2, m2);
-        }
-        // c_j = e0 f_j + e1 f_{j-1} + f_{j-3}  (D-type; wrap-around factors by address)
-        const int rlo = gb + K::RL + slot * 2 * R28_S2;
-        F28x2 r;
-        if constexpr (KARA) {
-          u64 v0[20], v1[20], ss[20];
-#pragma unroll
-          for (int q = 0; q < 20; ++q) v0[q] = v1[q] = ss[q] = 0;
-#pragma unroll 1
-          for (int t = 0; t < 2; ++t) {
-            int k = j - t;
+        for (int q = 0; q < NL; ++q) { a.v[q] = reinterpret_cast<const u32*>(pl)[q]; b.v[q] = reinterpret_cast<const u32*>(pp)[q]; }
+        u64 col[2 * NL];
+        ux_acc_new<X>(col, a, b);
+        const Ux<X> r = ux_redc<X>(col);
+        // M-type: entry 0 = B xP (w^2), entry 1 = A yP (w^3);  D-type: entry 0 = A yP (w^0), entry 1 = B xP (w^1)
+        const int e = X::TWIST_D ? (hsel >> 1) : 1 - (hsel >> 1);
+        mx_st_half<X, K::PACKED>(gb + K::line_off(2 * slot + e) + (hsel & 1) * K::HS, (hsel & 1) != 0, r);
+      }
+      wave_sync();
+      {                           // fetch the next line while this one is folded
+        int s2 = s, m2 = m + 1;
+        if (m2 == ng) { m2 = 0; ++s2; }
+        if (s2 < T::NSTEPS) prefetch(s2, m2);
+      }
+      Ux2<X> r = ux_dot_k2p<X, 2, (NL <= 10)>(
+          [&](int t, int h) { return mx_ld_half<X, K::PACKED>(gb + K::line_off(2 * slot + t) + h * K::HS, h != 0); },
+          [&](int t, int h) {
+            int k = j - (X::TWIST_D ? t : t + 2);
             const int wrap = k < 0 ? 1 : 0;
             k += 6 * wrap;
-            const F28x2 a = lds_ld28(rlo + t * R28_S2);
-            const F28x2 b = lds_ld28(rbo + (2 * k + wrap) * R28_S2);
-            r28_kara_term(v0, v1, ss, a, b);
-          }
-          r = r28_kara_finish<C>(v0, v1, ss);
-        } else {
-          u64 cr[20], ci[20];
-#pragma unroll
-          for (int q = 0; q < 20; ++q) cr[q] = ci[q] = 0;
-#pragma unroll 1
-          for (int t = 0; t < 2; ++t) {
-            int k = j - t;
-            const int wrap = k < 0 ? 1 : 0;
-            k += 6 * wrap;
-            const F28x2 a = lds_ld28(rlo + t * R28_S2);
-            const F28x2 b = lds_ld28(rbo + (2 * k + wrap) * R28_S2);
-            r28_acc(cr, a.c0, b.c0);
-            r28_acc(cr, a.c1, r28_fatneg<C>(b.c1));
-            r28_acc(ci, a.c0, b.c1);
-            r28_acc(ci, a.c1, b.c0);
-          }
-          r.c0 = r28_redc<C>(cr);
-          r.c1 = r28_redc<C>(ci);
-        }
-        {
-          int k = j - 3;
-          const int wrap = k < 0 ? 1 : 0;
-          k += 6 * wrap;
-          const F28x2 u = lds_ld28(rbo + (2 * k + wrap) * R28_S2);
-#pragma unroll
-          for (int q = 0; q < 10; ++q) { r.c0.v[q] += u.c0.v[q]; r.c1.v[q] += u.c1.v[q]; }
-        }
-        r.c0 = r28_reduce_small<C>(r28_norm(r.c0));
-        r.c1 = r28_reduce_small<C>(r28_norm(r.c1));
-        if (!skip) fj = r;                                     // a skipped pairing contributes the constant line 1
-        coop_publish28<C>(rbo, j, fj, live);
-        slot ^= 1;
+            return mx_ld_half<X, K::PACKED>(gb + K::acc_off(k, wrap) + h * K::HS, h != 0);
+          });
+      // + the unit coefficient's share: f_(j-3) (xi f_(j+3) where it wraps) on the D-type twist, f_j itself on the M-type
+      Ux2<X> u;
+      if constexpr (X::TWIST_D) {
+        int k = j - 3;
+        const int wrap = k < 0 ? 1 : 0;
+        k += 6 * wrap;
+        u.c0 = mx_ld_half<X, K::PACKED>(gb + K::acc_off(k, wrap), false);
+        u.c1 = mx_ld_half<X, K::PACKED>(gb + K::acc_off(k, wrap) + K::HS, true);
+      } else {
+        u = fj;
       }
-      ++s;
-    };
+#pragma unroll
+      for (int q = 0; q < NL; ++q) { r.c0.v[q] += u.c0.v[q]; r.c1.v[q] += u.c1.v[q]; }
+      // a reduction's output (below 1.3 p) plus a published value (below 2 p, xi copies below 3.001 p / 7 p): under 8 p; back below 2 p
+      r = ux_quasi<X, X::TWIST_D ? 2 : 3, 1>(r);
+      if (!skip) fj = r;                                     // a skipped pairing contributes the constant line 1
+      mxk_publish<X, K, true>(gb, j, fj, live);
+      slot ^= 1;
+    }
+    ++s;
+  };
 #pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      fj = coop_sqr_sym28<C>(rbo, j);
-      coop_publish28<C>(rbo, j, fj, live);
-      fold_step();
-      if (C::LOOP_NAF[i] != 0) fold_step();
+  for (int i = 1; i < C::LOOP_LEN; ++i) {
+    if (i > 1) {                                             // f = 1 before the first step
+      if constexpr (rx_lazy<X>) fj = ux_quasi<X, 3, 1>(mxk_sqr<X, K>(gb, j));
+      else fj = mxk_sqr3<X, K>(gb, sq_d, sq_p);
+      mxk_publish<X, K, true>(gb, j, fj, live);
     }
     fold_step();
+    if (C::LOOP_NAF[i] != 0) fold_step();
+  }
+  if constexpr (C::CURVE_ID == 0) {
     fold_step();
-    if (live) out[G * 6 + j] = from_r28<C>(fj);
-  } else {
-    const LReg rb = {gb + K::RB, 12};
-    Fp2<C> fj = j == 0 ? f2_one<C>() : f2_zero<C>();
-    coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-    auto fold_step = [&]() {
-#pragma unroll 1
-      for (int m = 0; m < ng; ++m) {
-        const u32 skip = pskip;
-        if (scaler) {
-          Fp<C> a, b;
-#pragma unroll
-          for (int q = 0; q < C::L; ++q) { a.v[q] = reinterpret_cast<const u32*>(pl)[q]; b.v[q] = reinterpret_cast<const u32*>(pp)[q]; }
-          const Fp<C> r = fp_mul_inl<C>(a, b);
-          // M-type: entry 0 = B xP (w^2), entry 1 = A yP (w^3);  D-type: entry 0 = A yP (w^0), entry 1 = B xP (w^1)
-          const int e = C::TWIST_D ? (hsel >> 1) : 1 - (hsel >> 1);
-          u32* dst = lds + gb + K::RL + slot * 2 * K::S2 + e * K::S2 + (hsel & 1) * C::L;
-#pragma unroll
-          for (int q = 0; q < C::L / 4; ++q) reinterpret_cast<uint4*>(dst)[q] = make_uint4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
-        }
-        wave_sync();
-        {
-          int s2 = s, m2 = m + 1;
-          if (m2 == ng) { m2 = 0; ++s2; }
-          if (s2 < T::NSTEPS) prefetch(s2, m2);
-        }
-        const LReg rl = {gb + K::RL + slot * 2 * K::S2, 2};
-        Fp2<C> r;
-        if constexpr (C::TWIST_D) {
-          r = coop_dot_inl<C, 2, K::XF>(rl, 0, 1, rb, j, COOP_SH_D);           // shifts {0, 1}
-          int k = j - 3;
-          const int wrap = k < 0 ? 1 : 0;
-          k += 6 * wrap;
-          Fp2<C> u = lds_ld<C>(rb, K::XF ? k : 2 * k + wrap);
-          if constexpr (K::XF) u = f2_select<C>(wrap != 0, f2_mulxi<C>(u), u);
-          r = f2_add<C>(r, u);
-        } else {
-          r = coop_dot_inl<C, 2, K::XF>(rl, 0, 1, rb, j, COOP_SH_M + 1);       // shifts {2, 3}
-          r = f2_add<C>(r, fj);
-        }
-        if (!skip) fj = r;
-        coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-        slot ^= 1;
-      }
-      ++s;
-    };
-#pragma unroll 1
-    for (int i = 1; i < C::LOOP_LEN; ++i) {
-      fj = coop_sqr_sym_inl<C, K::XF>(rb, j);
-      coop_publish<C, K::XF>(gb + K::RB, j, fj, live);
-      fold_step();
-      if (C::LOOP_NAF[i] != 0) fold_step();
+    fold_step();
+  }
+  if (live) {
+    Fp2<X> r = {from_ux_inl<X>(fj.c0), from_ux_inl<X>(fj.c1)};
+    if constexpr (C::CURVE_ID != 0) {
+      if (j & 1) r = f2_neg<X>(r);                          // x < 0: f^(p^6), w -> -w
     }
-    if constexpr (C::CURVE_ID == 0) {
-      fold_step();
-      fold_step();
-    } else {
-      if (j & 1) fj = f2_neg<C>(fj);                      // x < 0: f^(p^6), w -> -w
-    }
-    if (live) out[G * 6 + j] = fj;
+    Fp2<C> o;
+#pragma unroll
+    for (int q = 0; q < C::L; ++q) { o.c0.v[q] = r.c0.v[q]; o.c1.v[q] = r.c1.v[q]; }
+    out[G * 6 + j] = o;
   }
 }
 
