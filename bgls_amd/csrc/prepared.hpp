@@ -309,8 +309,9 @@ __global__ void __launch_bounds__(64, prep_fold_waves<C>()) k_fold_prep(const u3
       }
 #pragma unroll
       for (int q = 0; q < NL; ++q) { r.c0.v[q] += u.c0.v[q]; r.c1.v[q] += u.c1.v[q]; }
-      // a reduction's output (below 1.3 p) plus a published value (below 2 p, xi copies below 3.001 p / 7 p): under 8 p; back below 2 p
-      r = ux_quasi<X, X::TWIST_D ? 2 : 3, 1>(r);
+      // a reduction's output (below 1.3 p) plus a published value (below 2.31 p; the D-type twist's xi copies below 3.001 p): under 4.31 p.  ONE
+      // conditional subtraction of 2 p brings it below 2.31 p again -- all that the next xi multiple (below 3 p) and the piles (below 4 p) ask for
+      r = ux_quasi<X, 1, 1>(r);
       if (!skip) fj = r;                                     // a skipped pairing contributes the constant line 1
       mxk_publish<X, K, true>(gb, j, fj, live);
       slot ^= 1;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(64, prep_fold_waves<C>()) k_fold_prep(const u3
 #pragma unroll 1
   for (int i = 1; i < C::LOOP_LEN; ++i) {
     if (i > 1) {                                             // f = 1 before the first step
-      if constexpr (rx_lazy<X>) fj = ux_quasi<X, 3, 1>(mxk_sqr<X, K>(gb, j));
+      if constexpr (rx_lazy<X>) fj = mxk_sqr<X, K>(gb, j);
       else fj = mxk_sqr3<X, K>(gb, sq_d, sq_p);
       mxk_publish<X, K, true>(gb, j, fj, live);
     }

@@ -198,6 +198,22 @@ def aggregate_2pow20(gpu_lib, cid, fp, seed):
     assert run(dup, shards, t_sig_dup, scan=True)[0] == 0         # VerifyAggregateSignature does not
     # host-buffer door, whole batch in one call
     assert lib.bgls_verify_aggregate(cid, agg, keys, B(msgs), off, n, 0) == 1
+    # the same batch against a PREPARED resident key set (round 6: the fold on the Miller kernel's carry-free limbs, 38 / 52 pairings per
+    # group and squaring at this size -- one round of resident waves; the small sets of test_gpu_keys.py all run at 6): same verdicts, and the
+    # partial product differs from the unprepared one only by factors the final exponentiation removes -- the oracle's says so
+    h = ctypes.c_uint64()
+    devs = (ctypes.c_int * 1)(0)
+    assert lib.bgls_keys_upload(cid, keys, n, devs, 1, 2, ctypes.byref(h)) == 0          # BGLS_KEYS_PREPARE
+    part = torch.zeros(gtb, dtype=torch.uint8, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.bgls_miller_product_keys_dev(h, t_sig.data_ptr(), t_msgs.data_ptr(), 64, 64, n, 1, part.data_ptr(), flags.data_ptr(), None) == 0
+    assert lib.bgls_final_verify_dev(cid, part.data_ptr(), 1, flags.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    assert coracle.final_exp(cid, bytes(part.cpu().numpy())) == bytes(gtb - 1) + b"\x01"
+    flags.zero_()
+    assert lib.bgls_miller_product_keys_dev(h, t_sig.data_ptr(), bad.data_ptr(), 64, 64, n, 1, part.data_ptr(), flags.data_ptr(), None) == 0
+    assert lib.bgls_final_verify_dev(cid, part.data_ptr(), 1, flags.data_ptr(), None) == 0
+    assert lib.bgls_keys_free(h) == 0
 
 
 def test_bls12_hash_normalisation_batches_agree(gpu_lib):
