@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(64, prep_fold_waves<C>()) k_fold_prep(const u3
         if (m2 == ng) { m2 = 0; ++s2; }
         if (s2 < T::NSTEPS) prefetch(s2, m2);
       }
+      // (ux_dot_k2q, every fetch one stage ahead, was tried here too: 63 / 92 spilled registers next to the prefetched line, 35.9 -> 32.0 M pairs/s)
       Ux2<X> r = ux_dot_k2p<X, 2, (NL <= 10)>(
           [&](int t, int h) { return mx_ld_half<X, K::PACKED>(gb + K::line_off(2 * slot + t) + h * K::HS, h != 0); },
           [&](int t, int h) {
