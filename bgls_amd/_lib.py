@@ -5,7 +5,12 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbgls_hip.so")
+# BGLS_LIB_VARIANT=legacy loads libbgls_hip_legacy.so (`make LEGACY=1`: the shipped library plus the 32-bit-limb fallback kernels that only
+# BGLS_LEGACY / BGLS_MILLER_SHAPE=5 reach) -- tests/test_gpu_legacy_paths.py and A/B runs; nothing else should set it.
+_VARIANT = os.environ.get("BGLS_LIB_VARIANT", "")
+if _VARIANT not in ("", "legacy"):
+    raise RuntimeError("bgls_amd: unknown BGLS_LIB_VARIANT %r" % _VARIANT)
+LIB_PATH = os.path.join(_HERE, "libbgls_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u64p = ctypes.POINTER(ctypes.c_uint64)

@@ -60,6 +60,21 @@ for cname, cid, fp in (("altbn128", 0, 32), ("bls12", 1, 48)):
     hs = (ctypes.c_uint8 * (ns * 2 * fp))(); assert L.bgls_hash_to_g1(cid, B(b"".join(msgs)), off, ns, hs) == 0
     res[cname + "_hash"] = all(bytes(hs)[2 * fp * i:2 * fp * (i + 1)] == coracle.hash_to_g1(cid, msgs[i]) for i in range(ns))
     res[cname + "_sign"] = all(bytes(sigs)[2 * fp * i:2 * fp * (i + 1)] == coracle.scale_point(cid, 1, coracle.hash_to_g1(cid, msgs[i]), sks[i]) for i in range(ns))
+    # a Miller stage above the latency shape (k_miller_x60 by default, k_miller_ab64 under BGLS_MILLER_SHAPE=5): bilinearity pins the value,
+    # prod e(a_i g1, b_i g2) = e((sum a_i b_i) g1, g2)
+    nb = 700
+    ka = [rnd.randrange(1, 1 << 250) for _ in range(nb)]; kbs = [rnd.randrange(1, 1 << 250) for _ in range(nb)]
+    G1 = (ctypes.c_uint8 * (2 * fp))(); G2 = (ctypes.c_uint8 * (4 * fp))()
+    assert L.bgls_generator(cid, 1, G1) == 0 and L.bgls_generator(cid, 2, G2) == 0
+    p1 = (ctypes.c_uint8 * (nb * 2 * fp))(); p2 = (ctypes.c_uint8 * (nb * 4 * fp))()
+    assert L.bgls_scale_points(cid, 1, B(bytes(G1) * nb), B(b"".join(x.to_bytes(32, "big") for x in ka)), None, nb, p1) == 0
+    assert L.bgls_scale_points(cid, 2, B(bytes(G2) * nb), B(b"".join(x.to_bytes(32, "big") for x in kbs)), None, nb, p2) == 0
+    big = (ctypes.c_uint8 * (12 * fp))(); assert L.bgls_pairing_product(cid, p1, p2, nb, big) == 0
+    order = {0: 21888242871839275222246405745257275088548364400416034343698204186575808495617, 1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}[cid]
+    ssum = sum(x * y for x, y in zip(ka, kbs)) %% order
+    one = (ctypes.c_uint8 * (2 * fp))(); assert L.bgls_scale_points(cid, 1, G1, B(ssum.to_bytes(32, "big")), None, 1, one) == 0
+    e1 = (ctypes.c_uint8 * (12 * fp))(); assert L.bgls_pairing_product(cid, one, G2, 1, e1) == 0
+    res[cname + "_bilinear_700"] = bytes(big) == bytes(e1)
 print("RESULT " + json.dumps(res))
 """
 
@@ -68,12 +83,40 @@ print("RESULT " + json.dumps(res))
                          ids=["32-bit tails and key sum", "key-sum tree as one launch per level", "32-bit G1 scalar multiplications", "six-lane reduce passes",
                               "every fallback at once", "defaults"])
 def test_replaced_kernels_still_match_the_oracle(env):
+    """Round 6: the kernels that only BGLS_LEGACY bits 1 / 2 / 4 / 8 and BGLS_MILLER_SHAPE=5 reach live in libbgls_hip_legacy.so (`make LEGACY=1`,
+    built by __graft_entry__.build()); the shipped library ignores those bits.  Every combination below runs on the legacy build; the last one
+    ("defaults") also runs on the shipped library, where -- second test below -- asking for a fallback it does not carry changes nothing."""
     golden = os.path.join(ROOT, "tests", "golden")
     code = CHILD % (ROOT, golden)
     e = dict(os.environ)
     e.update(env)
+    e["BGLS_LIB_VARIANT"] = "legacy"
+    legacy_lib = os.path.join(ROOT, "bgls_amd", "libbgls_hip_legacy.so")
+    assert os.path.exists(legacy_lib), "build it: make -C bgls_amd/csrc LEGACY=1 (or __graft_entry__.build())"
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     res = json.loads(line[7:])
     assert res and all(res.values()), res
+
+
+def test_the_shipped_library_ignores_the_fallbacks_it_does_not_carry():
+    """libbgls_hip.so has no k_final36 / k_miller_lat / k_cofactor_epilogue / k_sum_main<G2> / k_miller_ab64: BGLS_LEGACY=15 and
+    BGLS_MILLER_SHAPE=5 must leave it on its default kernels (same oracle bytes), bgls_set_miller_shape(5) must refuse, and the symbols
+    must be absent from the library."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    code = CHILD % (ROOT, golden) + """
+assert L.bgls_set_miller_shape(5, 0) < 0 and b"LEGACY" in L.bgls_last_error()
+assert L.bgls_set_miller_shape(0, 0) == 0
+"""
+    e = dict(os.environ)
+    e.update({"BGLS_LEGACY": "15", "BGLS_MILLER_SHAPE": "5"})
+    e.pop("BGLS_LIB_VARIANT", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res and all(res.values()), res
+    blob = open(os.path.join(ROOT, "bgls_amd", "libbgls_hip.so"), "rb").read()
+    legacy_blob = open(os.path.join(ROOT, "bgls_amd", "libbgls_hip_legacy.so"), "rb").read()
+    for mangled in (b"9k_final36I", b"12k_miller_latI", b"19k_cofactor_epilogueI", b"13k_miller_ab64I"):      # kernel symbols (Itanium mangling), not error texts
+        assert mangled not in blob and mangled in legacy_blob, mangled

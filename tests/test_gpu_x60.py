@@ -62,13 +62,11 @@ def test_pairing_product_equals_oracle_at_tile_boundaries(gpu_lib, curve, shape)
             o = out(12 * n_fp)
             assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o) == 0
             assert bytes(o) == want, "k_miller_x60, %s pairings per block, n = %d" % (form, n)
-        shape(5)
-        o5 = out(12 * n_fp)
-        assert gpu_lib.bgls_pairing_product(cid, B(a), B(b), n, o5) == 0
-        assert bytes(o5) == want, "32-bit kernels, n = %d" % n
+        # (the 32-bit kernel k_miller_ab64 -- shape 5 -- left the shipped library in round 6: tests/test_gpu_legacy_paths.py runs it against the
+        # same oracle on the LEGACY=1 build)
 
 
-def test_large_batches_same_bytes_as_the_32_bit_kernels(gpu_lib, curve, shape):
+def test_large_batches_same_bytes_in_every_block_form_and_role_mode(gpu_lib, curve, shape):
     cid, n_fp = curve["id"], curve["fp"]
     rnd = random.Random(77 + cid)
     n = 7000
@@ -81,10 +79,10 @@ def test_large_batches_same_bytes_as_the_32_bit_kernels(gpu_lib, curve, shape):
     g1s, g2s = out(n * 2 * n_fp), out(n * 4 * n_fp)
     assert gpu_lib.bgls_scale_points(cid, 1, B(bytes(g1) * n), B(k1), None, n, g1s) == 0
     assert gpu_lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(k2), None, n, g2s) == 0
-    shape(5)
-    ref = out(12 * n_fp)
+    shape(4, 8)                                        # reference: the default form; the VALUE is pinned by bilinearity below (and, for the 32-bit
+    ref = out(12 * n_fp)                               # kernels of the LEGACY=1 build, by tests/test_gpu_legacy_paths.py at this size)
     assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, ref) == 0
-    for mode in (8, 0, 1, 2, 9, 4, 16, 16 + 8, 16 + 1, 16 + 2 + 4):
+    for mode in (0, 1, 2, 9, 4, 16, 16 + 8, 16 + 1, 16 + 2 + 4):
         shape(4, mode)
         o = out(12 * n_fp)
         assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, o) == 0
@@ -119,7 +117,7 @@ def test_off_curve_key_is_reported(gpu_lib, curve, shape):
 def test_degenerate_point_step_is_an_encoding_error(gpu_lib, curve, shape):
     """A twist point outside G2 handed to the Miller producers WITHOUT the subgroup check (the reference cannot construct one:
     curves/bls12_381.go:196-264, curves/altbn128.go:157-179).  Where its point steps degenerate (the fixture's point of order
-    13 on BLS12-381: T = +-Q after six steps) every producer -- latency form, k_miller_x60, the 32-bit fused kernels --
+    13 on BLS12-381: T = +-Q after six steps) every producer of the shipped library -- latency form, k_miller_x60 in both block forms --
     reports BGLS_ERR_ENCODING instead of an unspecified verdict; where they do not (no on-curve point of alt-bn128's twist
     degenerates: its smallest cofactor order is 10069) the value is the oracle's Miller formula, byte for byte."""
     from tests.conftest import load_golden
@@ -131,7 +129,7 @@ def test_degenerate_point_step_is_an_encoding_error(gpu_lib, curve, shape):
         bad = bytes.fromhex(r["pt"])
         deg = r["miller_degenerates"]       # walked with the Python oracle's point steps when the fixture was made (tests/golden/make_subgroup.py)
         seen_degenerate += deg
-        for n, shapes in ((3, (0,)), (200, (4, 64, 5))):    # <= 128 pairings: k_miller_latx; above: k_miller_x60 (both block forms) / k_miller_ab64
+        for n, shapes in ((3, (0,)), (200, (4, 64))):       # <= 128 pairings: k_miller_latx; above: k_miller_x60 (both block forms)
             g1s, g2s = random_points(curve, rnd, n)
             g2s[n // 2] = bad
             a, b = b"".join(g1s), b"".join(g2s)
@@ -181,12 +179,12 @@ def test_one_round_of_64_pairing_blocks_is_the_default_for_a_lone_2_16_batch(gpu
     assert gpu_lib.bgls_scale_points(cid, 1, B(bytes(g1) * n), B(k1), None, n, g1s) == 0
     assert gpu_lib.bgls_scale_points(cid, 2, B(bytes(g2) * n), B(k2), None, n, g2s) == 0
     got = {}
-    for name, args in (("auto", (0,)), ("x60", (4, 8)), ("x64", (4, 16 + 8)), ("ab64", (5,))):
+    for name, args in (("auto", (0,)), ("x60", (4, 8)), ("x64", (4, 16 + 8))):              # (k_miller_ab64, shape 5: LEGACY=1 builds only since round 6)
         shape(*args)
         o = out(12 * n_fp)
         assert gpu_lib.bgls_pairing_product(cid, g1s, g2s, n, o) == 0, name
         got[name] = bytes(o)
-    assert got["auto"] == got["x60"] == got["x64"] == got["ab64"]
+    assert got["auto"] == got["x60"] == got["x64"]
     r = ORDER[cid]
     s = sum(int.from_bytes(k1[32 * i:32 * i + 32], "big") * int.from_bytes(k2[32 * i:32 * i + 32], "big") for i in range(n)) % r
     one = out(2 * n_fp)

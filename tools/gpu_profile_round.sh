@@ -29,6 +29,8 @@ prof multisig_1048576 --only multisig --n 1048576 --in-flight 1 --reps 1 --steps
 prof multisig_keyset_1048576 --only multisig --key-set --n 1048576 --in-flight 1 --reps 1 --steps 5 --warmup 2
 prof default_overlapped --no-cpu-baseline --no-records --reps 1 --steps 5 --warmup 2
 prof bn_small_64 --only small --n 64
+prof bn_prepared_1048576 $SEQ --n 1048576 --prepared
+prof bls_prepared_1048576 $SEQ --n 1048576 --curve bls12 --prepared
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc bn_x60 $c $SEQ --n 1048576 --steps 2 --warmup 1
   pmc bls_x60 $c $SEQ --n 1048576 --curve bls12 --steps 2 --warmup 1
