@@ -626,9 +626,62 @@ BGLS_HD Fp<C> fp_inv(const Fp<C>& a) {
 // "root^2 == y^2" acceptance test of try-and-increment (curves/hash.go:62-66) -- at a few percent of the
 // cost (shifts and subtractions only).  Works on the Montgomery residue directly: (aR/p) = (a/p) because
 // R = 2^(32L) is a perfect square.
+// Round 6: the pair shrinks by about three bits per iteration, so most iterations shift, subtract and select limbs that are zero on every
+// lane.  The loop runs in PHASES of LC = L, L - 2, .. 2 limbs: a phase ends when the top two limbs of both numbers are zero on every lane of the
+// wave that is still at work (one ballot per iteration), and the next one touches two limbs less -- same iterations, same decisions, on average
+// half the instructions (the iteration is 130 instructions at twelve limbs, 11 L + 16 in general).
+template <int L, int LC>
+BGLS_HD void fp_jacobi_phase(u32 (&a)[L], u32 (&n)[L], u32& t, bool& done) {
+  for (int guard = 0; guard < 64 * L + 64; ++guard) {   // at most ~2 * 32L rounds in all: every round removes a bit
+    if (!done) {
+      const u32 low = a[0];
+      const u32 sft = low ? (u32)__builtin_ctz(low) : 31u;
+#pragma unroll
+      for (int j = 0; j < LC - 1; ++j) a[j] = (u32)((((u64)a[j + 1] << 32) | a[j]) >> sft);
+      a[LC - 1] >>= sft;
+      const u32 n8 = n[0] & 7u;
+      t ^= (sft & 1u) & (u32)(n8 == 3u || n8 == 5u);                 // (2/n) = -1 iff n = 3,5 mod 8
+      const bool odd = (a[0] & 1u) != 0;
+      u32 d[LC], e[LC];
+      u32 bw = 0, bw2 = 0;
+#pragma unroll
+      for (int j = 0; j < LC; ++j) d[j] = subb(a[j], n[j], bw);       // a - n
+#pragma unroll
+      for (int j = 0; j < LC; ++j) e[j] = subb(n[j], a[j], bw2);      // n - a
+      const bool lt = bw != 0;
+      const bool swp = odd && lt;
+      t ^= (u32)(swp && (a[0] & 3u) == 3u && (n[0] & 3u) == 3u);     // quadratic reciprocity
+      u32 z = 0;
+#pragma unroll
+      for (int j = 0; j < LC; ++j) {
+        const u32 na = odd ? (lt ? e[j] : d[j]) : a[j];
+        n[j] = swp ? a[j] : n[j];
+        a[j] = na;
+        z |= na;
+      }
+      if (z == 0) done = true;
+    }
+    bool again = !done, shrink = false;
+    if constexpr (LC > 2) shrink = !done && ((a[LC - 1] | a[LC - 2] | n[LC - 1] | n[LC - 2]) != 0);      // this lane still needs LC limbs
+#if defined(__HIP_DEVICE_COMPILE__)
+    again = __ballot(again) != 0;
+    if constexpr (LC > 2) shrink = __ballot(shrink) != 0;
+#endif
+    if (!again) return;
+    if constexpr (LC > 2) {
+      if (!shrink) return;            // every lane at work fits LC - 2 limbs: the caller goes on there
+    }
+  }
+}
+template <int L, int LC>
+BGLS_HD void fp_jacobi_phases(u32 (&a)[L], u32 (&n)[L], u32& t, bool& done) {
+  fp_jacobi_phase<L, LC>(a, n, t, done);
+  if constexpr (LC > 2) fp_jacobi_phases<L, LC - 2>(a, n, t, done);
+}
 template <class C>
 BGLS_FN int fp_jacobi(const Fp<C>& x) {
   constexpr int L = C::L;
+  static_assert(L % 2 == 0, "limb pairs");
   u32 a[L], n[L];
   u32 nz = 0;
 #pragma unroll
@@ -637,39 +690,13 @@ BGLS_FN int fp_jacobi(const Fp<C>& x) {
     n[j] = C::P[j];
     nz |= a[j];
   }
-  if (nz == 0) return 0;
   u32 t = 0;                                  // sign: 1 means -1
   // One uniform iteration = strip up to 31 factors of two from a, then (if a became odd) order the pair,
   // apply reciprocity and subtract -- all with selects, so the lanes of a wave do not serialise on
-  // data-dependent branches.
-  for (int guard = 0; guard < 64 * L + 64; ++guard) {   // at most ~2 * 32L rounds: every round removes a bit
-    const u32 low = a[0];
-    const u32 sft = low ? (u32)__builtin_ctz(low) : 31u;
-#pragma unroll
-    for (int j = 0; j < L - 1; ++j) a[j] = (u32)((((u64)a[j + 1] << 32) | a[j]) >> sft);
-    a[L - 1] >>= sft;
-    const u32 n8 = n[0] & 7u;
-    t ^= (sft & 1u) & (u32)(n8 == 3u || n8 == 5u);                 // (2/n) = -1 iff n = 3,5 mod 8
-    const bool odd = (a[0] & 1u) != 0;
-    u32 d[L], e[L];
-    u32 bw = 0, bw2 = 0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) d[j] = subb(a[j], n[j], bw);       // a - n
-#pragma unroll
-    for (int j = 0; j < L; ++j) e[j] = subb(n[j], a[j], bw2);      // n - a
-    const bool lt = bw != 0;
-    const bool swp = odd && lt;
-    t ^= (u32)(swp && (a[0] & 3u) == 3u && (n[0] & 3u) == 3u);     // quadratic reciprocity
-    u32 z = 0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const u32 na = odd ? (lt ? e[j] : d[j]) : a[j];
-      n[j] = swp ? a[j] : n[j];
-      a[j] = na;
-      z |= na;
-    }
-    if (z == 0) break;
-  }
+  // data-dependent branches.  A lane whose input is zero sits the loop out.
+  bool done = nz == 0;
+  fp_jacobi_phases<L, L>(a, n, t, done);
+  if (nz == 0) return 0;
   u32 one = n[0] ^ 1u;
 #pragma unroll
   for (int j = 1; j < L; ++j) one |= n[j];
