@@ -10,7 +10,7 @@ L = _lib.load(); assert L.bgls_init(0) == 0
 B = lambda b: (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if b else b"\0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(time.time()))
-t0 = time.time(); runs = 0; oracle_checks = 0; multis = 0
+t0 = time.time(); runs = 0; oracle_checks = 0; multis = 0; prepared_checks = 0
 
 
 def offsets(msgs):
@@ -51,6 +51,16 @@ while time.time() - t0 < budget:
         dup = list(msgs); dup[-1] = dup[0]
         r = L.bgls_verify_aggregate(cid, agg, keys, B(b"".join(dup)), offsets(dup), n, 0) if n > 1 else 0
     assert r == 0, ("corruption accepted", cid, n, mlen, kind)
+    # ---- the same instance against a resident key set, plain and PREPARED (round 6: the fold on the Miller kernel's carry-free limbs)
+    if runs % 4 == 1:
+        for flags in (1, 3):                  # BGLS_KEYS_CHECK, + BGLS_KEYS_PREPARE
+            h = ctypes.c_uint64()
+            assert L.bgls_keys_upload(cid, keys, n, (ctypes.c_int * 1)(0), 1, flags, ctypes.byref(h)) == 0
+            assert L.bgls_verify_aggregate_h(h, agg, B(blob), off, n, 0) == 1, ("valid rejected by the key set", cid, n, flags)
+            bad2 = bytearray(blob); bad2[rnd.randrange(len(bad2))] ^= 1 << rnd.randrange(8)
+            assert L.bgls_verify_aggregate_h(h, agg, B(bytes(bad2)), off, n, 1) == 0, ("corruption accepted by the key set", cid, n, flags)
+            assert L.bgls_keys_free(h) == 0
+        prepared_checks += 1
     if n <= 40:
         assert coracle.verify_aggregate(cid, bytes(agg), bytes(keys), msgs, threads=8) == 1
         oracle_checks += 1
@@ -100,5 +110,5 @@ while time.time() - t0 < budget:
         msgs_b[0] = rnd.randbytes(24)
         assert L.bgls_verify_multi_batch(cid, B(b"".join(sigs_b)), B(b"".join(sets)), koff, nsets, B(b"".join(msgs_b)), offsets(msgs_b), 1) == 0
         multis += 1
-print("multi-signature instances:", multis)
+print("multi-signature instances:", multis, " key-set instances (plain + prepared):", prepared_checks)
 print("soak ok: %d instances (%d also checked by the oracle) in %.0f s" % (runs, oracle_checks, time.time() - t0))
