@@ -25,6 +25,25 @@ struct ByteSrc {       // logical byte string: pre[0..npre) || msg[0..len) || su
     pos -= len;
     return suf[pos & 3];
   }
+  // eight logical bytes from pos on as a little-endian word; bytes at and beyond `total` read as zero.  Round 6: a word that lies wholly inside
+  // the message is ONE 8-byte load (unaligned addresses are served by the hardware) -- the absorb loops used to fetch every byte on its own,
+  // 65 dependent single-byte loads per 64-byte message and hash, and the try-and-increment rounds ran at the pace of those loads, not of
+  // their arithmetic.  Words that touch the prefix, the suffix or the end of the input take the byte path.
+  BGLS_HD u64 le64(size_t pos, size_t total) const {
+    if (pos >= (size_t)npre && pos + 8 <= (size_t)npre + len) {
+      u64 w;
+      __builtin_memcpy(&w, msg + (pos - (size_t)npre), 8);
+      return w;
+    }
+    u64 w = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const size_t q = pos + b;
+      const u32 byte = q < total ? at(q) : 0u;
+      w |= (u64)byte << (8 * b);
+    }
+    return w;
+  }
 };
 
 BGLS_HD u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
@@ -44,7 +63,9 @@ BGLS_TABLE u64 KECCAK_RC[24] = {
     0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
     0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
 
-inline BGLS_FN void keccak_f1600(u64 (&st)[25]) {
+// (round 6: inlined into keccak256_legacy -- as a call it took its 25 lanes by reference, i.e. through the stack, and every round read and
+// wrote them in scratch memory)
+BGLS_HD void keccak_f1600(u64 (&st)[25]) {
   constexpr int rotc[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
   constexpr int piln[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
   for (int round = 0; round < 24; ++round) {
@@ -89,14 +110,10 @@ inline BGLS_FN void keccak256_legacy(const ByteSrc& src, u32 (&out_be)[8]) {
     const bool last = (blk + 1 == nblk);
 #pragma unroll
     for (int i = 0; i < 17; ++i) {
-      u64 w = 0;
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        size_t pos = blk * RATE + 8 * i + b;
-        u32 byte = pos < total ? src.at(pos) : (pos == total ? 0x01u : 0u);
-        if (last && i == 16 && b == 7) byte ^= 0x80u;
-        w |= (u64)byte << (8 * b);
-      }
+      const size_t pos = blk * RATE + 8 * i;
+      u64 w = src.le64(pos, total);
+      if (total >= pos && total < pos + 8) w |= (u64)0x01u << (8 * (total - pos));      // the legacy domain byte right behind the input
+      if (last && i == 16) w ^= (u64)0x80u << 56;
       st[i] ^= w;
     }
     keccak_f1600(st);
@@ -132,7 +149,7 @@ BGLS_HD void blake2b_g(u64 (&v)[16], int a, int b, int c, int d, u64 x, u64 y) {
 }
 
 // one compression (RFC 7693 3.2): h <- F(h, m, t, last)
-inline BGLS_FN void blake2b_compress(u64 (&h)[8], const u64 (&m)[16], u64 t, bool last) {
+BGLS_HD void blake2b_compress(u64 (&h)[8], const u64 (&m)[16], u64 t, bool last) {
   u64 v[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -166,16 +183,7 @@ inline BGLS_FN void blake2b512(const ByteSrc& src, u32 (&out_be)[16]) {
   const size_t nblk = total == 0 ? 1 : (total + 127) / 128;
   for (size_t blk = 0; blk < nblk; ++blk) {
     u64 m[16];
-    for (int i = 0; i < 16; ++i) {
-      u64 w = 0;
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        size_t pos = blk * 128 + 8 * i + b;
-        u32 byte = pos < total ? src.at(pos) : 0u;
-        w |= (u64)byte << (8 * b);
-      }
-      m[i] = w;
-    }
+    for (int i = 0; i < 16; ++i) m[i] = src.le64(blk * 128 + 8 * (size_t)i, total);
     const bool last = (blk + 1 == nblk);
     blake2b_compress(h, m, last ? (u64)total : (u64)(blk + 1) * 128, last);
   }
