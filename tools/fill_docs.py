@@ -57,12 +57,13 @@ table = ("| Record | value | ms / step | dominant kernel, exclusive `frac` (algo
          "\n\nCPU beside it (`cpu_baseline`, the C oracle in the reference's parallel shape on the GPU box's host): %s pairs/s alt-bn128 on %s threads of %s host cores (%s ms per pairing on one core)."
          % (f(cpu.get("value", 0), 0), cpu.get("cores"), cpu.get("host_cores"), f(cpu.get("per_core_ms_per_pairing", 0))) +
          "  GPU tier: `profiles/r6/pytest_gpu.log`.")
-v = {"R6_TABLE": table, "R6_BN": f(d["value"] / 1e6, 1), "R6_BLS": f(b["value"] / 1e6, 1), "R6_PBN": f(pa["value"] / 1e6, 1), "R6_PBLS": f(pb["value"] / 1e6, 1)}
-for path in ("DESIGN.md", "README.md"):
-    s = open(path).read()
-    for k in sorted(v, key=len, reverse=True):
-        s = s.replace(k, v[k])
-    left = sorted(set(re.findall(r"R6_[A-Z0-9_]+", s)))
-    print(path, "placeholders left:", left)
-    if "--check" not in sys.argv:
-        open(path, "w").write(s)
+# idempotent: the generated pieces sit between markers and are replaced as a whole on every run
+s = open("DESIGN.md").read()
+s = re.sub(r"<!-- R6TAB_BEGIN \(tools/fill_docs.py\) -->.*?<!-- R6TAB_END -->", lambda m: "<!-- R6TAB_BEGIN (tools/fill_docs.py) -->\n" + table + "\n<!-- R6TAB_END -->", s, flags=re.S)
+r = open("README.md").read()
+r = re.sub(r"<!--R6H-->.*?<!--/R6H-->", "<!--R6H-->**%s M signer-pairs/s** alt-bn128 and **%s M** BLS12-381 at 2²⁰ signers<!--/R6H-->" % (f(d["value"] / 1e6, 1), f(b["value"] / 1e6, 1)), r, flags=re.S)
+r = re.sub(r"<!--R6P-->.*?<!--/R6P-->", "<!--R6P-->**prepared key sets %s M / %s M**<!--/R6P-->" % (f(pa["value"] / 1e6, 1), f(pb["value"] / 1e6, 1)), r, flags=re.S)
+if "--check" not in sys.argv:
+    open("DESIGN.md", "w").write(s)
+    open("README.md", "w").write(r)
+print("DESIGN.md / README.md refreshed from gpurun_out/%s" % tag)
