@@ -70,7 +70,7 @@ __global__ void k_dup_check(MsgView mv, size_t n, uint32_t* table, uint32_t mask
 // successful counter wins (= what the sequential loop would have found), failures are appended to
 // the next round's work list.  Counters 0..255 are covered by the fixed schedule in h2c_bn().
 template <int LPM>
-__global__ void __launch_bounds__(64) k_h2c_bn_round(MsgView mv, size_t n, const uint32_t* list_in, const uint32_t* count_in,
+__global__ void __launch_bounds__(64, 3) k_h2c_bn_round(MsgView mv, size_t n, const uint32_t* list_in, const uint32_t* count_in,
                                                      uint32_t c0, uint32_t* list_out, uint32_t* count_out, int last,
                                                      Aff<F1<BN254>>* out, uint32_t* flags) {
   typedef BN254 C;
@@ -143,7 +143,7 @@ __device__ __forceinline__ Fp<C> rx_sqrt_pow(const Fp<C>& a, i32* tab) {
 }
 
 // second half of the Legendre-symbol rounds: y = sqrt(x^3+3) with the reference's sign rule, once per message
-__global__ void __launch_bounds__(64) k_h2c_bn_finish(MsgView mv, size_t n, Aff<F1<BN254>>* out) {
+__global__ void __launch_bounds__(64, 3) k_h2c_bn_finish(MsgView mv, size_t n, Aff<F1<BN254>>* out) {
   typedef BN254 C;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -169,7 +169,7 @@ extern "C" int bgls_dbg_h2c_dump(unsigned long long* o) { return (int)hipMemcpyF
 #else
 #define H2C_T(k) do { } while (0)
 #endif
-__global__ void __launch_bounds__(64) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
+__global__ void __launch_bounds__(64, 3) k_h2c_bn_wide(MsgView mv, size_t n, Aff<F1<BN254>>* out, uint32_t* flags) {
   typedef BN254 C;
   const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
   const size_t i = (size_t)blockIdx.x * 4 + grp;
