@@ -104,9 +104,8 @@ BGLS_HD bool fp_plain_parity(const Fp<C>& a) {
   return b2 != 0;
 }
 
-// t (plain, reduced) for tag k in {0,1}
-inline BGLS_FN Fp<BLS381> bls_h2c_t(const uint8_t* msg, size_t len, int k, Fp<BLS381>& t_mont) {
-  typedef BLS381 C;
+// BLAKE2b-512(msg || "G1_" || k), k in {0,1}: the sixteen digest words, d[0] the most significant (curves/hash.go:97-107)
+inline BGLS_FN void bls_h2c_digest(const uint8_t* msg, size_t len, int k, u32 (&d)[16]) {
   ByteSrc src;
   src.msg = msg;
   src.len = len;
@@ -117,8 +116,13 @@ inline BGLS_FN Fp<BLS381> bls_h2c_t(const uint8_t* msg, size_t len, int k, Fp<BL
   src.suf[2] = '_';
   src.suf[3] = (uint8_t)('0' + k);
   src.nsuf = 4;
-  u32 d[16];
   blake2b512(src, d);
+}
+// t (plain, reduced) for tag k in {0,1}
+inline BGLS_FN Fp<BLS381> bls_h2c_t(const uint8_t* msg, size_t len, int k, Fp<BLS381>& t_mont) {
+  typedef BLS381 C;
+  u32 d[16];
+  bls_h2c_digest(msg, len, k, d);
   Fp<C> lo, hi = fp_zero<C>();
 #pragma unroll
   for (int j = 0; j < 12; ++j) lo.v[j] = d[15 - j];

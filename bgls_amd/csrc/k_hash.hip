@@ -6,6 +6,7 @@
 #include "launch.hpp"
 #include "rx_pow.hpp"
 #include "rx_jac1.hpp"
+#include "h2c_x.hpp"
 
 using namespace bgls;
 
@@ -229,54 +230,24 @@ __global__ void __launch_bounds__(64, 3) k_h2c_bn_wide(MsgView mv, size_t n, Aff
   H2C_T(6);
 }
 
-// BLS12-381: one work item per (message, tag); candidates chosen by Legendre symbols (isQuadRes,
-// curves/hash.go:254-265), then exactly one square-root exponentiation -- and NO inversion.  The reference computes the
-// three Shallue-van de Woestijne candidates through 1 / (u v), u = t^2 + 1 + b, v = 3 t^2 (curves/hash.go:97-167); they
-// are the fractions
-//     x0 = (Z u - sqrt(-3) t^2) / u,    x1 = -x0 - 1 = (-N0 - u) / u,    x2 = 1 - u^2 / v = (v - u^2) / v,
-// and for x = N / D:  g(x) = x^3 + b = G / D^3 with G = N^3 + b D^3, so that
-//     g(x) is a square  <=>  chi(G D) >= 0                         (D^4 is a square; g = 0 <=> G = 0, which counts as one),
-//     sqrt(G / D^3) = G D^3 (G D^9)^((p-3)/4)                      (p = 3 mod 4; either root: the parity rule picks the sign),
-// and the point leaves as Jacobian (X, Y, Z) = (N D, y D^3, D).  The affine x and y are the reference's field elements (x is
-// the same fraction, y the root with the parity of t), so the hash point, normalised once per message by k_bls_combine,
-// has the same bytes; the binary-Euclid inversion this replaces was 40 % of the kernel.
-__global__ void __launch_bounds__(64) k_bls_sw_jacobi(MsgView mv, size_t n_items, Jac<F1<BLS381>>* pts, uint32_t* kinds) {
+// BLS12-381: one work item per (message, tag); the Shallue-van de Woestijne candidates as fractions, chosen by Legendre symbols, one square-root
+// exponentiation, no inversion, all on the carry-free limbs: h2c_x.hpp (bls_sw_jac_x), which the CPU tier runs as well.
+__global__ void __launch_bounds__(64, 3) k_bls_sw_jacobi(MsgView mv, size_t n_items, Jac<F1<BLS381>>* pts, uint32_t* kinds) {
   typedef BLS381 C;
+  constexpr int N = C::RX_NL;
   size_t item = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   const size_t msg = item >> 1;
-  Fp<C> tm;
-  Fp<C> t = bls_h2c_t(mv.ptr(msg), mv.size(msg), (int)(item & 1), tm);
-  uint32_t kind = H2C_SW;
-  if (fp_is_zero<C>(t)) kind = H2C_INF;
-  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) kind = H2C_PLUS_G1;
-  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) kind = H2C_MINUS_G1;
-  kinds[item] = kind;
-  if (kind != H2C_SW) return;
-  const Fp<C> b = fp_load<C>(C::B);
-  const Fp<C> t2 = fp_sqr<C>(tm);
-  const Fp<C> u = fp_add<C>(fp_add<C>(t2, fp_one<C>()), b);
-  const Fp<C> v = fp_mul3<C>(t2);
-  const Fp<C> N0 = fp_sub<C>(fp_mul<C>(fp_load<C>(C::Z_SW), u), fp_mul<C>(fp_load<C>(C::SQRT_M3), t2));
-  Fp<C> N = N0, D = u;
-  Fp<C> D3 = fp_mul<C>(fp_sqr<C>(D), D);
-  const Fp<C> bD3 = fp_mul<C>(b, D3);
-  Fp<C> G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), bD3);
-  if (fp_jacobi<C>(fp_mul<C>(G, D)) < 0) {
-    N = fp_sub<C>(fp_neg<C>(N0), u);
-    G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), bD3);
-    if (fp_jacobi<C>(fp_mul<C>(G, D)) < 0) {
-      D = v;
-      N = fp_sub<C>(v, fp_sqr<C>(u));
-      D3 = fp_mul<C>(fp_sqr<C>(D), D);
-      G = fp_add<C>(fp_mul<C>(fp_sqr<C>(N), N), fp_mul<C>(b, D3));
-    }
-  }
-  const Fp<C> D9 = fp_mul<C>(fp_sqr<C>(D3), D3);
+  u32 d[16];
+  bls_h2c_digest(mv.ptr(msg), mv.size(msg), (int)(item & 1), d);
   __shared__ i32 tab[rxp_lds_words<C>()];
-  Fp<C> y = fp_mul<C>(fp_mul<C>(rx_sqrt_pow<C, true>(fp_mul<C>(G, D9), tab), G), D3);   // exponent (p - 3) / 4
-  if (fp_plain_parity<C>(fp_from_mont<C>(y)) != fp_plain_parity<C>(t)) y = fp_neg<C>(y);
-  pts[item] = {fp_mul<C>(N, D), fp_mul<C>(y, D3), D};
+  const int lane = threadIdx.x & 63;
+  auto ld = [&](int e, int i) { return tab[(e * N + i) * 64 + lane]; };
+  auto st = [&](int e, int i, i32 w) { tab[(e * N + i) * 64 + lane] = w; };
+  Jac<F1<C>> pt;
+  const uint32_t kind = bls_sw_jac_x<RXP_W, rxp_e0reg<C>()>(d, pt, ld, st);
+  kinds[item] = kind;
+  if (kind == H2C_SW) pts[item] = pt;
 }
 
 // per message: h * (sw_0 + sw_1) + special contributions, to affine.  The sum is normalised once (one

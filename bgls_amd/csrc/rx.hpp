@@ -955,6 +955,43 @@ BGLS_HD Sx<C, SX_T> sx_from_plain(const Fp<C>& y) {
   return sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int i) { return s[i]; });
 }
 
+// tight, non-negative, value < 4 p  ->  the canonical residue in [0, p) as a plain integer in the library's 32-bit words (no multiplication:
+// repack, subtract 2 p and p where possible).  With RX_TOM folded into the last carry-free product this IS the library's Montgomery residue.
+template <class C>
+BGLS_HD Fp<C> ux_to_words(const Ux<C>& a) {
+  constexpr int N = C::RX_NL;
+  constexpr int L = C::L;
+  u32 w[L + 1];
+#pragma unroll
+  for (int k = 0; k <= L; ++k) {
+    const int lo = 32 * k;
+    const int i = lo / C::RX_W, r = lo % C::RX_W;
+    u64 acc = 0;
+    if (i < N) acc = (u64)a.v[i] >> r;
+    int have = C::RX_W - r;
+    if (i + 1 < N) { acc |= (u64)a.v[i + 1] << have; have += C::RX_W; }
+    if (have < 32 && i + 2 < N) acc |= (u64)a.v[i + 2] << have;
+    w[k] = (u32)acc;
+  }
+#pragma unroll
+  for (int sh = 1; sh >= 0; --sh) {
+    u32 d[L + 1];
+    u32 bw = 0;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) {
+      const u32 pk = (k < L ? (C::P[k] << sh) : 0u) | ((sh && k >= 1) ? (C::P[k - 1] >> (32 - sh)) : 0u);
+      d[k] = subb(w[k], pk, bw);
+    }
+    const u32 keep = bw ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k <= L; ++k) w[k] = (d[k] & keep) | (w[k] & ~keep);
+  }
+  Fp<C> y;
+#pragma unroll
+  for (int k = 0; k < L; ++k) y.v[k] = w[k];
+  return y;
+}
+
 // x R' (tight, value < 4 p) -> x R in the library's form, everything expanded in place (no call, no stack: the Miller kernel's
 // epilogue must not drag a scratch frame along)
 template <class C>

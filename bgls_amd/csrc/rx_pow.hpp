@@ -76,6 +76,18 @@ BGLS_HD Sx<C, SX_T> sx_mul(const Sx<C, SX_T>& a, const Sx<C, SX_T>& b) {
   return sx_montr<C, 1, SX_T * SX_T>(cols, [&](int, int i) { return b.v[i]; });
 }
 
+// a (tight, value in (-p, 4 p)) / R' as the canonical plain integer in 32-bit words: the reduction rows alone (a product by one without the product)
+template <class C>
+BGLS_HD Fp<C> sx_over_r_words(const Sx<C, SX_T>& a) {
+  constexpr int N = C::RX_NL;
+  i64 t[2 * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = a.v[i];
+#pragma unroll
+  for (int i = N; i < 2 * N; ++i) t[i] = 0;
+  return ux_to_words<C>(sx_to_ux_p<C>(sx_redc_cols<C>(t)));
+}
+
 // a^e, e = sum word(k) 2^(32 k) over NBITS bits (public, the same for every lane), a tight with value in [0, 2p).
 // ld(e, i) / st(e, i, v): limb i of table entry e (entry e holds a^(2 e + 1)), 2^(W-1) entries.  Result tight, value in [0, 1.01 p).
 template <class C, int W, int NBITS, class Word, class Ld, class St>

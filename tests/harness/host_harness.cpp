@@ -11,6 +11,7 @@
 #include "../../bgls_amd/csrc/r28.hpp"
 #include "../../bgls_amd/csrc/rx_pair.hpp"
 #include "../../bgls_amd/csrc/rx_pow.hpp"
+#include "../../bgls_amd/csrc/h2c_x.hpp"
 
 // The file compiles as ONE translation unit (no HT_PART: the sanitizer build includes it whole) or as four parts compiled in parallel and linked
 // together (-DHT_PART=0..3; tests/conftest.py, __graft_entry__.py): the single unit takes five minutes of an -O1 compile, the parts under two.
@@ -443,6 +444,34 @@ static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
   if (g_rx_overflow) return -3;
   for (int i = 0; i < N; ++i) if (r3.v[i] < 0 || r4.v[i] < 0 || (i + 1 < N && ((u32)r3.v[i] > C::RX_MASK || (u32)r4.v[i] > C::RX_MASK))) return -2;
   return (fp_eq<C>(back(r3), want) ? 0 : 1) + (fp_eq<C>(back(r4), want) ? 0 : 2);
+}
+// h2c_x.hpp: one Shallue-van de Woestijne work item on the carry-free limbs (what k_bls_sw_jacobi runs per lane) against h2c.hpp's 32-bit form of
+// curves/hash.go:97-167.  out: the affine point (96 bytes) of the carry-free path.  Returns the kind (0..3) when both agree, -1 on a different
+// kind, -2 on a different point, -3 on a column overflow.
+extern "C" int ht_bls_sw_x(const uint8_t* msg, size_t len, int k, uint8_t* out) {
+  typedef BLS381 C;
+  g_rx_overflow = 0;
+  u32 d[16];
+  bls_h2c_digest(msg, len, k, d);
+  static thread_local i32 tab[4 * C::RX_NL];
+  auto ld = [&](int e, int i) { return tab[e * C::RX_NL + i]; };
+  auto st = [&](int e, int i, i32 v) { tab[e * C::RX_NL + i] = v; };
+  Jac<F1<C>> pt;
+  const u32 kind = bls_sw_jac_x<3, true>(d, pt, ld, st);
+  if (g_rx_overflow) return -3;
+  Fp<C> tm;
+  const Fp<C> t = bls_h2c_t(msg, len, k, tm);
+  u32 want = H2C_SW;
+  if (fp_is_zero<C>(t)) want = H2C_INF;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) want = H2C_PLUS_G1;
+  else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT2))) want = H2C_MINUS_G1;
+  if (kind != want) return -1;
+  if (kind != H2C_SW) return (int)kind;
+  const Aff<F1<C>> ref = bls_sw_encode(tm, fp_plain_parity<C>(t));
+  const Aff<F1<C>> got = jac_to_aff<F1<C>>(pt);
+  g1_to_bytes<C>(out, got);
+  if (got.inf != ref.inf || !fp_eq<C>(got.x, ref.x) || !fp_eq<C>(got.y, ref.y)) return -2;
+  return (int)kind;
 }
 extern "C" int ht_rx_pow(int curve, int op, uint8_t* bytes, i32* limbs) {
   return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : (curve == 2 ? rx_pow<BN254W>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs));

@@ -350,3 +350,21 @@ def test_29bit_form_sqrt_powers(host_harness):
             rc = host_harness.ht_rx_pow(2, op, buf, None)
             assert rc == 0, (op, x, rc)
             assert int.from_bytes(bytes(buf), "big") == pow(x, e, p)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6
+# k_bls_sw_jacobi's work item on the carry-free limbs (bgls_amd/csrc/h2c_x.hpp): the same header compiled for the host, every column accumulation
+# checked, against h2c.hpp's 32-bit form of curves/hash.go:97-167 (which the reference's 11 KATs pin through ht_hash_to_g1).
+def test_bls_sw_item_on_carry_free_limbs(host_harness):
+    host_harness.ht_bls_sw_x.restype = ctypes.c_int
+    host_harness.ht_bls_sw_x.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
+    rnd = random.Random(606)
+    msgs = [b"", b"a", b"abc", bytes(range(200))] + [rnd.randbytes(rnd.randrange(1, 90)) for _ in range(120)]
+    seen = set()
+    for m in msgs:
+        for k in (0, 1):
+            out = ctypes.create_string_buffer(96)
+            rc = host_harness.ht_bls_sw_x(m, len(m), k, out)
+            assert rc == 3, (m, k, rc)                      # H2C_SW, same point as the 32-bit form, no column overflow
+            seen.add(bytes(out.raw))
+    assert len(seen) == 2 * len(msgs)

@@ -171,6 +171,9 @@ def main():
         o += arr("RX_TO", lim(Rp * Rp * pow(R, -1, p) % p))
         # 32-bit Montgomery multiplier: (x R' mod p as an integer) * BACK / R = x R
         o += arr("RX_BACK", limbs(R * R * pow(Rp, -1, p) % p, L))
+        # round 6: (x R' in the carry-free form) * RX_TOM / R' = x R as a PLAIN integer in W-bit limbs: the library's 32-bit Montgomery residue after
+        # one carry-free product and a repacking (from_ux_inl pays a 32-bit Montgomery product for the same conversion)
+        o += arr("RX_TOM", lim(R % p))
         # Fat multiples of p for limb-wise negation: FAT[k-1] has limbs 0..N-2 in [k 2^28, (k+1) 2^28) and a top limb >= TOPK * k,
         # so FAT_k - b has non-negative limbs for every b with limbs below k 2^28 and value below k * RX_FAT_VB * p
         top_p = p >> (W * (N - 1))
@@ -323,6 +326,12 @@ def main():
         assert ec_mul(g1k, cof) == (g1x, g1y)
         o += arr("G1KX", limbs(M(g1k[0]), L)) + arr("G1KY", limbs(M(g1k[1]), L))
         o += arr("R3", limbs((1 << (32 * L)) ** 3 % p_bls, L))    # to Montgomery-convert a 2L-limb value: redc(wide) * R3
+        # the Shallue-van de Woestijne constants in the carry-free form (k_bls_sw_jacobi's fractions, round 6): 1 + b, Z = (-1 + sqrt(-3)) / 2, sqrt(-3), times R' = 2^392
+        Rp = 1 << (28 * 14)
+        l28 = lambda v: [(v >> (28 * i)) & ((1 << 28) - 1) for i in range(14)]
+        o += arr("RX_SW_U0", l28(5 * Rp % p_bls)) + arr("RX_SW_Z", l28(z_sw * Rp % p_bls)) + arr("RX_SW_S3", l28(sqrt_m3 * Rp % p_bls))
+        # t = (lo + hi 2^384) mod p from the 512-bit digest in one two-product reduction: lo R'^2 + hi (R'^2 2^384), over R'
+        o += arr("RX_SW_H384", l28(Rp * Rp * (1 << 384) % p_bls))
         return o
 
     f2bn = F2(p_bn)
