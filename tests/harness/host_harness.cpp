@@ -448,19 +448,21 @@ static int rx_pow(int op, uint8_t* bytes, i32* limbs) {
 // h2c_x.hpp: one Shallue-van de Woestijne work item on the carry-free limbs (what k_bls_sw_jacobi runs per lane) against h2c.hpp's 32-bit form of
 // curves/hash.go:97-167.  out: the affine point (96 bytes) of the carry-free path.  Returns the kind (0..3) when both agree, -1 on a different
 // kind, -2 on a different point, -3 on a column overflow.
-extern "C" int ht_bls_sw_x(const uint8_t* msg, size_t len, int k, uint8_t* out) {
+static int bls_sw_x_digest(const u32 (&d)[16], uint8_t* out) {
   typedef BLS381 C;
   g_rx_overflow = 0;
-  u32 d[16];
-  bls_h2c_digest(msg, len, k, d);
   static thread_local i32 tab[4 * C::RX_NL];
   auto ld = [&](int e, int i) { return tab[e * C::RX_NL + i]; };
   auto st = [&](int e, int i, i32 v) { tab[e * C::RX_NL + i] = v; };
   Jac<F1<C>> pt;
   const u32 kind = bls_sw_jac_x<3, true>(d, pt, ld, st);
   if (g_rx_overflow) return -3;
-  Fp<C> tm;
-  const Fp<C> t = bls_h2c_t(msg, len, k, tm);
+  // the 32-bit form from the same digest, as bls_h2c_t: (lo + hi 2^384) mod q
+  Fp<C> lo, hi = fp_zero<C>();
+  for (int j = 0; j < 12; ++j) lo.v[j] = d[15 - j];
+  for (int j = 0; j < 4; ++j) hi.v[j] = d[3 - j];
+  const Fp<C> tm = fp_add<C>(fp_mul<C>(lo, fp_load<C>(C::R2)), fp_mul<C>(hi, fp_load<C>(C::R3)));
+  const Fp<C> t = fp_from_mont<C>(tm);
   u32 want = H2C_SW;
   if (fp_is_zero<C>(t)) want = H2C_INF;
   else if (fp_eq<C>(t, fp_load<C>(C::FT_ROOT1))) want = H2C_PLUS_G1;
@@ -472,6 +474,17 @@ extern "C" int ht_bls_sw_x(const uint8_t* msg, size_t len, int k, uint8_t* out) 
   g1_to_bytes<C>(out, got);
   if (got.inf != ref.inf || !fp_eq<C>(got.x, ref.x) || !fp_eq<C>(got.y, ref.y)) return -2;
   return (int)kind;
+}
+extern "C" int ht_bls_sw_x(const uint8_t* msg, size_t len, int k, uint8_t* out) {
+  u32 d[16];
+  bls_h2c_digest(msg, len, k, d);
+  return bls_sw_x_digest(d, out);
+}
+// the same from a given 64-byte digest (big-endian, as BLAKE2b writes it): the degenerate t = 0, +-sqrt(-5) and unreduced values no message reaches
+extern "C" int ht_bls_sw_x_digest(const uint8_t* digest, uint8_t* out) {
+  u32 d[16];
+  for (int i = 0; i < 16; ++i) d[i] = ((u32)digest[4 * i] << 24) | ((u32)digest[4 * i + 1] << 16) | ((u32)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+  return bls_sw_x_digest(d, out);
 }
 extern "C" int ht_rx_pow(int curve, int op, uint8_t* bytes, i32* limbs) {
   return curve == 0 ? rx_pow<BN254>(op, bytes, limbs) : (curve == 2 ? rx_pow<BN254W>(op, bytes, limbs) : rx_pow<BLS381>(op, bytes, limbs));

@@ -38,6 +38,14 @@ int main() {
   const uint8_t msg[5] = {'b', 'g', 'l', 's', 0};
   CHECK(ht_hash_to_g1(0, msg, 5, out) == 0);
   CHECK(ht_hash_to_g1(1, msg, 5, out) == 0);
+  // k_bls_sw_jacobi's work item on the carry-free limbs (h2c_x.hpp), both tags, and an all-ones digest
+  CHECK(ht_bls_sw_x(msg, 5, 0, out) == 3);
+  CHECK(ht_bls_sw_x(msg, 5, 1, out) == 3);
+  {
+    uint8_t dg[64];
+    memset(dg, 0xFF, sizeof(dg));
+    CHECK(ht_bls_sw_x_digest(dg, out) == 3);
+  }
   // consumer arithmetic on worst-case limbs (every limb at its bound)
   for (int cid = 0; cid < 3; ++cid) {
     const int N = cid == 0 ? 10 : (cid == 1 ? 14 : 9), W = cid == 2 ? 29 : 28;

@@ -368,3 +368,27 @@ def test_bls_sw_item_on_carry_free_limbs(host_harness):
             assert rc == 3, (m, k, rc)                      # H2C_SW, same point as the 32-bit form, no column overflow
             seen.add(bytes(out.raw))
     assert len(seen) == 2 * len(msgs)
+
+
+def test_bls_sw_item_degenerate_and_unreduced_digests(host_harness):
+    """t = digest mod q with the digest read as a 512-bit big-endian integer: the kinds no message reaches (t = 0, t = +-sqrt(-5): curves/hash.go:109-118
+    via bls12FTRoot1 / 2, curves/bls12_381.go:345-346) and digests far above q, all through the one two-product reduction of h2c_x.hpp."""
+    host_harness.ht_bls_sw_x_digest.restype = ctypes.c_int
+    host_harness.ht_bls_sw_x_digest.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    p = CURVES["bls12"].p
+    root = pow(-5, (p + 1) // 4, p)
+    assert root * root % p == p - 5
+    roots = sorted([root, p - root])
+
+    def kind(v):
+        out = ctypes.create_string_buffer(96)
+        return host_harness.ht_bls_sw_x_digest(v.to_bytes(64, "big"), out)
+
+    top = (1 << 512) - 1
+    assert kind(0) == 0 and kind(p) == 0 and kind(p * (top // p)) == 0                  # H2C_INF
+    got = {kind(roots[0]), kind(roots[1])}
+    assert got == {1, 2}                                                                # +g1 / -g1, whichever root is FT_ROOT1
+    assert kind(roots[0] + 7 * p) == kind(roots[0]) and kind(roots[1] + p * ((top - roots[1]) // p)) == kind(roots[1])
+    rnd = random.Random(9)
+    for v in [1, 2, p - 1, p + 1, top, top - 1, (1 << 384) - 1, 1 << 384, (1 << 384) + 1, 1 << 511] + [rnd.getrandbits(512) for _ in range(40)]:
+        assert kind(v) == 3, hex(v)                                                     # H2C_SW, same point as the 32-bit form, no column overflow
