@@ -28,7 +28,7 @@
 // instruction (carry add, re-zeroed addend) -- here every dot product is bare v_mad_u64_u32 into 64-bit columns; a producer
 // lane holding a whole G2 point plus three piles (256 registers, 150-650 spilled) -- here half a point and one pile.
 //
-// Work per pairing in units of NL^2 multiplier instructions (NL = 10 / 14): producer 2 x (28 per doubling, 39 per
+// Work per pairing in units of NL^2 multiplier instructions (NL = 10 / 14): producer 2 x (27 per doubling since round 6 -- 3 E^2 as a square: 53.8 -> 53.5 ms alt-bn128, 82.8 -> 82.0 ms BLS12-381 per 2^20 pairings, same box -- 39 per
 // addition step), consumer 66 per line + 84 / 6 per squaring (round 4: the squaring's cross terms in the Karatsuba form, rx.hpp).  Same line coefficients and the same product order as the
 // other kernels: the partial products are bit-identical to k_miller_ab64's.
 //

@@ -122,24 +122,30 @@ RX_DEV Sx<C, SX_T> pair_sqrsub(const Sx<C, LG>& g, const Sx<C, LE>& e, const Sx<
     return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -pair_even1(f.v[i], odd) : -pair_odd1(f.v[i], odd));
   });
 }
-// own half of g^2 - 3 e^2, one reduction: pair_sqrsub(g, e, 3 e) with the multiple formed in the ROW factors, so that 3 e never
-// occupies NL registers next to e (round 5: the doubling step's register peak sits on this product; BLS12-381 spilled there)
+// own half of g^2 - 3 e^2, one reduction over TWO products (round 6; rounds 3-5 formed e * 3 e as a general product: two column factors, NL^2
+// multiplier instructions more per lane and doubling step).  Both are squares: own half of a^2 = (a0 + a1)(a0 - a1) | (2 a1) a0, so the column factors
+// are g + its odd-lane half and e + its odd-lane half, the row factors g0 - g1 | g0 and -3 (e0 - e1) | -3 e0 -- the multiple formed in the ROW factors,
+// so that 3 e never occupies NL registers next to e (round 5: the doubling step's register peak sits on this product; BLS12-381 spilled there).
 template <class C, int LG, int LE>
 RX_DEV Sx<C, SX_T> pair_sqrsub3(const Sx<C, LG>& g, const Sx<C, LE>& e, bool odd) {
   // Budget (units 2^(2W-8)): g is one parallel carry step behind a sum (limbs in (-2^4, 2^W + 2^4)), so the sum g0 + g1 stays below
   // 2 (2^W + 2^4) and the difference g0 - g1 inside +-(2^W + 2^5): 512.0002 units, counted as 513, where the bounds' product
-  // (2 * 17) * (2 * 17) would say 1156 -- with that BLS12-381's fourteen rows of 3 e^2 (1536 units) would not fit.
-  static_assert(LG <= SX_F, "g: a reduction's output or one carry step behind a sum");
+  // (2 * 17) * (2 * 17) would say 1156.  e is a reduction's (or the centred quasi-reduction's) output: limbs 0 .. NL-2 in [0, 2^W), so e0 + e1 is
+  // below 2 * 2^W and e0 - e1 inside +-2^W: 3 * (2 LE) * LE units.
+  static_assert(LG <= SX_F && LE <= SX_T, "g: a reduction's output or one carry step behind a sum; e: a reduction's output");
   constexpr int BUDGET = 513 + 6 * LE * LE;
-  static_assert(rx_fits<C>(BUDGET), "three products per reduction: 28-bit forms");
+  static_assert(rx_fits<C>(BUDGET), "two squares per reduction: 28-bit forms");
   Sx<C, 2 * LG> u;
+  Sx<C, 2 * LE> w;
 #pragma unroll
-  for (int i = 0; i < C::RX_NL; ++i) u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
+  for (int i = 0; i < C::RX_NL; ++i) {
+    u.v[i] = g.v[i] + pair_odd1(g.v[i], odd);
+    w.v[i] = e.v[i] + pair_odd1(e.v[i], odd);
+  }
   const i32 even = odd ? 0 : -1;
-  const Sx<C, LE> pe = pair_swap_neg_even<C>(e, odd);
-  const i32* const cols[3] = {u.v, e.v, pe.v};
-  return sx_montr<C, 3, BUDGET>(cols, [&](int k, int i) {
-    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : (k == 1 ? -3 * pair_even1(e.v[i], odd) : -3 * pair_odd1(e.v[i], odd));
+  const i32* const cols[2] = {u.v, w.v};
+  return sx_montr<C, 2, BUDGET>(cols, [&](int k, int i) {
+    return k == 0 ? pair_even1(g.v[i], odd) - (pair_odd1(g.v[i], odd) & even) : -3 * (pair_even1(e.v[i], odd) - (pair_odd1(e.v[i], odd) & even));
   });
 }
 // 3 b' z of the doubling step.  alt-bn128: a product by the constant (3 b' = 9 / (9 + i) is a full-size element).  BLS12-381: 3 b' = 12 (1 + i)
@@ -173,7 +179,7 @@ struct PointX {
 // 29-bit form (BN254W): the column budget holds TWO products of near-tight factors per reduction, so every factor that is a sum or
 // a multiple goes through one parallel carry step first (sx_normf: three instructions per limb) and the two results that the 28-bit
 // forms reduce lazily as differences of products (Y3 here, Y3 and the P-free line coefficient of the addition) are reduced apart
-// and subtracted: one reduction more per doubling step (29 units of NL^2 = 81 multiplier instructions against 28 of 100), two more
+// and subtracted: one reduction more per doubling step (28 units of NL^2 = 81 multiplier instructions against 27 of 100 / 196), two more
 // per addition step (41 against 39).  Same values mod p at every step, hence the same lines.
 template <class C, class T>
 RX_DEV auto rx_nf(const T& a) {              // one carry step where the form has no head-room for the raw sum
@@ -193,7 +199,7 @@ RX_DEV void dbl_step_x(PointX<C>& R, Env&& env, bool odd, Emit&& emit) {
   const Sx<C, SX_F> G = sx_normf<C>(sx_half<C>(sx_add<C>(B, Fv)));
   // G^2 - 3 E^2: the step's register peak (Z3 and I come after it).  The 28-bit forms take 3 E in the row factors, so that Fv is dead here.
   if constexpr (rx_lazy<C>) R.Y = pair_sqrsub3<C>(G, E, odd);
-  else R.Y = sx_norm<C>(sx_sub<C>(pair_sqr<C>(G, odd), pair_mul<C>(E, Fv, odd)));
+  else R.Y = sx_norm<C>(sx_sub<C>(pair_sqr<C>(G, odd), sx_mulc<3, C>(pair_sqr<C>(E, odd))));      // 3 E^2 as a square (round 6; E * 3 E before)
   const auto I = sx_sub<C>(E, B);
   R.Z = pair_mul<C>(B, H, odd);
   // the line, last: its coefficients go straight from registers to the hand-over
