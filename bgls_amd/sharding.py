@@ -15,10 +15,16 @@ def shard_range(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
+def _solo(world):
+    """world == 1 without a process group: nothing to exchange.  With a group of ONE rank the collectives are still issued (copies
+    inside the backend): that is how the RCCL code path runs on a one-GPU box (tests/test_gpu_rccl_world1.py)."""
+    return world == 1 and not (dist.is_available() and dist.is_initialized())
+
+
 def all_gather_bytes(part, world):
     """part: 1-D uint8 tensor (on the device of the default process group's backend).
     Returns a [world, len] uint8 tensor holding every rank's bytes in rank order."""
-    if world == 1:
+    if _solo(world):
         return part.reshape(1, -1).clone()
     if part.is_cuda and dist.get_backend() == "gloo":       # development runs that share one GPU: stage through the host
         host = torch.empty(world * part.numel(), dtype=torch.uint8)
@@ -86,7 +92,7 @@ def digest_slot_records(n_local, world):
 
 def all_to_all_bytes(send, world):
     """send: uint8[world * chunk], chunk r goes to rank r.  Returns uint8[world * chunk]: chunk r came from rank r."""
-    if world == 1:
+    if _solo(world):
         return send.clone()
     if send.is_cuda and dist.get_backend() == "gloo":       # development runs that share one GPU: stage through the host
         host = torch.empty(send.numel(), dtype=torch.uint8)
@@ -129,7 +135,7 @@ def global_duplicate_scan(scan, msgs, n_local, world, digest=None, msg_len=64, p
     bytes -- and `probe` is handed those records (bgls_duplicate_scan_packed_dev; its bool must include an overflow reported by
     `pack`).  EVERY rank must pass the same digest / probe / rank-or-None / pack choice: the collectives are entered in the same
     order on all of them.  Returns None when the digests prove that there is no duplicate, otherwise what `scan` returns."""
-    if world == 1:
+    if _solo(world):
         return scan(msgs, msg_len, n_local)
     if digest is not None and probe is not None:
         _check_probe(probe, rank, world)                       # before any collective
