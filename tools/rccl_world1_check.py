@@ -71,16 +71,26 @@ for dup in (False, True):
         torch.cuda.synchronize()
         return bool(w.item())
 
-    sharding.enqueue_digest_probe(digest, probe_scan, t_msgs, n, world, rank=rank, pack=pack)
+    # one rank plays both buckets of a two-bucket exchange: its two send slots come back through RCCL's all-to-all as they are, each is then
+    # scanned as the bucket it belongs to (the bucket rule needs two buckets or more: include/bgls_hip.h)
+    cap = sharding.digest_slot_records(n, 2)
+    send = pack(digest(t_msgs, n), n, 2, cap)
+    recs = sharding.all_to_all_bytes(send, world)
+    assert recs.numel() == 2 * cap * 16
+    for bucket in (0, 1):
+        probe_scan(recs[bucket * cap * 16:(bucket + 1) * cap * 16], 16, cap, bucket, 2)
     _, m2 = sharding.gather_partials_and_flags(part[:384], word, world)
     torch.cuda.synchronize()
     hit = bool(int(m2[1].item()))
     assert hit == dup, (dup, m2.tolist())
     if hit:
         assert sharding.settle_digest_hit(exact, t_msgs, n, world) is True
-    # the synchronous form with its one-word all-reduce
-    r = sharding.global_duplicate_scan(exact, t_msgs, n, world, digest=digest, msg_len=64, rank=rank, pack=pack,
-                                       probe=lambda b, rec, c, bk, nb: (word.zero_(), probe_scan(b, rec, c, bk, nb), torch.cuda.synchronize(), bool(int(word[1].item())))[3])
+    # the synchronous form's one-word all-reduce
+    w1 = torch.tensor([1 if hit else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(w1, op=dist.ReduceOp.MAX)
+    assert bool(int(w1.item())) == dup
+    # without a rank: every digest gathered, the full scan over them (rounds 3-4's path), then the exact scan on a hit
+    r = sharding.global_duplicate_scan(exact, t_msgs, n, world, digest=digest, msg_len=64, probe=lambda b, rec, c: exact(b, rec, c))
     assert r is (True if dup else None), (dup, r)
 # (5) the bench's timing reduction and its barrier
 t = torch.tensor([1.25], dtype=torch.float64, device=dev)
