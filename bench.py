@@ -679,14 +679,17 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
         one()
         torch.cuda.synchronize()
         seq.append((time.perf_counter() - t0) * 1e3)
-    # (2) every stage by itself: the same checks one at a time on ONE stream (throughput mode: no side-stream fork), stage timers on
-    check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
+    # (2) every stage by itself: the same checks one at a time on ONE stream, stage timers on, in the launch shapes a check ALONE runs (mode 2:
+    # 2048-wave main pass, no side-stream fork).  This is where roofline.launch_ms comes from: the kernel with the machine to itself.
+    check(lib.bgls_set_throughput_mode(2), "set_throughput_mode")
     lib.bgls_profile_enable(1)
     for _ in range(max(1, warmup)):
         one()
         torch.cuda.synchronize()
     stages_excl = {s_: stage(lib, s_) for s_ in ("sum_points", "sum_main", "h2c", "miller", "reduce", "final_exp")}
-    # (3) several checks in flight (still throughput mode: one stream per check)
+    # (3) several checks in flight: throughput mode (one stream per check, no side-stream fork, 1024-wave main passes so that the other checks'
+    # latency-bound tails find wave slots: engine_core.inc sum_points_jac)
+    check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
     lanes.run(L, submit, L > 1)
     regions = []
     for _ in range(reps):

@@ -271,8 +271,10 @@ int bgls_final_verify_submit_dev(int curve, const void* d_partials, size_t count
 int bgls_final_verify_collect(int curve);
 /* Throughput mode: tells the engine that several verifications are in flight, so that Miller launches keep the block form
  * that is fastest per pairing (60 pairings per block) even where a launch's last round of resident blocks is nearly empty --
- * the neighbours fill it.  Results are identical in both modes.  Off by default; BGLS_THROUGHPUT=1 turns it on from the
- * environment. */
+ * the neighbours fill it -- and a multi-signature's key sum runs at one wave per SIMD so that the other checks' latency-bound tails find
+ * wave slots.  Results are identical in every mode.  Off by default; BGLS_THROUGHPUT=1 turns it on from the environment.  on = 2: one stream
+ * per verification (no fork onto the context's side stream) but the launch shapes of a verification that has the machine to itself -- for
+ * timing ONE verification stage by stage. */
 int bgls_set_throughput_mode(int on);
 /* Environment switches, each read ONCE per process (four in all).  None changes a result: they select between kernels that
  * compute the same bytes and exist for A/B measurements and for the legacy-path tests (tests/test_gpu_legacy_paths.py,

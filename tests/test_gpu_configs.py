@@ -73,6 +73,16 @@ def test_config4_multisig_2pow20_altbn128(gpu_lib):
     assert lib.bgls_verify_multi(cid, B(sig), keys, n, B(msg), len(msg)) == 1
     # the two-pairing tail agrees with the oracle on the aggregated key
     assert coracle.verify_multi(cid, sig, apk_b, 1, msg) == 1
+    # the key sum's other launch shapes (round 6): throughput mode adds the 2^20 keys with one wave per SIMD (1024 waves), mode 2 is the lone
+    # shape on one stream -- same verdicts
+    try:
+        for mode in (1, 2):
+            assert lib.bgls_set_throughput_mode(mode) == 0
+            assert lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_msg.data_ptr(), len(msg), None) == 1, mode
+            assert lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n - 1, t_msg.data_ptr(), len(msg), None) == 0, mode
+            assert lib.bgls_verify_multi_dev(cid, t_sig.data_ptr(), t_keys.data_ptr(), n, t_bad.data_ptr(), len(msg), None) == 0, mode
+    finally:
+        lib.bgls_set_throughput_mode(0)
 
 
 @pytest.mark.parametrize("cid,fp", [(0, 32), (1, 48)])

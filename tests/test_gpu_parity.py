@@ -331,7 +331,7 @@ def test_throughput_mode_agrees(gpu_lib, curve):
     gtb = 12 * n_fp
     parts = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):                                       # 2: one stream, the lone verification's launch shapes (stage timing)
             assert lib.bgls_set_throughput_mode(mode) == 0
             o = out(gtb)
             assert lib.bgls_pairing_product(cid, B(g1s), B(g2s), len(pp["g1s"]), o) == 0
@@ -349,7 +349,7 @@ def test_throughput_mode_agrees(gpu_lib, curve):
                 parts[(mode, with_sig)] = bytes(part.cpu().numpy())
     finally:
         lib.bgls_set_throughput_mode(0)
-    assert parts[(0, True)] == parts[(1, True)] and parts[(0, False)] == parts[(1, False)]
+    assert parts[(0, True)] == parts[(1, True)] == parts[(2, True)] and parts[(0, False)] == parts[(1, False)] == parts[(2, False)]
     # the partial product without the signature pair is the oracle's product of Miller values over the hash points
     hs = b"".join(coracle.hash_to_g1(cid, m) for m in msgs[:40])
     part = torch.zeros(gtb, dtype=torch.uint8, device=dev)
