@@ -689,7 +689,7 @@ def bench_multisig(lib, dev, inst, n, steps, warmup, reps, in_flight, key_set=Fa
     stages_excl = {s_: stage(lib, s_) for s_ in ("sum_points", "sum_main", "h2c", "miller", "reduce", "final_exp")}
     # (3) several checks in flight: throughput mode (one stream per check, no side-stream fork, 1024-wave main passes so that the other checks'
     # latency-bound tails find wave slots: engine_core.inc sum_points_jac)
-    check(lib.bgls_set_throughput_mode(1), "set_throughput_mode")
+    check(lib.bgls_set_throughput_mode(1 if L > 1 else 2), "set_throughput_mode")       # --in-flight 1 (the profile runs): one at a time, the lone shapes
     lanes.run(L, submit, L > 1)
     regions = []
     for _ in range(reps):
