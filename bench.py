@@ -973,7 +973,7 @@ def main():
             small_n = min(1 << 16, args.n)
             for c_, i_ in ((cid, inst), (other, oinst)):
                 i_["n_local"] = small_n
-                records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 48, 12, args.reps, max(args.in_flight, 12), tp, CNAME[c_] + " 2^16")
+                records["%s_%d" % (CNAME[c_], small_n)] = bench_aggregate(lib, dev, i_, small_n, 0, 1, 64, 16, args.reps, max(args.in_flight, 16), tp, CNAME[c_] + " 2^16")
                 i_["n_local"] = i_["n"]
             for c_, i_ in ((cid, inst), (other, oinst)):      # the same batches against prepared key sets (secondary records, labelled)
                 records["%s_%d_prepared_keys" % (CNAME[c_], args.n)] = bench_aggregate(lib, dev, i_, args.n, 0, 1, max(2, args.steps // 2), 1, args.reps, args.in_flight,

@@ -38,7 +38,7 @@ lm, fr, fc = roof(b)
 rows.append("| **BLS12-381, 2²⁰** (config 5 on one GPU) | **%s M pairs/s** (r5: 10.53) | %s | `k_miller_x60<BLS381, 0, 60>` **%s ms** (rocprof, %d calls): `frac` %s, `frac_cycles` %s; `k_bls_sw_jacobi` 16.8 ms per 2²⁰ messages |"
             % (f(b["value"] / 1e6), f(b["ms_per_step"], 1), f(bls_ms, 2) if bls_ms else "n/a", bls_calls, f(fr), f(fc) if fc else "n/a"))
 a16, b16 = r["altbn128_65536"], r["bls12_65536"]
-rows.append("| config 2 / 3: 2¹⁶ (12 in flight) | %s / %s M pairs/s | %s / %s | lone 64-form launches: `frac` %s / %s |"
+rows.append("| config 2 / 3: 2¹⁶ (16 in flight) | %s / %s M pairs/s | %s / %s | lone 64-form launches: `frac` %s / %s |"
             % (f(a16["value"] / 1e6, 1), f(b16["value"] / 1e6, 1), f(a16["ms_per_step"]), f(b16["ms_per_step"]), f(roof(a16)[1]), f(roof(b16)[1])))
 pa, pb = r["altbn128_1048576_prepared_keys"], r["bls12_1048576_prepared_keys"]
 rows.append("| prepared key sets, 2²⁰ (secondary: keys' line functions resident, 17.7 / 18.5 GB) | **%s / %s M pairs/s** (r5: 29.3 / 14.2) | %s / %s | `k_fold_prep` on the carry-free limbs (round 6): `frac` %s / %s of the probe peak on its own work model |"
