@@ -913,6 +913,7 @@ def main():
     ap.add_argument("--only", default=None, choices=["aggregate", "multisig", "multisig_batch", "small"], help="run ONE record (profiling runs): --curve, --n apply")
     ap.add_argument("--no-records", action="store_true", help="headline only")
     ap.add_argument("--prepared", action="store_true", help="with --only aggregate: verify against a prepared key set")
+    ap.add_argument("--x60-mode", type=int, default=None, help="development: bgls_set_miller_shape(4, MODE) -- role / priority / block-form word of k_miller_x60")
     ap.add_argument("--key-set", action="store_true", help="with --only multisig: the keys are a resident key set (bgls_keys_upload) instead of wire bytes")
     args = ap.parse_args()
 
@@ -933,6 +934,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     check(lib.bgls_init(local_rank), "bgls_init")
+    if args.x60_mode is not None:
+        check(lib.bgls_set_miller_shape(4, args.x60_mode), "set_miller_shape")
     tp = not args.no_throughput_mode
 
     def shard_instance(cid, n_total, seed):
