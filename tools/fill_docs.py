@@ -56,7 +56,7 @@ cpu = d.get("cpu_baseline") or {}
 table = ("| Record | value | ms / step | dominant kernel, exclusive `frac` (algorithmic MACs of one launch ÷ its duration ÷ peak) |\n|---|---|---|---|\n" + "\n".join(rows) +
          "\n\nCPU beside it (`cpu_baseline`, the C oracle in the reference's parallel shape on the GPU box's host): %s pairs/s alt-bn128 on %s threads of %s host cores (%s ms per pairing on one core)."
          % (f(cpu.get("value", 0), 0), cpu.get("cores"), cpu.get("host_cores"), f(cpu.get("per_core_ms_per_pairing", 0))) +
-         "  GPU tier: `profiles/r6/pytest_gpu.log`.")
+         "  GPU tier: `profiles/r6/pytest_gpu.log`; randomised soak against expectations and the C oracle: `profiles/r6/soak.txt`.")
 # idempotent: the generated pieces sit between markers and are replaced as a whole on every run
 s = open("DESIGN.md").read()
 s = re.sub(r"<!-- R6TAB_BEGIN \(tools/fill_docs.py\) -->.*?<!-- R6TAB_END -->", lambda m: "<!-- R6TAB_BEGIN (tools/fill_docs.py) -->\n" + table + "\n<!-- R6TAB_END -->", s, flags=re.S)
